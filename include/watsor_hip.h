@@ -1,0 +1,154 @@
+/* libwatsor_hip.so -- C ABI of the MI355X detection backend for Watsor.
+ *
+ * The reference has no FFI on this path: the boundary is a duck-typed Python plugin
+ * (`watsor/detection/tensorflow_cpu.py:13,64-92`, `watsor/detection/tensorrt_gpu.py:20,55-91`)
+ * driven by `ObjectDetector._next_frame` (`watsor/detection/detector.py:102-112`).  This header is
+ * what sits *behind* the Python class `watsor_amd.detection.hip_gpu.HipObjectDetector`: plain
+ * pointers and sizes, no torch / numpy types.  Every entry point names the reference code it
+ * stands in for.  INTEGRATION.md shows the ctypes binding and the two-line change in
+ * `watsor/detection/detector.py` that enables it.
+ *
+ * Conventions: all functions return 0 on success or a negative WZ_E* code; `wz_last_error()`
+ * returns a human readable message for the calling thread's last failure.  One engine = one GPU
+ * = one HIP stream; calls on one engine must be serialised by the caller (the reference worker
+ * is sequential per detector instance, detector.py:84-112).  Host frames are packed RGB24, HWC,
+ * C-contiguous (`Frame.get_numpy_image`, watsor/stream/share.py:68-73); they are read only and
+ * not retained past the call.
+ */
+#ifndef WATSOR_HIP_H
+#define WATSOR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WZ_MAX_DETECTIONS 100 /* Header.detections length, watsor/stream/share.py:31 */
+#define WZ_MAX_ZONES 10       /* Detection.zones length,   watsor/stream/share.py:22 */
+#define WZ_NUM_LABELS 91      /* len(COCO_CLASSES),        watsor/config/coco.py:14-106 */
+
+#define WZ_OK 0
+#define WZ_EINVAL (-1)   /* bad argument */
+#define WZ_ENOENT (-2)   /* engine file missing  -> Python raises FileNotFoundError (detector.py:97-98) */
+#define WZ_EFORMAT (-3)  /* engine file corrupt / wrong version */
+#define WZ_EHIP (-4)     /* HIP runtime error (message has the hipError string) */
+#define WZ_ENODEV (-5)   /* no such GPU */
+#define WZ_ELIMIT (-6)   /* batch / resolution / camera id beyond what wz_create() reserved */
+
+/* Byte-for-byte `Detection` of watsor/stream/share.py:11-25 (72 bytes; label@0 zones@4
+ * confidence@48 bounding_box@56).  Rows are written in place. */
+typedef struct wz_detection {
+    int32_t label;
+    int32_t zones[WZ_MAX_ZONES];
+    int32_t _pad;
+    double confidence;
+    int32_t x_min, y_min, x_max, y_max;
+} wz_detection_t;
+
+typedef struct wz_engine wz_engine_t;
+
+/* ---- device enumeration: what `cuda_gpus()` does with pycuda (watsor/detection/devices.py:28-77) */
+int wz_device_count(void);
+int wz_device_name_of(int device, char* buf, int buflen);
+
+/* ---- lifecycle: TensorRTObjectDetector.__init__/__exit__ (tensorrt_gpu.py:20-53,62-63)
+ * engine_path: file written by `python -m watsor_amd.engine` (the analogue of gpu.trt).
+ * max_batch frames per call, each at most max_width x max_height. */
+int wz_create(const char* engine_path, int device, int max_batch, int max_width, int max_height,
+              wz_engine_t** out);
+void wz_destroy(wz_engine_t* e);
+const char* wz_device_name(wz_engine_t* e);          /* plugin property `device_name` */
+const char* wz_last_error(void);
+
+/* ---- the hot call: `detect(image_shape, image_np, detections) -> ms`
+ * (tensorflow_cpu.py:74-92 / tensorrt_gpu.py:65-91) for n frames at once.
+ *   rgb[i]   host pointer to frame i (h[i] x w[i] x 3 uint8)
+ *   cam[i]   camera id whose filter (wz_set_camera_filter) is applied to frame i, or -1; cam may be NULL
+ *   out[i]   100 Detection rows of frame i, ALL rewritten (rows past the detections carry label 1,
+ *            confidence 0, box 0 exactly like the TF graph's zero padding + label offset)
+ *   pass[i]  optional (may be NULL / pass may be NULL): 100 bytes, 1 where the row survives
+ *            `label > 0 and Confidence and Area and Mask` (watsor/filter/track.py:26)
+ *   ms[i]    wall time of the batch in milliseconds (every frame of a batch reports the batch time)
+ */
+int wz_detect_batch(wz_engine_t* e, int n, const uint8_t* const* rgb, const int* w, const int* h,
+                    const int* cam, wz_detection_t* const* out, uint8_t* const* pass, float* ms);
+
+/* Same, frames already resident in this GPU's HBM (device pointers).  Split into an asynchronous
+ * submit (everything enqueued on the engine's stream, results land in pinned slot `slot`) and a
+ * collect that waits for that slot -- so a caller can keep WZ_SLOTS batches in flight. */
+#define WZ_SLOTS 4
+int wz_submit_device(wz_engine_t* e, int slot, int n, const uint8_t* const* d_rgb, const int* w,
+                     const int* h, const int* cam);
+int wz_collect(wz_engine_t* e, int slot, wz_detection_t* const* out, uint8_t* const* pass);
+/* Wait for `slot` without copying rows out (rows stay readable via wz_slot_rows). */
+int wz_wait(wz_engine_t* e, int slot);
+const wz_detection_t* wz_slot_rows(wz_engine_t* e, int slot); /* pinned host, [n][100] */
+int wz_sync(wz_engine_t* e);
+
+/* ---- per-camera filters on the GPU: ConfidenceFilter / AreaFilter / MaskFilter
+ * (watsor/filter/confidence.py:10-19, area.py:10-26, mask.py:17-59).
+ *   conf_thr[l]  confidence/100 for label l, NaN when the label is not configured (-> reject)
+ *   area_thr[l]  area/100 * (width*height) as the reference computes it, NaN when not configured
+ *   n_zones      number of zones of the camera's mask (0 = no mask -> Mask filter absent)
+ *   zone_allow   [WZ_NUM_LABELS][n_zones] bytes: 1 if label l may report zone z (mask.py:29-42);
+ *                NULL = every label sees every zone
+ *   zone_fill    [n_zones][height][width] bytes: 1 on the lattice points of zone z's polygon
+ *                (8-connected alpha==255 component with holes filled, ordered as mask.py:78-88)
+ */
+int wz_set_camera_filter(wz_engine_t* e, int cam, int width, int height, const double* conf_thr,
+                         const double* area_thr, int n_zones, const uint8_t* zone_allow,
+                         const uint8_t* zone_fill);
+int wz_clear_camera_filter(wz_engine_t* e, int cam);
+/* Run only the filter stage on caller-provided rows (host), in place: zones are written into the
+ * rows exactly where the reference's MaskFilter would have been invoked; pass[100] receives the verdict. */
+int wz_filter_rows(wz_engine_t* e, int cam, wz_detection_t* rows, uint8_t* pass);
+
+/* Host-side zone extraction from an alpha plane: MaskFilter.__init__ / find_contours / contours_key
+ * (mask.py:17-27,78-88) without OpenCV.  Writes up to max_zones filled-zone bitmaps ([z][h][w] bytes)
+ * ordered by the reference's centroid key and returns the zone count (or a negative error). */
+int wz_zones_from_alpha(const uint8_t* alpha, int width, int height, int max_zones, uint8_t* zone_fill,
+                        int32_t* centroid_xy /* [max_zones][2], may be NULL */);
+
+/* ---- introspection used by the engine CLI, bench.py (roofline) and the parity tests */
+int wz_input_size(wz_engine_t* e);
+int wz_num_anchors(wz_engine_t* e);
+int wz_num_classes(wz_engine_t* e);
+int wz_num_tensors(wz_engine_t* e);
+int wz_tensor_info(wz_engine_t* e, int idx, char* name, int namelen, int* h, int* w, int* c);
+int wz_num_ops(wz_engine_t* e);
+/* dims[12] = kind,cin,cout,ksize,stride,hin,win,hout,wout,n_pad,kc,splitk */
+int wz_op_info(wz_engine_t* e, int idx, char* name, int namelen, int* dims);
+int wz_num_stages(wz_engine_t* e);                              /* kernels per batch, pre + ops + post */
+int wz_stage_name(wz_engine_t* e, int stage, char* name, int namelen);
+/* Run the pipeline `reps` times on device frames with a hipEvent pair around every kernel launch
+ * (events on the engine's own stream); stage_ms[stage] = mean milliseconds of that launch. */
+int wz_profile_device(wz_engine_t* e, int n, const uint8_t* const* d_rgb, const int* w, const int* h,
+                      int reps, float* stage_ms);
+
+/* ---- device memory helpers so callers need no other GPU runtime binding */
+int wz_dev_alloc(wz_engine_t* e, uint64_t bytes, void** d_ptr);
+int wz_dev_free(wz_engine_t* e, void* d_ptr);
+int wz_dev_upload(wz_engine_t* e, void* d_dst, const void* h_src, uint64_t bytes);
+int wz_dev_download(wz_engine_t* e, void* h_dst, const void* d_src, uint64_t bytes);
+
+/* ---- stage-level entry points for the parity tests (host in, host out, synchronous) */
+/* resize + normalise of one frame -> half[size*size*4] (x,y,z,0 per pixel) */
+int wz_stage_preprocess(wz_engine_t* e, const uint8_t* rgb, int w, int h, uint16_t* out_half);
+/* network only: half input [n][size][size][4] -> float box encodings [n][A][4], logits [n][A][C] */
+int wz_stage_forward(wz_engine_t* e, int n, const uint16_t* in_half, float* box_enc, float* logits);
+/* read activation tensor `idx` of frame `frame` left behind by the last forward (half, NHWC).
+ * Only meaningful when the engine was created with WZ_NO_BUFFER_REUSE=1 in the environment. */
+int wz_stage_read_tensor(wz_engine_t* e, int idx, int frame, uint16_t* out_half);
+/* decode + sigmoid + NMS + top-k on caller-provided head outputs:
+ * boxes [n][100][4] (ymin,xmin,ymax,xmax), scores [n][100], classes [n][100] (1-based), num [n] */
+int wz_stage_postprocess(wz_engine_t* e, int n, const float* box_enc, const float* logits, float* boxes,
+                         float* scores, int32_t* classes, int32_t* num);
+/* row fill (tensorflow_cpu.py:79-90) for caller-provided detections of one frame of size w x h */
+int wz_stage_rows(wz_engine_t* e, int w, int h, const float* boxes, const float* scores,
+                  const int32_t* classes, wz_detection_t* rows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WATSOR_HIP_H */

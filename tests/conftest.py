@@ -1,0 +1,68 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+REFERENCE = "/root/reference"          # present in the build container only, never on the GPU box
+HAVE_REFERENCE = os.path.isdir(os.path.join(REFERENCE, "watsor"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "reference: needs /root/reference (build container only)")
+
+
+def pytest_collection_modifyitems(config, items):
+    skip_ref = pytest.mark.skip(reason="/root/reference not present")
+    for item in items:
+        if "reference" in item.keywords and not HAVE_REFERENCE:
+            item.add_marker(skip_ref)
+
+
+@pytest.fixture(scope="session")
+def reference_on_path():
+    if not HAVE_REFERENCE:
+        pytest.skip("/root/reference not present")
+    if REFERENCE not in sys.path:
+        sys.path.insert(0, REFERENCE)
+    return REFERENCE
+
+
+SEED = 1234
+
+
+@pytest.fixture(scope="session")
+def synth_weights():
+    from watsor_amd.synth import synthetic_weights
+    return synthetic_weights(SEED)
+
+
+@pytest.fixture(scope="session")
+def model_dir(synth_weights, tmp_path_factory):
+    """A model directory holding mi355x.bin built from the seeded synthetic weights."""
+    from watsor_amd import engine
+    d = tmp_path_factory.mktemp("model")
+    engine.save_engine(engine.build_engine(synth_weights), str(d / "mi355x.bin"))
+    return str(d)
+
+
+@pytest.fixture(scope="session")
+def oracle_net(synth_weights):
+    from oracle.ssd_mobilenet_v2 import OracleNet
+    return OracleNet(synth_weights)
+
+
+@pytest.fixture(scope="session")
+def frames_640():
+    from watsor_amd.synth import synthetic_frame
+    return [synthetic_frame(640, 480, SEED + i) for i in range(4)]
+
+
+def make_engine(model_dir, max_batch=8, max_width=1920, max_height=1080, device=0):
+    from watsor_amd.runtime import HipEngine
+    return HipEngine(os.path.join(model_dir, "mi355x.bin"), device, max_batch, max_width, max_height)

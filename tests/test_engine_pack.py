@@ -1,0 +1,141 @@
+"""Engine builder (watsor_amd/engine.py): file format, BN folding, MFMA fragment layout, buffer slots."""
+import struct
+
+import numpy as np
+import pytest
+
+from watsor_amd import arch, engine
+
+
+@pytest.fixture(scope="module")
+def blob(synth_weights):
+    return engine.build_engine(synth_weights)
+
+
+def parse(blob):
+    h = struct.unpack_from("<10I6f6Q12I", blob, 0)
+    hdr = dict(magic=h[0], version=h[1], precision=h[2], size=h[3], classes=h[4], anchors=h[5], n_tensors=h[6],
+               n_ops=h[7], max_total=h[8], max_per_class=h[9], score_thr=h[10], iou_thr=h[11], scales=h[12:16],
+               tensors_off=h[16], ops_off=h[17], anchors_off=h[18], weights_off=h[19], weights_bytes=h[20],
+               total=h[21], n_slots=h[22])
+    tensors = []
+    for i in range(hdr["n_tensors"]):
+        t = struct.unpack_from("<4i48s", blob, hdr["tensors_off"] + 64 * i)
+        tensors.append(dict(h=t[0], w=t[1], c=t[2], slot=t[3], name=t[4].split(b"\0")[0].decode()))
+    ops = []
+    keys = ("kind src dst res cin cout ksize stride hin win hout wout pad_t pad_l act out_mode anchor_off "
+            "anchors_per_loc n_pad kc").split()
+    for i in range(hdr["n_ops"]):
+        o = struct.unpack_from("<20i2q8i64s", blob, hdr["ops_off"] + 192 * i)
+        d = dict(zip(keys, o[:20]))
+        d.update(w_off=o[20], b_off=o[21], name=o[30].split(b"\0")[0].decode())
+        ops.append(d)
+    return hdr, tensors, ops
+
+
+def test_header(blob):
+    hdr, tensors, ops = parse(blob)
+    assert hdr["magic"] == engine.MAGIC and hdr["version"] == engine.FORMAT_VERSION
+    assert hdr["total"] == len(blob) and hdr["precision"] == 16 and hdr["size"] == 300
+    assert hdr["classes"] == 91 and hdr["anchors"] == 1917 and hdr["n_ops"] == 72
+    assert hdr["max_total"] == 100 and abs(hdr["iou_thr"] - 0.6) < 1e-7 and hdr["scales"] == (10.0, 10.0, 5.0, 5.0)
+    assert tensors[0]["name"] == "input" and tensors[0]["c"] == 4
+    assert sum(1 for o in ops if o["out_mode"] != arch.OUT_ACT) == 12
+
+
+def test_shapes_follow_tf_same_padding(blob):
+    _, tensors, ops = parse(blob)
+    by = {t["name"]: t for t in tensors}
+    assert (by["Conv"]["h"], by["Conv"]["c"]) == (150, 32)
+    assert (by["expanded_conv_1/depthwise"]["h"], by["expanded_conv_3/depthwise"]["h"]) == (75, 38)
+    assert (by["expanded_conv_13/expand"]["h"], by["expanded_conv_13/expand"]["c"]) == (19, 576)
+    assert (by["Conv_1"]["h"], by["Conv_1"]["c"]) == (10, 1280)
+    pads = {o["name"].split("/")[-2] if o["kind"] == arch.OP_DW else o["name"]: (o["pad_t"], o["pad_l"])
+            for o in ops if o["stride"] == 2}
+    assert pads["FeatureExtractor/MobilenetV2/Conv"] == (0, 0)          # 300 -> 150: pad only after
+    assert pads["expanded_conv_3"] == (1, 1)                            # 75 -> 38
+    assert pads["expanded_conv_6"] == (0, 0)                            # 38 -> 19
+    assert pads["expanded_conv_13"] == (1, 1)                           # 19 -> 10
+    heads = [o for o in ops if o["out_mode"] == arch.OUT_CLS]
+    assert [o["anchor_off"] for o in heads] == [0, 1083, 1683, 1833, 1887, 1911]
+
+
+def test_slots_never_alias_live_tensors(blob):
+    hdr, tensors, ops = parse(blob)
+    last = {}
+    for i, o in enumerate(ops):
+        last[o["src"]] = i
+        if o["res"] >= 0:
+            last[o["res"]] = i
+    born = {0: -1}
+    for i, o in enumerate(ops):
+        if o["dst"] >= 0:
+            born[o["dst"]] = i
+    for a in born:
+        for b in born:
+            if a < b and tensors[a]["slot"] == tensors[b]["slot"]:
+                # lifetimes [born, last] must be disjoint; an op's dst may not reuse its own inputs
+                assert last[a] < born[b] or last[b] < born[a], (tensors[a]["name"], tensors[b]["name"])
+    assert hdr["n_slots"] < len(tensors) // 4       # sharing actually happens
+
+
+def unpack_conv(blob, hdr, o):
+    taps = o["ksize"] ** 2
+    n = (o["n_pad"] // 16) * taps * o["kc"] * 512
+    w = np.frombuffer(blob, np.float16, n, hdr["weights_off"] + o["w_off"]).astype(np.float32)
+    w = w.reshape(o["n_pad"] // 16, taps, o["kc"], 4, 16, 8)            # [t][tap][c][g][r][j]
+    w = w.transpose(1, 2, 3, 5, 0, 4).reshape(taps, o["kc"] * 32, o["n_pad"])
+    return w
+
+
+def test_weight_fragments_round_trip(blob, synth_weights):
+    hdr, tensors, ops = parse(blob)
+    prog = arch.build()
+    for o, op in zip(ops, prog.ops):
+        wf, bf = engine.fold_batch_norm(synth_weights, op)
+        bias_n = o["n_pad"] if o["kind"] == arch.OP_CONV else op.cout
+        bias = np.frombuffer(blob, np.float32, bias_n, hdr["weights_off"] + o["b_off"])
+        np.testing.assert_array_equal(bias[:op.cout], bf.astype(np.float32))
+        if o["kind"] == arch.OP_CONV:
+            w = unpack_conv(blob, hdr, o)
+            ref = wf.reshape(op.k * op.k, op.cin, op.cout).astype(np.float32).astype(np.float16).astype(np.float32)
+            np.testing.assert_array_equal(w[:, :op.cin, :op.cout], ref)
+            assert not w[:, op.cin:, :].any() and not w[:, :, op.cout:].any() and not bias[op.cout:].any()
+        elif o["kind"] == arch.OP_DW:
+            w = np.frombuffer(blob, np.float16, 9 * op.cin, hdr["weights_off"] + o["w_off"]).reshape(9, op.cin)
+            np.testing.assert_array_equal(w, wf.reshape(9, op.cin).astype(np.float16))
+
+
+def test_fold_matches_oracle_fold(synth_weights):
+    from oracle import ssd_mobilenet_v2 as net
+    prog = arch.build()
+    spec = net.graph_spec()
+    assert len(spec) == len(prog.ops)
+    for s, op in zip(spec, prog.ops):
+        assert s.name == op.scope and s.cin == op.cin and s.cout == op.cout and s.stride == op.stride
+        w1, b1 = net.fold_bn(synth_weights, s)
+        w2, b2 = engine.fold_batch_norm(synth_weights, op)
+        np.testing.assert_allclose(w1, w2.astype(np.float32), rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(b1, b2.astype(np.float32), rtol=1e-6, atol=1e-7)
+
+
+def test_anchor_table_matches_oracle(blob):
+    from oracle import postprocess as post
+    hdr, _, _ = parse(blob)
+    a = np.frombuffer(blob, np.float32, 1917 * 4, hdr["anchors_off"]).reshape(1917, 4)
+    np.testing.assert_array_equal(a, post.anchors_center_size(post.generate_anchors()))
+
+
+def test_cli_and_errors(tmp_path, synth_weights):
+    np.savez(tmp_path / "m.npz", **synth_weights)
+    out = tmp_path / "model" / "mi355x.bin"
+    assert engine.main(["-i", str(tmp_path / "m.npz"), "-o", str(out), "-p", "16"]) == 0
+    assert out.stat().st_size > 30e6
+    with pytest.raises(FileNotFoundError):
+        engine.load_weights(str(tmp_path / "missing.npz"))
+    bad = dict(synth_weights)
+    bad.pop("FeatureExtractor/MobilenetV2/Conv/weights")
+    with pytest.raises(KeyError):
+        engine.build_engine(bad)
+    with pytest.raises(ValueError):
+        engine.build_engine(synth_weights, precision=32)

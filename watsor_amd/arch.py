@@ -1,0 +1,163 @@
+"""SSD-MobileNet-v2 300x300 as an *op program* for the MI355X engine.
+
+The reference never describes the network: it is whatever model file the user drops into
+`model/` (`watsor/detection/tensorflow_cpu.py:14-18,50-53`; README.md:446-451 names
+`ssd_mobilenet_v2_coco_2018_03_29`).  The engine builder (`watsor_amd/engine.py`, the
+analogue of `watsor/engine.py:17-58`) needs the topology to fold BatchNorm, pad channels and
+lay weights out for the HIP kernels, so it is spelled out here.
+
+A program is a list of `Op`s over named activation tensors (NHWC fp16 in HBM).  Variable
+names are the TF-slim / TF-OD-API names found in the frozen graph so that a real checkpoint
+(dict name -> array) can be packed by the same code path as the seeded synthetic weights.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+INPUT_SIZE = 300
+NUM_CLASSES = 91                      # class-head columns per anchor (column 0 = background)
+FE = "FeatureExtractor/MobilenetV2/"
+
+# op kinds understood by the runtime (keep in sync with csrc/wz_program.h)
+OP_STEM, OP_DW, OP_CONV = 1, 2, 3
+# output modes of OP_CONV
+OUT_ACT, OUT_BOX, OUT_CLS = 0, 1, 2
+ACT_NONE, ACT_RELU6 = 0, 1
+
+_INVERTED_RESIDUAL = [  # (t, c, n, s) rows of the MobileNetV2 paper, depth multiplier 1.0
+    (1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2), (6, 96, 3, 1), (6, 160, 3, 2), (6, 320, 1, 1),
+]
+_EXTRA_DEPTHS = [(256, 512), (128, 256), (128, 256), (64, 128)]
+_ANCHORS_PER_LOCATION = [3, 6, 6, 6, 6, 6]
+
+
+def tf_same(n_in: int, k: int, s: int) -> Tuple[int, int]:
+    """(n_out, pad_before) of TensorFlow 'SAME' padding."""
+    n_out = (n_in + s - 1) // s
+    total = max((n_out - 1) * s + k - n_in, 0)
+    return n_out, total // 2
+
+
+@dataclass
+class Tensor:
+    name: str
+    h: int
+    w: int
+    c: int
+
+
+@dataclass
+class Op:
+    kind: int
+    scope: str                 # TF variable scope holding weights / BatchNorm / biases
+    src: str
+    dst: str
+    cin: int
+    cout: int
+    k: int
+    stride: int
+    act: int
+    has_bn: bool
+    res: Optional[str] = None
+    out_mode: int = OUT_ACT
+    head_index: int = -1       # which SSD feature map (for OUT_BOX / OUT_CLS)
+    anchors_per_loc: int = 0
+    # filled in by build():
+    hin: int = 0
+    win: int = 0
+    hout: int = 0
+    wout: int = 0
+    pad_t: int = 0
+    pad_l: int = 0
+    anchor_offset: int = 0     # first anchor index of this head's feature map
+
+
+@dataclass
+class Program:
+    size: int
+    tensors: Dict[str, Tensor] = field(default_factory=dict)
+    ops: List[Op] = field(default_factory=list)
+    feature_maps: List[Tuple[str, int, int]] = field(default_factory=list)   # (tensor, grid, anchors/loc)
+    num_anchors: int = 0
+
+    def variable_shapes(self) -> Dict[str, Tuple[int, ...]]:
+        """TF variable name -> shape, for every variable the program consumes."""
+        out: Dict[str, Tuple[int, ...]] = {}
+        for op in self.ops:
+            if op.kind == OP_DW:
+                out[op.scope + "/depthwise_weights"] = (op.k, op.k, op.cin, 1)
+            else:
+                out[op.scope + "/weights"] = (op.k, op.k, op.cin, op.cout)
+            if op.has_bn:
+                for v in ("gamma", "beta", "moving_mean", "moving_variance"):
+                    out[op.scope + "/BatchNorm/" + v] = (op.cout,)
+            else:
+                out[op.scope + "/biases"] = (op.cout,)
+        return out
+
+
+def _blk(i: int) -> str:
+    return "expanded_conv" if i == 0 else "expanded_conv_%d" % i
+
+
+def build(size: int = INPUT_SIZE) -> Program:
+    p = Program(size=size)
+    ops: List[Op] = []
+    ops.append(Op(OP_STEM, FE + "Conv", "input", "Conv", 3, 32, 3, 2, ACT_RELU6, True))
+    cur, cin, idx = "Conv", 32, 0
+    tap0 = None
+    for t, c, n, s in _INVERTED_RESIDUAL:
+        for j in range(n):
+            stride = s if j == 0 else 1
+            name = _blk(idx)
+            x_in, mid = cur, cin * t
+            if t != 1:
+                ops.append(Op(OP_CONV, FE + name + "/expand", cur, name + "/expand", cin, mid, 1, 1, ACT_RELU6, True))
+                cur = name + "/expand"
+                if idx == 13:
+                    tap0 = cur
+            ops.append(Op(OP_DW, FE + name + "/depthwise", cur, name + "/depthwise", mid, mid, 3, stride,
+                          ACT_RELU6, True))
+            res = x_in if (stride == 1 and cin == c) else None
+            ops.append(Op(OP_CONV, FE + name + "/project", name + "/depthwise", name + "/output", mid, c, 1, 1,
+                          ACT_NONE, True, res=res))
+            cur, cin = name + "/output", c
+            idx += 1
+    ops.append(Op(OP_CONV, FE + "Conv_1", cur, "Conv_1", cin, 1280, 1, 1, ACT_RELU6, True))
+    cur, cin = "Conv_1", 1280
+    taps = [tap0, "Conv_1"]
+    for i, (d1, d2) in enumerate(_EXTRA_DEPTHS):
+        n1 = "layer_19_1_Conv2d_%d_1x1_%d" % (i + 2, d1)
+        n2 = "layer_19_2_Conv2d_%d_3x3_s2_%d" % (i + 2, d2)
+        ops.append(Op(OP_CONV, FE + n1, cur, n1, cin, d1, 1, 1, ACT_RELU6, True))
+        ops.append(Op(OP_CONV, FE + n2, n1, n2, d1, d2, 3, 2, ACT_RELU6, True))
+        cur, cin = n2, d2
+        taps.append(n2)
+
+    # shape inference
+    p.tensors["input"] = Tensor("input", size, size, 3)
+    for op in ops:
+        src = p.tensors[op.src]
+        op.hin, op.win = src.h, src.w
+        op.hout, op.pad_t = tf_same(src.h, op.k, op.stride)
+        op.wout, op.pad_l = tf_same(src.w, op.k, op.stride)
+        p.tensors[op.dst] = Tensor(op.dst, op.hout, op.wout, op.cout)
+
+    # heads (box then class per feature map, 3x3 SAME, biases, no activation)
+    off = 0
+    for i, (tname, a) in enumerate(zip(taps, _ANCHORS_PER_LOCATION)):
+        tt = p.tensors[tname]
+        for mode, scope, cols in ((OUT_BOX, "BoxEncodingPredictor", 4), (OUT_CLS, "ClassPredictor", NUM_CLASSES)):
+            op = Op(OP_CONV, "BoxPredictor_%d/%s" % (i, scope), tname, "head_%d_%d" % (i, mode), tt.c, a * cols,
+                    3, 1, ACT_NONE, False, out_mode=mode, head_index=i, anchors_per_loc=a)
+            op.hin, op.win = tt.h, tt.w
+            op.hout, op.pad_t = tf_same(tt.h, 3, 1)
+            op.wout, op.pad_l = tf_same(tt.w, 3, 1)
+            op.anchor_offset = off
+            ops.append(op)
+        p.feature_maps.append((tname, tt.h, a))
+        off += tt.h * tt.w * a
+    p.num_anchors = off
+    p.ops = ops
+    return p

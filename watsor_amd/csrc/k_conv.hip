@@ -1,0 +1,286 @@
+// Convolution stack of SSD-MobileNet-v2 on gfx950: activations NHWC fp16 in HBM, fp32 accumulate.
+//
+// In the reference all of this is inside `sess.run` (`watsor/detection/tensorflow_cpu.py:114-115`)
+// or inside the TensorRT engine (`tensorrt_gpu.py:150`); there is no reference kernel to mirror
+// (SURVEY.md §2 "Native inventory").  Layer shapes: SURVEY.md Appendix A.
+//
+//  wz_k_stem   3x3 s2, 3(+1 pad)->32, BN folded, ReLU6            VALU, K = 27
+//  wz_k_dw     depthwise 3x3 s1/s2, TF SAME, BN folded, ReLU6      VALU, HBM-bound (AI 1.8-4.5 flop/B)
+//  wz_k_conv   1x1 and dense 3x3 as implicit GEMM on v_mfma_f32_16x16x32_f16:
+//              D[n][m] = sum_k W[n][k] * X[m][k]; the weights are the MFMA "A" operand (pre-packed by
+//              the engine builder in fragment order, one coalesced 1 KiB load per fragment) and the
+//              activations the "B" operand (each lane gathers 8 consecutive channels = 16 B of one
+//              input pixel), so a lane ends up with 4 consecutive output channels of one pixel and
+//              stores them as one 8-byte word.  Epilogue fuses bias, ReLU6 and the residual add.
+//  wz_k_splitk_reduce  deterministic (fixed order) reduction of split-K partials + the same epilogue.
+#include "wz_common.h"
+
+// --------------------------------------------------------------------------------------------
+// stem: thread = (output pixel, group of 8 output channels)
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wz_k_stem(const half_t* __restrict__ in, const float* __restrict__ w,
+                                                 const float* __restrict__ bias, half_t* __restrict__ out,
+                                                 int total, int hin, int win, int hout, int wout, int pad_t,
+                                                 int pad_l) {
+    __shared__ float sw[27 * 32 + 32];
+    for (int i = threadIdx.x; i < 27 * 32; i += 256) sw[i] = w[i];
+    if (threadIdx.x < 32) sw[27 * 32 + threadIdx.x] = bias[threadIdx.x];
+    __syncthreads();
+    const int tid = blockIdx.x * 256 + threadIdx.x;
+    if (tid >= total) return;
+    const int cg = tid & 3, pix = tid >> 2;
+    const int ox = pix % wout;
+    const int t2 = pix / wout;
+    const int oy = t2 % hout, b = t2 / hout;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = sw[27 * 32 + cg * 8 + j];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * 2 - pad_t + ky;
+        if (iy < 0 || iy >= hin) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox * 2 - pad_l + kx;
+            if (ix < 0 || ix >= win) continue;
+            const half4_t p = *reinterpret_cast<const half4_t*>(in + ((size_t)(b * hin + iy) * win + ix) * 4);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float x = (float)p[c];
+                const float* wr = sw + ((ky * 3 + kx) * 3 + c) * 32 + cg * 8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(x, wr[j], acc[j]);
+            }
+        }
+    }
+    half8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (half_t)fminf(fmaxf(acc[j], 0.0f), 6.0f);
+    *reinterpret_cast<half8_t*>(out + (size_t)pix * 32 + cg * 8) = o;
+}
+
+void wz_launch_stem(const half_t* in, const float* w, const float* bias, half_t* out, int n, int hin, int win,
+                    int hout, int wout, int pad_t, int pad_l, hipStream_t s) {
+    const int total = n * hout * wout * 4;
+    hipLaunchKernelGGL(wz_k_stem, dim3((total + 255) / 256), dim3(256), 0, s, in, w, bias, out, total, hin, win,
+                       hout, wout, pad_t, pad_l);
+}
+
+// --------------------------------------------------------------------------------------------
+// depthwise 3x3: thread = (output pixel, group of 8 channels); 16-byte loads/stores, channel-coalesced
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wz_k_dw(const half_t* __restrict__ in, const half_t* __restrict__ w,
+                                               const float* __restrict__ bias, half_t* __restrict__ out,
+                                               int total, int hin, int win, int c, int hout, int wout, int stride,
+                                               int pad_t, int pad_l, int act) {
+    const int tid = blockIdx.x * 256 + threadIdx.x;
+    if (tid >= total) return;
+    const int c8 = c >> 3;
+    const int cg = tid % c8, pix = tid / c8;
+    const int ox = pix % wout;
+    const int t2 = pix / wout;
+    const int oy = t2 % hout, b = t2 / hout;
+    float acc[8];
+    {
+        const float4_t b0 = *reinterpret_cast<const float4_t*>(bias + cg * 8);
+        const float4_t b1 = *reinterpret_cast<const float4_t*>(bias + cg * 8 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[j] = b0[j]; acc[4 + j] = b1[j]; }
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * stride - pad_t + ky;
+        if (iy < 0 || iy >= hin) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox * stride - pad_l + kx;
+            if (ix < 0 || ix >= win) continue;
+            const half8_t x = *reinterpret_cast<const half8_t*>(in + ((size_t)(b * hin + iy) * win + ix) * c + cg * 8);
+            const half8_t k = *reinterpret_cast<const half8_t*>(w + (size_t)(ky * 3 + kx) * c + cg * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf((float)x[j], (float)k[j], acc[j]);
+        }
+    }
+    half8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float v = acc[j];
+        if (act == WZ_ACT_RELU6) v = fminf(fmaxf(v, 0.0f), 6.0f);
+        o[j] = (half_t)v;
+    }
+    *reinterpret_cast<half8_t*>(out + (size_t)pix * c + cg * 8) = o;
+}
+
+void wz_launch_dw(const half_t* in, const half_t* w, const float* bias, half_t* out, int n, int hin, int win,
+                  int c, int hout, int wout, int stride, int pad_t, int pad_l, int act, hipStream_t s) {
+    const int total = n * hout * wout * (c >> 3);
+    hipLaunchKernelGGL(wz_k_dw, dim3((total + 255) / 256), dim3(256), 0, s, in, w, bias, out, total, hin, win, c,
+                       hout, wout, stride, pad_t, pad_l, act);
+}
+
+// --------------------------------------------------------------------------------------------
+// implicit-GEMM convolution on MFMA.  Workgroup = 4 waves; wave = (MT*16 pixels) x (NT*16 channels).
+// --------------------------------------------------------------------------------------------
+#define CONV_MT 2
+#define CONV_NT 2
+
+__device__ __forceinline__ void wz_epilogue4(const WzConvArgs& a, int m, int n4, float4_t v) {
+    // v = 4 consecutive output channels n4..n4+3 of output pixel m (bias not yet added)
+    if (m >= a.M || n4 >= a.cout) return;
+    const float4_t bv = *reinterpret_cast<const float4_t*>(a.bias + n4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float x = v[r] + bv[r];
+        if (a.act == WZ_ACT_RELU6) x = fminf(fmaxf(x, 0.0f), 6.0f);
+        v[r] = x;
+    }
+    if (a.out_mode == WZ_OUT_ACT) {
+        const size_t o = (size_t)m * a.cout + n4;
+        if (a.res) {
+            const half4_t rv = *reinterpret_cast<const half4_t*>(a.res + o);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+        }
+        half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(a.out) + o) = h;
+    } else {
+        const int hw = a.hout * a.wout;
+        const int b = m / hw, pix = m - b * hw;
+        float* o = reinterpret_cast<float*>(a.out) + (size_t)b * a.out_batch_stride + a.out_off +
+                   (size_t)pix * a.cout + n4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n4 + r < a.cout) o[r] = v[r];
+    }
+}
+
+template <int KS>
+__global__ __launch_bounds__(256) void wz_k_conv(const WzConvArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int m_base = (blockIdx.x * 4 + wave) * (CONV_MT * 16);
+    const int nt0 = blockIdx.y * CONV_NT;
+    if (m_base >= a.M) return;   // whole wave out of range (no barriers in this kernel)
+
+    const int hw = a.hout * a.wout;
+    int iy0[CONV_MT], ix0[CONV_MT], boff[CONV_MT];
+    bool mv[CONV_MT];
+#pragma unroll
+    for (int mt = 0; mt < CONV_MT; ++mt) {
+        const int m = m_base + mt * 16 + r16;
+        mv[mt] = m < a.M;
+        const int mm = mv[mt] ? m : 0;
+        const int b = mm / hw, rem = mm - b * hw;
+        const int oy = rem / a.wout, ox = rem - oy * a.wout;
+        iy0[mt] = oy * a.stride - a.pad_t;
+        ix0[mt] = ox * a.stride - a.pad_l;
+        boff[mt] = b * a.hin;
+    }
+
+    float4_t acc[CONV_MT][CONV_NT];
+#pragma unroll
+    for (int mt = 0; mt < CONV_MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < CONV_NT; ++nt) acc[mt][nt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    // K range of this split (flattened chunk index q = tap * kc + c)
+    const int per = (a.kchunks + a.splitk - 1) / a.splitk;
+    const int q0 = blockIdx.z * per;
+    const int q1 = min(q0 + per, a.kchunks);
+    constexpr int taps = KS * KS;
+    const half_t* wlane = a.w + (size_t)lane * 8;
+    const int cg8 = g * 8;
+
+    int t = q0 / a.kc, c = q0 - t * a.kc;
+    for (int q = q0; q < q1;) {
+        const int ky = t / KS, kx = t - ky * KS;
+        const half_t* ap[CONV_MT];
+        bool ok[CONV_MT];
+#pragma unroll
+        for (int mt = 0; mt < CONV_MT; ++mt) {
+            const int iy = iy0[mt] + ky, ix = ix0[mt] + kx;
+            ok[mt] = mv[mt] && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
+            ap[mt] = a.in + ((size_t)(boff[mt] + iy) * a.win + ix) * a.cin + cg8;
+        }
+        const int c_end = min(a.kc, c + (q1 - q));
+#pragma unroll 2
+        for (; c < c_end; ++c, ++q) {
+            half8_t xa[CONV_MT], wf[CONV_NT];
+            const bool cin_ok = (c * 32 + cg8) < a.cin;
+#pragma unroll
+            for (int mt = 0; mt < CONV_MT; ++mt) {
+                if (ok[mt] && cin_ok)
+                    xa[mt] = *reinterpret_cast<const half8_t*>(ap[mt] + c * 32);
+                else
+                    xa[mt] = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int nt = 0; nt < CONV_NT; ++nt)
+                wf[nt] = *reinterpret_cast<const half8_t*>(wlane + ((size_t)((nt0 + nt) * taps + t) * a.kc + c) * 512);
+#pragma unroll
+            for (int mt = 0; mt < CONV_MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < CONV_NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], xa[mt], acc[mt][nt], 0, 0, 0);
+        }
+        c = 0;
+        ++t;
+    }
+
+    // D layout: lane holds rows (n) g*4..g*4+3 of column (m) r16
+#pragma unroll
+    for (int mt = 0; mt < CONV_MT; ++mt) {
+        const int m = m_base + mt * 16 + r16;
+#pragma unroll
+        for (int nt = 0; nt < CONV_NT; ++nt) {
+            const int n4 = (nt0 + nt) * 16 + g * 4;
+            if (a.splitk > 1) {
+                if (m < a.M)
+                    *reinterpret_cast<float4_t*>(reinterpret_cast<float*>(a.out) +
+                                                 ((size_t)blockIdx.z * a.M + m) * a.n_pad + n4) = acc[mt][nt];
+            } else {
+                wz_epilogue4(a, m, n4, acc[mt][nt]);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wz_k_splitk_reduce(const WzConvArgs a, const float* __restrict__ ws) {
+    const int tid = blockIdx.x * 256 + threadIdx.x;
+    const int n4s = a.n_pad >> 2;
+    if (tid >= a.M * n4s) return;
+    const int m = tid / n4s, n4 = (tid - m * n4s) * 4;
+    float4_t v = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < a.splitk; ++z) {
+        const float4_t p = *reinterpret_cast<const float4_t*>(ws + ((size_t)z * a.M + m) * a.n_pad + n4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += p[r];
+    }
+    wz_epilogue4(a, m, n4, v);
+}
+
+int wz_choose_splitk(int M, int n_pad, int kchunks) {
+    // Enough waves to cover the 1024 SIMDs several times; only long K loops are worth splitting.
+    const long waves = (long)((M + CONV_MT * 16 - 1) / (CONV_MT * 16)) * (n_pad / (CONV_NT * 16));
+    if (kchunks < 32 || waves >= 4096) return 1;
+    int s = (int)(4096 / (waves > 0 ? waves : 1));
+    const int max_by_k = kchunks / 8;
+    if (s > max_by_k) s = max_by_k;
+    if (s > 16) s = 16;
+    return s < 1 ? 1 : s;
+}
+
+void wz_launch_conv(const WzConvArgs& a, hipStream_t s) {
+    const int mtiles = (a.M + CONV_MT * 16 - 1) / (CONV_MT * 16);
+    dim3 grid((mtiles + 3) / 4, a.n_pad / (CONV_NT * 16), a.splitk);
+    if (a.ksize == 1)
+        hipLaunchKernelGGL(wz_k_conv<1>, grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(wz_k_conv<3>, grid, dim3(256), 0, s, a);
+}
+
+void wz_launch_splitk_reduce(const WzConvArgs& a, const float* ws, hipStream_t s) {
+    const int total = a.M * (a.n_pad >> 2);
+    hipLaunchKernelGGL(wz_k_splitk_reduce, dim3((total + 255) / 256), dim3(256), 0, s, a, ws);
+}

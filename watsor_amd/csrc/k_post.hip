@@ -1,0 +1,442 @@
+// SSD post-processing on gfx950: anchor-box decode, sigmoid, per-class greedy NMS, top-100, row fill,
+// and the per-camera confidence / area / zone filters.
+//
+// Decode .. top-100 live inside the TF graph the reference executes (`tensorflow_cpu.py:94-121`,
+// SURVEY.md D7 / Appendix B.3-B.5); the row fill is `tensorflow_cpu.py:79-90`; the filters are
+// `watsor/filter/confidence.py:17-19`, `area.py:19-26`, `mask.py:44-59`.
+//
+// NMS formulation: TF runs greedy NMS class by class (<= max_per_class each), concatenates, sorts by
+// score and keeps max_total.  A candidate's fate depends only on higher-scored boxes of its own class,
+// so walking ALL (anchor, class) candidates once in global order (score desc, class asc, anchor asc),
+// suppressing only against kept boxes of the same class and stopping at max_total kept, yields exactly
+// the same rows.  The walk needs the head of that order only: a 1024-bin histogram of the score bits
+// picks a threshold that admits >= WZ_CAND_TARGET candidates, they are compacted, bitonic-sorted in LDS
+// and walked by one wavefront (lanes = already kept boxes, `__any` = "suppressed").  If that head is
+// exhausted before max_total rows are kept (or the threshold bin overflows WZ_CAND_CAP) the kernel
+// continues with an exact, slower "next best candidate below the bound" scan, so the result never
+// depends on the tuning constants.
+//
+// All comparisons the result depends on (score order, IoU > thr, area > 0, truncation) use fp32/fp64
+// operations rounded once each in the oracle's order: contraction is disabled for this file.
+#pragma clang fp contract(off)
+#include "wz_common.h"
+
+__device__ __forceinline__ float wz_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---------------------------------------------------------------------------------------------
+// decode + clip (FasterRcnnBoxCoder._decode, clip_to_window [0,0,1,1], area > 0)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wz_k_decode(WzPostBuffers b, WzPostConsts k, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * k.num_anchors) return;
+    const int a = i % k.num_anchors;
+    const float4_t e = *reinterpret_cast<const float4_t*>(b.box_enc + (size_t)i * 4);
+    const float4_t an = *reinterpret_cast<const float4_t*>(b.anchors + (size_t)a * 4);  // yc, xc, h, w
+    const float ty = e[0] / k.scale_y, tx = e[1] / k.scale_x, th = e[2] / k.scale_h, tw = e[3] / k.scale_w;
+    const float w = expf(tw) * an[3];
+    const float h = expf(th) * an[2];
+    const float yc = ty * an[2] + an[0];
+    const float xc = tx * an[3] + an[1];
+    const float hh = h / 2.0f, hw = w / 2.0f;
+    float ymin = yc - hh, xmin = xc - hw, ymax = yc + hh, xmax = xc + hw;
+    ymin = fminf(fmaxf(ymin, 0.0f), 1.0f);
+    xmin = fminf(fmaxf(xmin, 0.0f), 1.0f);
+    ymax = fminf(fmaxf(ymax, 0.0f), 1.0f);
+    xmax = fminf(fmaxf(xmax, 0.0f), 1.0f);
+    const float area = (ymax - ymin) * (xmax - xmin);
+    *reinterpret_cast<float4_t*>(b.boxes + (size_t)i * 4) = (float4_t){ymin, xmin, ymax, xmax};
+    b.valid[i] = area > 0.0f ? 1 : 0;
+}
+
+// candidate j of a frame = entry j of logits[f] (anchor-major, class innermost, column 0 = background)
+__device__ __forceinline__ bool wz_candidate(const WzPostBuffers& b, const WzPostConsts& k, int f, int j,
+                                             uint32_t& key, uint32_t& tie) {
+    const int a = j / k.num_classes, col = j - a * k.num_classes;
+    if (col == 0) return false;
+    if (!b.valid[(size_t)f * k.num_anchors + a]) return false;
+    const float s = wz_sigmoid(b.logits[(size_t)f * k.num_anchors * k.num_classes + j]);
+    if (!(s > k.score_thr)) return false;
+    key = __float_as_uint(s);
+    tie = (uint32_t)(col - 1) * (uint32_t)k.num_anchors + (uint32_t)a;   // class asc, then anchor asc
+    return true;
+}
+
+#define POST_ITEMS 8
+__global__ __launch_bounds__(256) void wz_k_hist(WzPostBuffers b, WzPostConsts k) {
+    __shared__ uint32_t h[WZ_HIST_BINS];
+    for (int i = threadIdx.x; i < WZ_HIST_BINS; i += 256) h[i] = 0;
+    __syncthreads();
+    const int f = blockIdx.y, total = k.num_anchors * k.num_classes;
+    const int base = blockIdx.x * 256 * POST_ITEMS;
+#pragma unroll
+    for (int it = 0; it < POST_ITEMS; ++it) {
+        const int j = base + it * 256 + threadIdx.x;
+        uint32_t key, tie;
+        if (j < total && wz_candidate(b, k, f, j, key, tie)) atomicAdd(&h[key >> 20], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < WZ_HIST_BINS; i += 256)
+        if (h[i]) atomicAdd(&b.hist[(size_t)f * WZ_HIST_BINS + i], h[i]);
+}
+
+// threshold bin: the largest b with (number of candidates in bins >= b) >= target, else 0.
+// Called by all 256*k threads of a block; `sh` is WZ_HIST_BINS+2 uint32 of LDS.  Returns total too.
+__device__ int wz_threshold_bin(const uint32_t* __restrict__ ghist, uint32_t* sh, uint32_t target,
+                                uint32_t* total_out) {
+    const int nth = blockDim.x;
+    for (int i = threadIdx.x; i < WZ_HIST_BINS; i += nth) sh[i] = ghist[i];
+    __syncthreads();
+    if (threadIdx.x == 0) {   // 1024-step serial suffix scan: ~2 us, once per block, simple and exact
+        uint32_t run = 0;
+        int thr = 0;
+        bool found = false;
+        for (int i = WZ_HIST_BINS - 1; i >= 0; --i) {
+            run += sh[i];
+            if (!found && run >= target) { thr = i; found = true; }
+        }
+        sh[WZ_HIST_BINS] = (uint32_t)thr;
+        sh[WZ_HIST_BINS + 1] = run;
+    }
+    __syncthreads();
+    if (total_out) *total_out = sh[WZ_HIST_BINS + 1];
+    return (int)sh[WZ_HIST_BINS];
+}
+
+__global__ __launch_bounds__(256) void wz_k_compact(WzPostBuffers b, WzPostConsts k) {
+    __shared__ uint32_t sh[WZ_HIST_BINS + 2];
+    const int f = blockIdx.y, total = k.num_anchors * k.num_classes;
+    const uint32_t thr = (uint32_t)wz_threshold_bin(b.hist + (size_t)f * WZ_HIST_BINS, sh, WZ_CAND_TARGET, nullptr);
+    const int base = blockIdx.x * 256 * POST_ITEMS;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int it = 0; it < POST_ITEMS; ++it) {
+        const int j = base + it * 256 + threadIdx.x;
+        uint32_t key = 0, tie = 0;
+        const bool p = j < total && wz_candidate(b, k, f, j, key, tie) && (key >> 20) >= thr;
+        const unsigned long long m = __ballot(p);
+        if (m) {
+            uint32_t pos0 = 0;
+            const int leader = __ffsll((long long)m) - 1;
+            if (lane == leader) pos0 = atomicAdd(&b.count[f], (uint32_t)__popcll(m));
+            pos0 = __shfl(pos0, leader);
+            if (p) {
+                const uint32_t pos = pos0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (pos < WZ_CAND_CAP) b.cand[(size_t)f * WZ_CAND_CAP + pos] = make_uint2(key, tie);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// greedy NMS walk: one workgroup per frame
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wz_iou(const float4_t a, const float4_t c) {
+    // tensorflow/core/kernels/non_max_suppression_op.cc IOU(): boxes are (y1,x1,y2,x2)
+    const float ymin_i = fminf(a[0], a[2]), xmin_i = fminf(a[1], a[3]);
+    const float ymax_i = fmaxf(a[0], a[2]), xmax_i = fmaxf(a[1], a[3]);
+    const float ymin_j = fminf(c[0], c[2]), xmin_j = fminf(c[1], c[3]);
+    const float ymax_j = fmaxf(c[0], c[2]), xmax_j = fmaxf(c[1], c[3]);
+    const float area_i = (ymax_i - ymin_i) * (xmax_i - xmin_i);
+    const float area_j = (ymax_j - ymin_j) * (xmax_j - xmin_j);
+    if (area_i <= 0.0f || area_j <= 0.0f) return 0.0f;
+    const float iy0 = fmaxf(ymin_i, ymin_j), ix0 = fmaxf(xmin_i, xmin_j);
+    const float iy1 = fminf(ymax_i, ymax_j), ix1 = fminf(xmax_i, xmax_j);
+    const float inter = fmaxf(iy1 - iy0, 0.0f) * fmaxf(ix1 - ix0, 0.0f);
+    return inter / (area_i + area_j - inter);
+}
+
+#define NMS_THREADS 1024
+#define NMS_KEEP_MAX 128   // >= max_total (100)
+
+struct NmsShared {   // carved from dynamic LDS, every member 16-byte aligned
+    unsigned long long keys[WZ_CAND_CAP];   // 32 KiB
+    float4_t sbox[WZ_CAND_CAP];             // 64 KiB
+    float4_t kbox[NMS_KEEP_MAX];
+    float kscore[NMS_KEEP_MAX];
+    int32_t kcls[NMS_KEEP_MAX];
+    unsigned long long red[NMS_THREADS / 64];
+    uint32_t hist[WZ_HIST_BINS + 2];
+    int32_t kept;
+    int32_t pad[3];
+};
+
+// wave 0: try to keep candidate (box, cls, score); returns new kept count (uniform across the wave)
+__device__ __forceinline__ int wz_try_keep(NmsShared* S, int kept, const float4_t box, int cls, float score,
+                                           const WzPostConsts& k, int lane) {
+    bool sup = false;
+    int same = 0;
+    for (int j = lane; j < kept; j += 64) {
+        if (S->kcls[j] == cls) {
+            ++same;
+            if (wz_iou(box, S->kbox[j]) > k.iou_thr) sup = true;
+        }
+    }
+    const bool any_sup = __any(sup);
+    int tot = same;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+    if (!any_sup && tot < k.max_per_class) {
+        if (lane == 0) {
+            S->kbox[kept] = box;
+            S->kcls[kept] = cls;
+            S->kscore[kept] = score;
+        }
+        ++kept;
+    }
+    return kept;
+}
+
+__global__ __launch_bounds__(NMS_THREADS) void wz_k_nms(WzPostBuffers b, WzPostConsts k) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    NmsShared* S = reinterpret_cast<NmsShared*>(smem);
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int A = k.num_anchors;
+
+    uint32_t total = 0;
+    const int thr_bin = wz_threshold_bin(b.hist + (size_t)f * WZ_HIST_BINS, S->hist, WZ_CAND_TARGET, &total);
+    const uint32_t cnt_raw = b.count[f];
+    const bool overflow = cnt_raw > WZ_CAND_CAP;
+    const int cnt = overflow ? 0 : (int)cnt_raw;
+
+    int kept = 0;
+    if (cnt > 0) {
+        int npow = 64;
+        while (npow < cnt) npow <<= 1;
+        for (int i = tid; i < npow; i += NMS_THREADS) {
+            unsigned long long v = 0ull;
+            if (i < cnt) {
+                const uint2 c = b.cand[(size_t)f * WZ_CAND_CAP + i];
+                v = ((unsigned long long)c.x << 32) | (unsigned long long)(0xFFFFFFFFu - c.y);
+            }
+            S->keys[i] = v;
+        }
+        __syncthreads();
+        // bitonic sort, descending
+        for (int size = 2; size <= npow; size <<= 1) {
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int i = tid; i < (npow >> 1); i += NMS_THREADS) {
+                    const int lo = 2 * i - (i & (stride - 1));
+                    const int hi = lo + stride;
+                    const bool desc = ((lo & size) == 0);
+                    const unsigned long long x = S->keys[lo], y = S->keys[hi];
+                    if ((x < y) == desc) { S->keys[lo] = y; S->keys[hi] = x; }
+                }
+                __syncthreads();
+            }
+        }
+        for (int i = tid; i < cnt; i += NMS_THREADS) {
+            const uint32_t tie = 0xFFFFFFFFu - (uint32_t)(S->keys[i] & 0xFFFFFFFFull);
+            const int a = (int)(tie % (uint32_t)A);
+            S->sbox[i] = *reinterpret_cast<const float4_t*>(b.boxes + ((size_t)f * A + a) * 4);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            for (int i = 0; i < cnt && kept < k.max_total; ++i) {
+                const unsigned long long comp = S->keys[i];
+                const uint32_t tie = 0xFFFFFFFFu - (uint32_t)(comp & 0xFFFFFFFFull);
+                const int cls = (int)(tie / (uint32_t)A);
+                kept = wz_try_keep(S, kept, S->sbox[i], cls, __uint_as_float((uint32_t)(comp >> 32)), k, lane);
+            }
+            if (lane == 0) S->kept = kept;
+        }
+        __syncthreads();
+        kept = S->kept;
+    }
+
+    // exact continuation below the bound (rare): one best candidate per scan
+    const bool more = overflow ? (total > 0) : (total > (uint32_t)cnt);
+    if (kept < k.max_total && more) {
+        unsigned long long bound = overflow ? ~0ull : ((unsigned long long)((uint32_t)thr_bin << 20) << 32);
+        const int n_entries = A * k.num_classes;
+        while (kept < k.max_total) {
+            unsigned long long best = 0ull;
+            for (int j = tid; j < n_entries; j += NMS_THREADS) {
+                uint32_t key, tie;
+                if (wz_candidate(b, k, f, j, key, tie)) {
+                    const unsigned long long comp = ((unsigned long long)key << 32) | (0xFFFFFFFFu - tie);
+                    if (comp < bound && comp > best) best = comp;
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned long long other = __shfl_xor(best, o);
+                if (other > best) best = other;
+            }
+            if (lane == 0) S->red[wave] = best;
+            __syncthreads();
+            best = 0ull;
+            for (int w = 0; w < NMS_THREADS / 64; ++w)
+                if (S->red[w] > best) best = S->red[w];
+            __syncthreads();
+            if (best == 0ull) break;
+            bound = best;
+            if (wave == 0) {
+                const uint32_t tie = 0xFFFFFFFFu - (uint32_t)(best & 0xFFFFFFFFull);
+                const int cls = (int)(tie / (uint32_t)A), a = (int)(tie % (uint32_t)A);
+                const float4_t box = *reinterpret_cast<const float4_t*>(b.boxes + ((size_t)f * A + a) * 4);
+                kept = wz_try_keep(S, kept, box, cls, __uint_as_float((uint32_t)(best >> 32)), k, lane);
+                if (lane == 0) S->kept = kept;
+            }
+            __syncthreads();
+            kept = S->kept;
+        }
+    }
+
+    // detection_boxes / scores / classes (+1 label offset on every row, zero padding included)
+    for (int i = tid; i < k.max_total; i += NMS_THREADS) {
+        const bool on = i < kept;
+        const float4_t bx = on ? S->kbox[i] : (float4_t){0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<float4_t*>(b.det_boxes + ((size_t)f * k.max_total + i) * 4) = bx;
+        b.det_scores[(size_t)f * k.max_total + i] = on ? S->kscore[i] : 0.0f;
+        b.det_classes[(size_t)f * k.max_total + i] = (on ? S->kcls[i] : 0) + 1;
+    }
+    if (tid == 0) b.det_num[f] = kept;
+}
+
+// ---------------------------------------------------------------------------------------------
+// row fill + per-camera filters
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wz_zone_sum(const int32_t* sat, int W, int x0, int y0, int x1, int y1) {
+    // inclusive pixel rectangle [x0..x1] x [y0..y1] on a (H+1) x (W+1) summed-area table
+    const int s = W + 1;
+    return sat[(y1 + 1) * s + (x1 + 1)] - sat[y0 * s + (x1 + 1)] - sat[(y1 + 1) * s + x0] + sat[y0 * s + x0];
+}
+
+__device__ void wz_apply_filter(const WzCamFilter& cf, wz_detection_t& d, uint8_t* pass) {
+    // `label > 0 and Confidence and Area and Mask`, short-circuit left to right (track.py:26)
+    bool ok = d.label > 0 && d.label < WZ_NUM_LABELS;
+    if (ok) {
+        const double ct = cf.conf_thr[d.label];            // confidence.py:17-19
+        ok = (ct == ct) && d.confidence >= ct;
+    }
+    if (ok) {
+        const double at = cf.area_thr[d.label];            // area.py:19-26
+        long long ar = (long long)(d.x_max - d.x_min + 1) * (long long)(d.y_max - d.y_min + 1);
+        if (ar < 0) ar = -ar;
+        ok = (at == at) && (double)ar >= at;
+    }
+    if (ok && cf.n_zones > 0) {                            // mask.py:44-59
+        // lattice rule: hit <=> a filled-zone pixel lies inside the closed box
+        const int x0 = max(min(d.x_min, d.x_max), 0), x1 = min(max(d.x_min, d.x_max), cf.width - 1);
+        const int y0 = max(min(d.y_min, d.y_max), 0), y1 = min(max(d.y_min, d.y_max), cf.height - 1);
+        bool hit = false;
+        int z = 0;
+        const size_t plane = (size_t)(cf.width + 1) * (cf.height + 1);
+        for (int p = 0; p < cf.n_zones && z < WZ_MAX_ZONES; ++p) {
+            if (!cf.allow[d.label][p]) continue;
+            if (x0 <= x1 && y0 <= y1 && wz_zone_sum(cf.sat + p * plane, cf.width, x0, y0, x1, y1) > 0) {
+                d.zones[z++] = p + 1;
+                hit = true;
+            }
+        }
+        ok = hit;
+    }
+    if (pass) *pass = ok ? 1 : 0;
+}
+
+__global__ __launch_bounds__(128) void wz_k_rows(WzPostBuffers b, const WzFrameDesc* __restrict__ frames,
+                                                 const WzCamFilter* __restrict__ cams, int max_total,
+                                                 wz_detection_t* __restrict__ rows, uint8_t* __restrict__ pass) {
+    const int f = blockIdx.x, i = threadIdx.x;
+    if (i >= WZ_MAX_DETECTIONS) return;
+    wz_detection_t d;
+    d.label = 0;
+#pragma unroll
+    for (int z = 0; z < WZ_MAX_ZONES; ++z) d.zones[z] = 0;
+    d._pad = 0;
+    d.confidence = 0.0;
+    d.x_min = d.y_min = d.x_max = d.y_max = 0;
+    const WzFrameDesc fd = frames[f];
+    if (i < max_total) {
+        // tensorflow_cpu.py:79-90: label=int(class), confidence=score (float32 widened to double),
+        // int(box * (dim-1)) with the product exact in double, truncation toward zero, no clamp
+        const float4_t bx = *reinterpret_cast<const float4_t*>(b.det_boxes + ((size_t)f * max_total + i) * 4);
+        const double mh = (double)(fd.h - 1), mw = (double)(fd.w - 1);
+        d.label = b.det_classes[(size_t)f * max_total + i];
+        d.confidence = (double)b.det_scores[(size_t)f * max_total + i];
+        d.y_min = (int)((double)bx[0] * mh);
+        d.x_min = (int)((double)bx[1] * mw);
+        d.y_max = (int)((double)bx[2] * mh);
+        d.x_max = (int)((double)bx[3] * mw);
+    }
+    uint8_t p = (d.label > 0) ? 1 : 0;
+    if (fd.cam >= 0 && cams[fd.cam].enabled) wz_apply_filter(cams[fd.cam], d, &p);
+    rows[(size_t)f * WZ_MAX_DETECTIONS + i] = d;
+    pass[(size_t)f * WZ_MAX_DETECTIONS + i] = p;
+}
+
+__global__ __launch_bounds__(128) void wz_k_filter_rows(const WzCamFilter* __restrict__ cams, int cam,
+                                                        wz_detection_t* __restrict__ rows,
+                                                        uint8_t* __restrict__ pass) {
+    const int i = threadIdx.x;
+    if (i >= WZ_MAX_DETECTIONS) return;
+    wz_detection_t d = rows[i];
+    uint8_t p = (d.label > 0) ? 1 : 0;
+    if (cams[cam].enabled) wz_apply_filter(cams[cam], d, &p);
+    rows[i] = d;
+    pass[i] = p;
+}
+
+// summed-area tables of the filled-zone bitmaps: one workgroup per zone, two passes (rows, then columns)
+__global__ __launch_bounds__(256) void wz_k_sat_rows(const uint8_t* __restrict__ fill, int32_t* __restrict__ sat,
+                                                     int W, int H) {
+    const int z = blockIdx.y;
+    const int y = blockIdx.x * 256 + threadIdx.x;   // one thread per image row
+    const size_t plane = (size_t)(W + 1) * (H + 1);
+    int32_t* o = sat + z * plane;
+    if (y == 0)
+        for (int x = 0; x <= W; ++x) o[x] = 0;
+    if (y >= H) return;
+    const uint8_t* src = fill + ((size_t)z * H + y) * W;
+    int32_t run = 0;
+    o[(size_t)(y + 1) * (W + 1)] = 0;
+    for (int x = 0; x < W; ++x) {
+        run += src[x] ? 1 : 0;
+        o[(size_t)(y + 1) * (W + 1) + x + 1] = run;
+    }
+}
+__global__ __launch_bounds__(256) void wz_k_sat_cols(int32_t* __restrict__ sat, int W, int H) {
+    const int z = blockIdx.y;
+    const int x = blockIdx.x * 256 + threadIdx.x;   // one thread per column (coalesced across threads)
+    if (x > W) return;
+    int32_t* o = sat + z * (size_t)(W + 1) * (H + 1);
+    int32_t run = 0;
+    for (int y = 1; y <= H; ++y) {
+        run += o[(size_t)y * (W + 1) + x];
+        o[(size_t)y * (W + 1) + x] = run;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+void wz_launch_decode(const WzPostBuffers& b, const WzPostConsts& c, int n, hipStream_t s) {
+    const int total = n * c.num_anchors;
+    hipLaunchKernelGGL(wz_k_decode, dim3((total + 255) / 256), dim3(256), 0, s, b, c, n);
+}
+void wz_launch_hist(const WzPostBuffers& b, const WzPostConsts& c, int n, hipStream_t s) {
+    const int total = c.num_anchors * c.num_classes;
+    dim3 grid((total + 256 * POST_ITEMS - 1) / (256 * POST_ITEMS), n);
+    hipLaunchKernelGGL(wz_k_hist, grid, dim3(256), 0, s, b, c);
+}
+void wz_launch_compact(const WzPostBuffers& b, const WzPostConsts& c, int n, hipStream_t s) {
+    const int total = c.num_anchors * c.num_classes;
+    dim3 grid((total + 256 * POST_ITEMS - 1) / (256 * POST_ITEMS), n);
+    hipLaunchKernelGGL(wz_k_compact, grid, dim3(256), 0, s, b, c);
+}
+void wz_post_init() {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wz_k_nms), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)sizeof(NmsShared));
+}
+void wz_launch_nms(const WzPostBuffers& b, const WzPostConsts& c, int n, hipStream_t s) {
+    hipLaunchKernelGGL(wz_k_nms, dim3(n), dim3(NMS_THREADS), sizeof(NmsShared), s, b, c);
+}
+void wz_launch_rows(const WzPostBuffers& b, const WzFrameDesc* d_frames, const WzCamFilter* d_cams, int n,
+                    int max_total, wz_detection_t* rows, uint8_t* pass, hipStream_t s) {
+    hipLaunchKernelGGL(wz_k_rows, dim3(n), dim3(128), 0, s, b, d_frames, d_cams, max_total, rows, pass);
+}
+void wz_launch_filter_rows(const WzCamFilter* d_cams, int cam, wz_detection_t* rows, uint8_t* pass, hipStream_t s) {
+    hipLaunchKernelGGL(wz_k_filter_rows, dim3(1), dim3(128), 0, s, d_cams, cam, rows, pass);
+}
+void wz_launch_sat(const uint8_t* fill, int32_t* sat, int width, int height, int n_zones, hipStream_t s) {
+    hipLaunchKernelGGL(wz_k_sat_rows, dim3((height + 255) / 256, n_zones), dim3(256), 0, s, fill, sat, width, height);
+    hipLaunchKernelGGL(wz_k_sat_cols, dim3((width + 1 + 255) / 256, n_zones), dim3(256), 0, s, sat, width, height);
+}

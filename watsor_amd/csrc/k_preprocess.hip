@@ -1,0 +1,54 @@
+// Resize + normalise: packed RGB24 frame of any resolution -> 300x300 fp16 network input.
+//
+// Stands in for the first nodes of the TF graph the reference's CPU plugin runs on the full
+// resolution frame (`watsor/detection/tensorflow_cpu.py:113-115`):
+// ToFloat -> ResizeBilinear(align_corners=False, legacy: src = dst * (in/out), lo = floor,
+// hi = min(ceil, in-1), lerp in fp32) -> (2/255)*x - 1.  The TRT plugin does the same two steps on
+// the host (`tensorrt_gpu.py:67,179-180`).  Every fp32 operation is rounded once, in TF's order,
+// so the result equals the oracle (oracle/preprocess.py) bit for bit before the final fp16 rounding.
+//
+// Roofline: HBM-bound streaming kernel.  Algorithmic bytes per frame = W*H*3 read + size*size*4*2
+// written (the 4th channel is zero padding so the stem conv reads one aligned 8-byte pixel).
+#pragma clang fp contract(off)
+#include "wz_common.h"
+
+__global__ __launch_bounds__(256) void wz_k_preprocess(const WzFrameDesc* __restrict__ frames, int size,
+                                                       half_t* __restrict__ out) {
+    const WzFrameDesc f = frames[blockIdx.y];
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= size * size) return;
+    const int oy = pix / size, ox = pix - oy * size;
+
+    const float in_y = (float)oy * f.scale_y;
+    const float fl_y = floorf(in_y);
+    const int y_lo = max((int)fl_y, 0);
+    const int y_hi = min((int)ceilf(in_y), f.h - 1);
+    const float ly = in_y - fl_y;
+    const float in_x = (float)ox * f.scale_x;
+    const float fl_x = floorf(in_x);
+    const int x_lo = max((int)fl_x, 0);
+    const int x_hi = min((int)ceilf(in_x), f.w - 1);
+    const float lx = in_x - fl_x;
+
+    const uint8_t* r0 = f.rgb + (size_t)y_lo * f.w * 3;
+    const uint8_t* r1 = f.rgb + (size_t)y_hi * f.w * 3;
+    half_t v[4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float tl = (float)r0[x_lo * 3 + c], tr = (float)r0[x_hi * 3 + c];
+        const float bl = (float)r1[x_lo * 3 + c], br = (float)r1[x_hi * 3 + c];
+        const float top = tl + (tr - tl) * lx;
+        const float bot = bl + (br - bl) * lx;
+        const float px = top + (bot - top) * ly;
+        const float nv = (2.0f / 255.0f) * px - 1.0f;
+        v[c] = (half_t)nv;   // round-to-nearest-even
+    }
+    v[3] = (half_t)0.0f;
+    half4_t o = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<half4_t*>(out + ((size_t)blockIdx.y * size * size + pix) * 4) = o;
+}
+
+void wz_launch_preprocess(const WzFrameDesc* d_frames, int n, int size, half_t* out, hipStream_t s) {
+    dim3 grid((size * size + 255) / 256, n);
+    hipLaunchKernelGGL(wz_k_preprocess, grid, dim3(256), 0, s, d_frames, size, out);
+}

@@ -1,0 +1,93 @@
+// Internal declarations shared by the HIP translation units of libwatsor_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "../../include/watsor_hip.h"
+#include "wz_program.h"
+
+typedef _Float16 half_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 half8_t;
+typedef __attribute__((ext_vector_type(4))) _Float16 half4_t;
+typedef __attribute__((ext_vector_type(4))) float float4_t;
+
+// One frame handed to the pre-processing kernel.
+struct WzFrameDesc {
+    const uint8_t* rgb;   // packed RGB24, h x w x 3 (device)
+    int32_t w, h;
+    float scale_x, scale_y;   // (float)w / (float)size, TF legacy ResizeBilinear scale
+    int32_t cam;              // camera filter index or -1
+    int32_t _pad;
+};
+
+struct WzConvArgs {
+    const half_t* in;
+    const half_t* w;
+    const float* bias;
+    const half_t* res;     // residual (same shape as the fp16 output) or nullptr
+    void* out;             // half NHWC, or float head buffer, or float split-K workspace
+    int32_t M;             // n * hout * wout
+    int32_t hin, win, cin;
+    int32_t hout, wout, cout, n_pad;
+    int32_t ksize, stride, pad_t, pad_l, kc;
+    int32_t act, out_mode;
+    int32_t splitk;        // >1: raw fp32 partials to workspace [z][M][n_pad]
+    int32_t kchunks;       // ksize*ksize*kc
+    int64_t out_batch_stride;   // head modes: floats per frame in the concat buffer
+    int64_t out_off;            // head modes: first float of this feature map
+};
+
+// Per-camera filter state resident in HBM (see wz_set_camera_filter).
+struct WzCamFilter {
+    int32_t enabled, width, height, n_zones;
+    const int32_t* sat;          // [n_zones][(height+1)][(width+1)] inclusive-prefix sums, row/col 0 = 0
+    double conf_thr[WZ_NUM_LABELS];   // NaN = label not configured
+    double area_thr[WZ_NUM_LABELS];
+    uint8_t allow[WZ_NUM_LABELS][WZ_MAX_ZONES * 4]; // up to 40 zones tracked; allow[l][z]
+};
+#define WZ_MAX_ZONES_PER_CAM (WZ_MAX_ZONES * 4)
+
+struct WzPostConsts {
+    int32_t num_anchors, num_classes;   // classes incl. background
+    int32_t max_total, max_per_class;
+    float score_thr, iou_thr;
+    float scale_y, scale_x, scale_h, scale_w;
+};
+
+// ---- launchers (each enqueues exactly one kernel on `s`) ------------------------------------
+void wz_launch_preprocess(const WzFrameDesc* d_frames, int n, int size, half_t* out, hipStream_t s);
+void wz_launch_stem(const half_t* in, const float* w, const float* bias, half_t* out, int n, int hin, int win,
+                    int hout, int wout, int pad_t, int pad_l, hipStream_t s);
+void wz_launch_dw(const half_t* in, const half_t* w, const float* bias, half_t* out, int n, int hin, int win,
+                  int c, int hout, int wout, int stride, int pad_t, int pad_l, int act, hipStream_t s);
+void wz_launch_conv(const WzConvArgs& a, hipStream_t s);
+void wz_launch_splitk_reduce(const WzConvArgs& a, const float* ws, hipStream_t s);
+int wz_choose_splitk(int M, int n_pad, int kchunks);
+
+#define WZ_HIST_BINS 1024
+#define WZ_CAND_CAP 4096
+#define WZ_CAND_TARGET 512
+struct WzPostBuffers {
+    const float* box_enc;     // [n][A][4]
+    const float* logits;      // [n][A][C]
+    const float* anchors;     // [A][4] (ycenter, xcenter, h, w)
+    float* boxes;             // [n][A][4] decoded + clipped
+    uint8_t* valid;           // [n][A]   clipped area > 0
+    uint32_t* hist;           // [n][WZ_HIST_BINS]
+    uint32_t* count;          // [n]  (directly behind hist so one memset clears both)
+    uint2* cand;              // [n][WZ_CAND_CAP] (score bits, tie index c*A + a)
+    float* det_boxes;         // [n][100][4]
+    float* det_scores;        // [n][100]
+    int32_t* det_classes;     // [n][100] 1-based
+    int32_t* det_num;         // [n]
+};
+void wz_launch_decode(const WzPostBuffers& b, const WzPostConsts& c, int n, hipStream_t s);
+void wz_launch_hist(const WzPostBuffers& b, const WzPostConsts& c, int n, hipStream_t s);
+void wz_launch_compact(const WzPostBuffers& b, const WzPostConsts& c, int n, hipStream_t s);
+void wz_launch_nms(const WzPostBuffers& b, const WzPostConsts& c, int n, hipStream_t s);
+void wz_launch_rows(const WzPostBuffers& b, const WzFrameDesc* d_frames, const WzCamFilter* d_cams, int n,
+                    int max_total, wz_detection_t* rows, uint8_t* pass, hipStream_t s);
+void wz_post_init();   // one-time kernel attributes (must run before any stream capture)
+void wz_launch_filter_rows(const WzCamFilter* d_cams, int cam, wz_detection_t* rows, uint8_t* pass, hipStream_t s);
+void wz_launch_sat(const uint8_t* fill, int32_t* sat, int width, int height, int n_zones, hipStream_t s);

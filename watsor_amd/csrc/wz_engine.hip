@@ -1,0 +1,775 @@
+// Runtime + C ABI of libwatsor_hip.so (see include/watsor_hip.h for the contract of every entry point).
+//
+// One engine = one MI355X = one HIP stream.  A batch is one dependent chain of kernels
+// (pre-process -> ~70 conv ops -> post-process -> rows) captured once per (slot, batch size) into a
+// hipGraph and replayed; frame descriptors travel through a pinned host block that the graph's first
+// node copies to HBM, results come back through a pinned row block that its last nodes fill.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <chrono>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "wz_common.h"
+
+static thread_local char g_err[512] = "";
+static int wz_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIPCHK(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess) return wz_fail(WZ_EHIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                             __FILE__, __LINE__);                                     \
+    } while (0)
+
+#define WZ_MAX_CAMS 256
+#define WZ_WS_BYTES (64ull << 20)
+
+struct StageTimer {
+    std::vector<hipEvent_t> ev;
+    size_t used = 0;
+    hipStream_t s = nullptr;
+    void mark() {
+        if (used == ev.size()) {
+            hipEvent_t e;
+            (void)hipEventCreate(&e);
+            ev.push_back(e);
+        }
+        (void)hipEventRecord(ev[used++], s);
+    }
+};
+
+struct wz_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string name;
+    std::vector<uint8_t> blob;
+    WzBlobHeader hdr;
+    const WzTensorDesc* tensors = nullptr;
+    const WzOpDesc* ops = nullptr;
+    int max_batch = 0, max_w = 0, max_h = 0;
+    bool no_reuse = false, use_graph = true, use_splitk = true;
+
+    uint8_t* d_weights = nullptr;
+    float* d_anchors = nullptr;
+    std::vector<void*> bufs;                 // owned activation buffers
+    std::vector<half_t*> tptr;               // tensor index -> device pointer
+    uint8_t* d_frames = nullptr;             // staging for host frames [max_batch][max_w*max_h*3]
+    size_t frame_stride = 0;
+    float* d_box_enc = nullptr;
+    float* d_logits = nullptr;
+    float* d_ws = nullptr;
+    WzPostBuffers post;
+    WzPostConsts pc;
+    void* d_post_scratch = nullptr;          // hist + count (memset per batch)
+    size_t post_scratch_bytes = 0;
+
+    WzFrameDesc* h_desc[WZ_SLOTS] = {};      // pinned
+    WzFrameDesc* d_desc[WZ_SLOTS] = {};
+    wz_detection_t* d_rows[WZ_SLOTS] = {};
+    uint8_t* d_pass[WZ_SLOTS] = {};
+    wz_detection_t* h_rows[WZ_SLOTS] = {};   // pinned
+    uint8_t* h_pass[WZ_SLOTS] = {};
+    hipEvent_t slot_done[WZ_SLOTS] = {};
+    int slot_n[WZ_SLOTS] = {};
+    std::map<int, hipGraphExec_t> graphs;    // key = slot * 4096 + n
+
+    std::vector<WzCamFilter> h_cams;
+    WzCamFilter* d_cams = nullptr;
+    std::vector<int32_t*> cam_sat;
+    wz_detection_t* d_tmp_rows = nullptr;
+    uint8_t* d_tmp_pass = nullptr;
+
+    std::vector<std::string> stage_names;
+};
+
+static int input_tensor_index(wz_engine* e) { return e->ops[0].src; }
+
+// ------------------------------------------------------------------------------------------------
+// pipeline
+// ------------------------------------------------------------------------------------------------
+static void enqueue_network(wz_engine* e, int n, StageTimer* t) {
+    hipStream_t s = e->stream;
+    for (uint32_t i = 0; i < e->hdr.n_ops; ++i) {
+        const WzOpDesc& op = e->ops[i];
+        const uint8_t* wbase = e->d_weights;
+        if (op.kind == WZ_OP_STEM) {
+            wz_launch_stem(e->tptr[op.src], (const float*)(wbase + op.w_off), (const float*)(wbase + op.b_off),
+                           e->tptr[op.dst], n, op.hin, op.win, op.hout, op.wout, op.pad_t, op.pad_l, s);
+        } else if (op.kind == WZ_OP_DW) {
+            wz_launch_dw(e->tptr[op.src], (const half_t*)(wbase + op.w_off), (const float*)(wbase + op.b_off),
+                         e->tptr[op.dst], n, op.hin, op.win, op.cin, op.hout, op.wout, op.stride, op.pad_t,
+                         op.pad_l, op.act, s);
+        } else {
+            WzConvArgs a;
+            memset(&a, 0, sizeof(a));
+            a.in = e->tptr[op.src];
+            a.w = (const half_t*)(wbase + op.w_off);
+            a.bias = (const float*)(wbase + op.b_off);
+            a.res = op.res >= 0 ? e->tptr[op.res] : nullptr;
+            a.M = n * op.hout * op.wout;
+            a.hin = op.hin; a.win = op.win; a.cin = op.cin;
+            a.hout = op.hout; a.wout = op.wout; a.cout = op.cout; a.n_pad = op.n_pad;
+            a.ksize = op.ksize; a.stride = op.stride; a.pad_t = op.pad_t; a.pad_l = op.pad_l; a.kc = op.kc;
+            a.act = op.act; a.out_mode = op.out_mode;
+            a.kchunks = op.ksize * op.ksize * op.kc;
+            void* final_out;
+            if (op.out_mode == WZ_OUT_ACT) {
+                final_out = e->tptr[op.dst];
+            } else if (op.out_mode == WZ_OUT_BOX) {
+                final_out = e->d_box_enc;
+                a.out_batch_stride = (int64_t)e->hdr.num_anchors * 4;
+                a.out_off = (int64_t)op.anchor_off * 4;
+            } else {
+                final_out = e->d_logits;
+                a.out_batch_stride = (int64_t)e->hdr.num_anchors * e->hdr.num_classes;
+                a.out_off = (int64_t)op.anchor_off * e->hdr.num_classes;
+            }
+            int sk = e->use_splitk ? wz_choose_splitk(a.M, a.n_pad, a.kchunks) : 1;
+            while (sk > 1 && (size_t)sk * a.M * a.n_pad * 4 > WZ_WS_BYTES) --sk;
+            a.splitk = sk;
+            if (sk > 1) {
+                a.out = e->d_ws;
+                wz_launch_conv(a, s);
+                a.out = final_out;
+                wz_launch_splitk_reduce(a, e->d_ws, s);
+            } else {
+                a.out = final_out;
+                wz_launch_conv(a, s);
+            }
+        }
+        if (t) t->mark();
+    }
+}
+
+static void enqueue_post(wz_engine* e, int slot, int n, StageTimer* t) {
+    hipStream_t s = e->stream;
+    (void)hipMemsetAsync(e->d_post_scratch, 0, e->post_scratch_bytes, s);
+    wz_launch_decode(e->post, e->pc, n, s);
+    if (t) t->mark();
+    wz_launch_hist(e->post, e->pc, n, s);
+    if (t) t->mark();
+    wz_launch_compact(e->post, e->pc, n, s);
+    if (t) t->mark();
+    wz_launch_nms(e->post, e->pc, n, s);
+    if (t) t->mark();
+    if (slot >= 0) {
+        wz_launch_rows(e->post, e->d_desc[slot], e->d_cams, n, e->pc.max_total, e->d_rows[slot], e->d_pass[slot], s);
+        if (t) t->mark();
+    }
+}
+
+// everything between "descriptors are in h_desc[slot]" and "rows are in h_rows[slot]"
+static void enqueue_batch(wz_engine* e, int slot, int n, StageTimer* t) {
+    hipStream_t s = e->stream;
+    (void)hipMemcpyAsync(e->d_desc[slot], e->h_desc[slot], sizeof(WzFrameDesc) * n, hipMemcpyHostToDevice, s);
+    if (t) t->mark();
+    wz_launch_preprocess(e->d_desc[slot], n, (int)e->hdr.input_size, e->tptr[input_tensor_index(e)], s);
+    if (t) t->mark();
+    enqueue_network(e, n, t);
+    enqueue_post(e, slot, n, t);
+    (void)hipMemcpyAsync(e->h_rows[slot], e->d_rows[slot], sizeof(wz_detection_t) * WZ_MAX_DETECTIONS * n,
+                         hipMemcpyDeviceToHost, s);
+    (void)hipMemcpyAsync(e->h_pass[slot], e->d_pass[slot], (size_t)WZ_MAX_DETECTIONS * n, hipMemcpyDeviceToHost, s);
+}
+
+static int run_batch(wz_engine* e, int slot, int n) {
+    if (e->use_graph) {
+        const int key = slot * 4096 + n;
+        auto it = e->graphs.find(key);
+        if (it == e->graphs.end()) {
+            hipGraph_t g = nullptr;
+            HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+            enqueue_batch(e, slot, n, nullptr);
+            HIPCHK(hipStreamEndCapture(e->stream, &g));
+            hipGraphExec_t ge = nullptr;
+            HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(g);
+            it = e->graphs.emplace(key, ge).first;
+        }
+        HIPCHK(hipGraphLaunch(it->second, e->stream));
+    } else {
+        enqueue_batch(e, slot, n, nullptr);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(e->slot_done[slot], e->stream));
+    e->slot_n[slot] = n;
+    return WZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// lifecycle
+// ------------------------------------------------------------------------------------------------
+extern "C" int wz_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int wz_device_name_of(int device, char* buf, int buflen) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) return wz_fail(WZ_ENODEV, "no HIP device %d", device);
+    snprintf(buf, buflen, "%s (%s)", p.name, p.gcnArchName);
+    return WZ_OK;
+}
+
+extern "C" const char* wz_last_error(void) { return g_err; }
+
+static int load_blob(wz_engine* e, const char* path) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return wz_fail(WZ_ENOENT, "engine file not found: %s", path);
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    if (sz < (long)sizeof(WzBlobHeader)) {
+        fclose(f);
+        return wz_fail(WZ_EFORMAT, "engine file %s is truncated", path);
+    }
+    e->blob.resize(sz);
+    size_t rd = fread(e->blob.data(), 1, sz, f);
+    fclose(f);
+    if (rd != (size_t)sz) return wz_fail(WZ_EFORMAT, "short read on %s", path);
+    memcpy(&e->hdr, e->blob.data(), sizeof(WzBlobHeader));
+    const WzBlobHeader& h = e->hdr;
+    if (h.magic != WZ_MAGIC) return wz_fail(WZ_EFORMAT, "%s is not an mi355x engine (bad magic)", path);
+    if (h.version != WZ_FORMAT_VERSION)
+        return wz_fail(WZ_EFORMAT, "%s: engine format %u, runtime expects %u -- rebuild it with watsor_amd.engine",
+                       path, h.version, WZ_FORMAT_VERSION);
+    if (h.total_bytes != (uint64_t)sz || h.precision != 16 || h.max_total > WZ_MAX_DETECTIONS || h.max_total < 1 ||
+        h.num_classes > 4096 || h.n_ops == 0 || h.weights_off + h.weights_bytes > (uint64_t)sz ||
+        h.tensors_off + (uint64_t)h.n_tensors * sizeof(WzTensorDesc) > (uint64_t)sz ||
+        h.ops_off + (uint64_t)h.n_ops * sizeof(WzOpDesc) > (uint64_t)sz ||
+        h.anchors_off + (uint64_t)h.num_anchors * 16 > (uint64_t)sz)
+        return wz_fail(WZ_EFORMAT, "%s: inconsistent engine header", path);
+    e->tensors = reinterpret_cast<const WzTensorDesc*>(e->blob.data() + h.tensors_off);
+    e->ops = reinterpret_cast<const WzOpDesc*>(e->blob.data() + h.ops_off);
+    for (uint32_t i = 0; i < h.n_ops; ++i) {
+        const WzOpDesc& op = e->ops[i];
+        if (op.src < 0 || op.src >= (int)h.n_tensors || op.dst >= (int)h.n_tensors || op.res >= (int)h.n_tensors ||
+            (op.out_mode == WZ_OUT_ACT && op.dst < 0) || op.w_off < 0 || (uint64_t)op.w_off >= h.weights_bytes ||
+            (op.kind == WZ_OP_CONV && (op.n_pad % 32 != 0 || op.cin % 8 != 0 || op.cout % 4 != 0 ||
+                                       (op.ksize != 1 && op.ksize != 3))) ||
+            (op.kind == WZ_OP_DW && op.cin % 8 != 0))
+            return wz_fail(WZ_EFORMAT, "%s: op %u (%s) is malformed", path, i, op.name);
+    }
+    return WZ_OK;
+}
+
+extern "C" int wz_create(const char* engine_path, int device, int max_batch, int max_width, int max_height,
+                         wz_engine_t** out) {
+    if (!engine_path || !out || max_batch < 1 || max_batch > 4095 || max_width < 1 || max_height < 1)
+        return wz_fail(WZ_EINVAL, "wz_create: bad argument");
+    *out = nullptr;
+    wz_engine* e = new wz_engine();
+    int rc = load_blob(e, engine_path);
+    if (rc != WZ_OK) {
+        delete e;
+        return rc;
+    }
+    int ndev = wz_device_count();
+    if (device < 0 || device >= ndev) {
+        delete e;
+        return wz_fail(WZ_ENODEV, "HIP device %d not present (%d visible)", device, ndev);
+    }
+    e->device = device;
+    e->max_batch = max_batch;
+    e->max_w = max_width;
+    e->max_h = max_height;
+    const char* env;
+    e->no_reuse = (env = getenv("WZ_NO_BUFFER_REUSE")) && atoi(env) != 0;
+    e->use_graph = !((env = getenv("WZ_GRAPH")) && atoi(env) == 0);
+    e->use_splitk = !((env = getenv("WZ_SPLITK")) && atoi(env) == 0);
+
+#define CK(expr)                                                                                        \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) {                                                                         \
+            wz_fail(WZ_EHIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);       \
+            wz_destroy(e);                                                                              \
+            return WZ_EHIP;                                                                             \
+        }                                                                                               \
+    } while (0)
+
+    CK(hipSetDevice(device));
+    char nm[256];
+    wz_device_name_of(device, nm, sizeof(nm));
+    e->name = nm;
+    CK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    wz_post_init();
+
+    const WzBlobHeader& h = e->hdr;
+    CK(hipMalloc((void**)&e->d_weights, h.weights_bytes));
+    CK(hipMemcpy(e->d_weights, e->blob.data() + h.weights_off, h.weights_bytes, hipMemcpyHostToDevice));
+    CK(hipMalloc((void**)&e->d_anchors, (size_t)h.num_anchors * 16));
+    CK(hipMemcpy(e->d_anchors, e->blob.data() + h.anchors_off, (size_t)h.num_anchors * 16, hipMemcpyHostToDevice));
+
+    // activation buffers: one per slot (tensors with disjoint lifetimes share), or one per tensor
+    e->tptr.assign(h.n_tensors, nullptr);
+    if (e->no_reuse) {
+        for (uint32_t i = 0; i < h.n_tensors; ++i) {
+            const WzTensorDesc& t = e->tensors[i];
+            void* p = nullptr;
+            CK(hipMalloc(&p, (size_t)max_batch * t.h * t.w * t.c * 2 + 256));
+            e->bufs.push_back(p);
+            e->tptr[i] = (half_t*)p;
+        }
+    } else {
+        std::vector<size_t> slot_bytes(h.n_slots, 0);
+        for (uint32_t i = 0; i < h.n_tensors; ++i) {
+            const WzTensorDesc& t = e->tensors[i];
+            if (t.slot < 0 || t.slot >= (int)h.n_slots) {
+                wz_fail(WZ_EFORMAT, "tensor %u has a bad slot", i);
+                wz_destroy(e);
+                return WZ_EFORMAT;
+            }
+            size_t b = (size_t)max_batch * t.h * t.w * t.c * 2 + 256;
+            if (b > slot_bytes[t.slot]) slot_bytes[t.slot] = b;
+        }
+        for (uint32_t sidx = 0; sidx < h.n_slots; ++sidx) {
+            void* p = nullptr;
+            CK(hipMalloc(&p, slot_bytes[sidx]));
+            e->bufs.push_back(p);
+        }
+        for (uint32_t i = 0; i < h.n_tensors; ++i) e->tptr[i] = (half_t*)e->bufs[e->tensors[i].slot];
+    }
+
+    e->frame_stride = ((size_t)max_width * max_height * 3 + 255) & ~(size_t)255;
+    CK(hipMalloc((void**)&e->d_frames, e->frame_stride * max_batch));
+    CK(hipMalloc((void**)&e->d_box_enc, (size_t)max_batch * h.num_anchors * 4 * 4));
+    CK(hipMalloc((void**)&e->d_logits, (size_t)max_batch * h.num_anchors * h.num_classes * 4));
+    CK(hipMalloc((void**)&e->d_ws, WZ_WS_BYTES));
+
+    e->pc.num_anchors = h.num_anchors;
+    e->pc.num_classes = h.num_classes;
+    e->pc.max_total = h.max_total;
+    e->pc.max_per_class = h.max_per_class;
+    e->pc.score_thr = h.score_threshold;
+    e->pc.iou_thr = h.iou_threshold;
+    e->pc.scale_y = h.scale_y; e->pc.scale_x = h.scale_x; e->pc.scale_h = h.scale_h; e->pc.scale_w = h.scale_w;
+
+    WzPostBuffers& pb = e->post;
+    pb.box_enc = e->d_box_enc;
+    pb.logits = e->d_logits;
+    pb.anchors = e->d_anchors;
+    CK(hipMalloc((void**)&pb.boxes, (size_t)max_batch * h.num_anchors * 16));
+    CK(hipMalloc((void**)&pb.valid, (size_t)max_batch * h.num_anchors));
+    e->post_scratch_bytes = (size_t)max_batch * (WZ_HIST_BINS + 1) * 4;
+    CK(hipMalloc(&e->d_post_scratch, e->post_scratch_bytes));
+    pb.hist = (uint32_t*)e->d_post_scratch;
+    pb.count = pb.hist + (size_t)max_batch * WZ_HIST_BINS;
+    CK(hipMalloc((void**)&pb.cand, (size_t)max_batch * WZ_CAND_CAP * sizeof(uint2)));
+    CK(hipMalloc((void**)&pb.det_boxes, (size_t)max_batch * h.max_total * 16));
+    CK(hipMalloc((void**)&pb.det_scores, (size_t)max_batch * h.max_total * 4));
+    CK(hipMalloc((void**)&pb.det_classes, (size_t)max_batch * h.max_total * 4));
+    CK(hipMalloc((void**)&pb.det_num, (size_t)max_batch * 4));
+
+    for (int sidx = 0; sidx < WZ_SLOTS; ++sidx) {
+        CK(hipHostMalloc((void**)&e->h_desc[sidx], sizeof(WzFrameDesc) * max_batch, hipHostMallocDefault));
+        CK(hipMalloc((void**)&e->d_desc[sidx], sizeof(WzFrameDesc) * max_batch));
+        CK(hipMalloc((void**)&e->d_rows[sidx], sizeof(wz_detection_t) * WZ_MAX_DETECTIONS * max_batch));
+        CK(hipMalloc((void**)&e->d_pass[sidx], (size_t)WZ_MAX_DETECTIONS * max_batch));
+        CK(hipHostMalloc((void**)&e->h_rows[sidx], sizeof(wz_detection_t) * WZ_MAX_DETECTIONS * max_batch,
+                         hipHostMallocDefault));
+        CK(hipHostMalloc((void**)&e->h_pass[sidx], (size_t)WZ_MAX_DETECTIONS * max_batch, hipHostMallocDefault));
+        CK(hipEventCreateWithFlags(&e->slot_done[sidx], hipEventDisableTiming));
+    }
+
+    e->h_cams.resize(WZ_MAX_CAMS);
+    memset(e->h_cams.data(), 0, sizeof(WzCamFilter) * WZ_MAX_CAMS);
+    e->cam_sat.assign(WZ_MAX_CAMS, nullptr);
+    CK(hipMalloc((void**)&e->d_cams, sizeof(WzCamFilter) * WZ_MAX_CAMS));
+    CK(hipMemset(e->d_cams, 0, sizeof(WzCamFilter) * WZ_MAX_CAMS));
+    CK(hipMalloc((void**)&e->d_tmp_rows, sizeof(wz_detection_t) * WZ_MAX_DETECTIONS));
+    CK(hipMalloc((void**)&e->d_tmp_pass, WZ_MAX_DETECTIONS));
+
+    e->stage_names.push_back("h2d_descriptors");
+    e->stage_names.push_back("preprocess");
+    for (uint32_t i = 0; i < h.n_ops; ++i) e->stage_names.push_back(e->ops[i].name);
+    e->stage_names.push_back("post/decode");
+    e->stage_names.push_back("post/hist");
+    e->stage_names.push_back("post/compact");
+    e->stage_names.push_back("post/nms");
+    e->stage_names.push_back("post/rows");
+    CK(hipDeviceSynchronize());
+#undef CK
+    *out = e;
+    return WZ_OK;
+}
+
+extern "C" void wz_destroy(wz_engine_t* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
+    for (void* p : e->bufs) (void)hipFree(p);
+    for (int32_t* p : e->cam_sat)
+        if (p) (void)hipFree(p);
+    void* devp[] = {e->d_weights, e->d_anchors, e->d_frames, e->d_box_enc, e->d_logits, e->d_ws, e->post.boxes,
+                    e->post.valid, e->d_post_scratch, e->post.cand, e->post.det_boxes, e->post.det_scores,
+                    e->post.det_classes, e->post.det_num, e->d_cams, e->d_tmp_rows, e->d_tmp_pass};
+    for (void* p : devp)
+        if (p) (void)hipFree(p);
+    for (int s = 0; s < WZ_SLOTS; ++s) {
+        if (e->h_desc[s]) (void)hipHostFree(e->h_desc[s]);
+        if (e->d_desc[s]) (void)hipFree(e->d_desc[s]);
+        if (e->d_rows[s]) (void)hipFree(e->d_rows[s]);
+        if (e->d_pass[s]) (void)hipFree(e->d_pass[s]);
+        if (e->h_rows[s]) (void)hipHostFree(e->h_rows[s]);
+        if (e->h_pass[s]) (void)hipHostFree(e->h_pass[s]);
+        if (e->slot_done[s]) (void)hipEventDestroy(e->slot_done[s]);
+    }
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+extern "C" const char* wz_device_name(wz_engine_t* e) { return e ? e->name.c_str() : ""; }
+
+// ------------------------------------------------------------------------------------------------
+// the hot call
+// ------------------------------------------------------------------------------------------------
+static int fill_desc(wz_engine* e, int slot, int n, const uint8_t* const* d_rgb, const int* w, const int* h,
+                     const int* cam) {
+    if (slot < 0 || slot >= WZ_SLOTS) return wz_fail(WZ_EINVAL, "slot %d out of range", slot);
+    if (n < 1 || n > e->max_batch) return wz_fail(WZ_ELIMIT, "batch %d exceeds max_batch %d", n, e->max_batch);
+    const float size = (float)e->hdr.input_size;
+    for (int i = 0; i < n; ++i) {
+        if (w[i] < 1 || h[i] < 1 || !d_rgb[i]) return wz_fail(WZ_EINVAL, "frame %d: bad pointer or size", i);
+        const int c = cam ? cam[i] : -1;
+        if (c >= WZ_MAX_CAMS) return wz_fail(WZ_ELIMIT, "camera id %d >= %d", c, WZ_MAX_CAMS);
+        if (c >= 0 && e->h_cams[c].enabled && (e->h_cams[c].width != w[i] || e->h_cams[c].height != h[i]))
+            return wz_fail(WZ_EINVAL, "frame %d is %dx%d but camera %d filter was set for %dx%d", i, w[i], h[i], c,
+                           e->h_cams[c].width, e->h_cams[c].height);
+        WzFrameDesc& d = e->h_desc[slot][i];
+        d.rgb = d_rgb[i];
+        d.w = w[i];
+        d.h = h[i];
+        d.scale_x = (float)w[i] / size;   // CalculateResizeScale(in, out, align_corners=false)
+        d.scale_y = (float)h[i] / size;
+        d.cam = c < 0 ? -1 : c;
+        d._pad = 0;
+    }
+    return WZ_OK;
+}
+
+extern "C" int wz_submit_device(wz_engine_t* e, int slot, int n, const uint8_t* const* d_rgb, const int* w,
+                                const int* h, const int* cam) {
+    if (!e || !d_rgb || !w || !h) return wz_fail(WZ_EINVAL, "wz_submit_device: null argument");
+    HIPCHK(hipSetDevice(e->device));
+    if (slot >= 0 && slot < WZ_SLOTS) HIPCHK(hipEventSynchronize(e->slot_done[slot]));  // slot free again?
+    int rc = fill_desc(e, slot, n, d_rgb, w, h, cam);
+    if (rc != WZ_OK) return rc;
+    return run_batch(e, slot, n);
+}
+
+extern "C" int wz_wait(wz_engine_t* e, int slot) {
+    if (!e || slot < 0 || slot >= WZ_SLOTS) return wz_fail(WZ_EINVAL, "wz_wait: bad argument");
+    HIPCHK(hipEventSynchronize(e->slot_done[slot]));
+    return WZ_OK;
+}
+
+extern "C" const wz_detection_t* wz_slot_rows(wz_engine_t* e, int slot) {
+    if (!e || slot < 0 || slot >= WZ_SLOTS) return nullptr;
+    return e->h_rows[slot];
+}
+
+extern "C" int wz_collect(wz_engine_t* e, int slot, wz_detection_t* const* out, uint8_t* const* pass) {
+    int rc = wz_wait(e, slot);
+    if (rc != WZ_OK) return rc;
+    const int n = e->slot_n[slot];
+    for (int i = 0; i < n; ++i) {
+        if (out && out[i])
+            memcpy(out[i], e->h_rows[slot] + (size_t)i * WZ_MAX_DETECTIONS, sizeof(wz_detection_t) * WZ_MAX_DETECTIONS);
+        if (pass && pass[i]) memcpy(pass[i], e->h_pass[slot] + (size_t)i * WZ_MAX_DETECTIONS, WZ_MAX_DETECTIONS);
+    }
+    return WZ_OK;
+}
+
+extern "C" int wz_sync(wz_engine_t* e) {
+    if (!e) return wz_fail(WZ_EINVAL, "wz_sync: null engine");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return WZ_OK;
+}
+
+extern "C" int wz_detect_batch(wz_engine_t* e, int n, const uint8_t* const* rgb, const int* w, const int* h,
+                               const int* cam, wz_detection_t* const* out, uint8_t* const* pass, float* ms) {
+    if (!e || !rgb || !w || !h) return wz_fail(WZ_EINVAL, "wz_detect_batch: null argument");
+    if (n < 1 || n > e->max_batch) return wz_fail(WZ_ELIMIT, "batch %d exceeds max_batch %d", n, e->max_batch);
+    const auto t0 = std::chrono::steady_clock::now();
+    HIPCHK(hipSetDevice(e->device));
+    std::vector<const uint8_t*> dptr(n);
+    for (int i = 0; i < n; ++i) {
+        if (!rgb[i] || w[i] < 1 || h[i] < 1) return wz_fail(WZ_EINVAL, "frame %d: bad pointer or size", i);
+        if (w[i] > e->max_w || h[i] > e->max_h || (size_t)w[i] * h[i] * 3 > e->frame_stride)
+            return wz_fail(WZ_ELIMIT, "frame %d is %dx%d, engine was created for at most %dx%d", i, w[i], h[i],
+                           e->max_w, e->max_h);
+        uint8_t* dst = e->d_frames + e->frame_stride * i;
+        HIPCHK(hipMemcpyAsync(dst, rgb[i], (size_t)w[i] * h[i] * 3, hipMemcpyHostToDevice, e->stream));
+        dptr[i] = dst;
+    }
+    int rc = wz_submit_device(e, 0, n, dptr.data(), w, h, cam);
+    if (rc != WZ_OK) return rc;
+    rc = wz_collect(e, 0, out, pass);
+    if (rc != WZ_OK) return rc;
+    const float el = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (ms)
+        for (int i = 0; i < n; ++i) ms[i] = el;
+    return WZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// filters
+// ------------------------------------------------------------------------------------------------
+extern "C" int wz_set_camera_filter(wz_engine_t* e, int cam, int width, int height, const double* conf_thr,
+                                    const double* area_thr, int n_zones, const uint8_t* zone_allow,
+                                    const uint8_t* zone_fill) {
+    if (!e || !conf_thr || !area_thr || width < 1 || height < 1) return wz_fail(WZ_EINVAL, "wz_set_camera_filter: bad argument");
+    if (cam < 0 || cam >= WZ_MAX_CAMS) return wz_fail(WZ_ELIMIT, "camera id %d out of range [0,%d)", cam, WZ_MAX_CAMS);
+    if (n_zones < 0 || n_zones > WZ_MAX_ZONES_PER_CAM) return wz_fail(WZ_ELIMIT, "%d zones > %d", n_zones, WZ_MAX_ZONES_PER_CAM);
+    if (n_zones > 0 && !zone_fill) return wz_fail(WZ_EINVAL, "zone_fill is null");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    WzCamFilter& c = e->h_cams[cam];
+    if (e->cam_sat[cam]) {
+        (void)hipFree(e->cam_sat[cam]);
+        e->cam_sat[cam] = nullptr;
+    }
+    memset(&c, 0, sizeof(c));
+    c.enabled = 1;
+    c.width = width;
+    c.height = height;
+    c.n_zones = n_zones;
+    memcpy(c.conf_thr, conf_thr, sizeof(double) * WZ_NUM_LABELS);
+    memcpy(c.area_thr, area_thr, sizeof(double) * WZ_NUM_LABELS);
+    for (int l = 0; l < WZ_NUM_LABELS; ++l)
+        for (int z = 0; z < n_zones; ++z) c.allow[l][z] = zone_allow ? (zone_allow[(size_t)l * n_zones + z] ? 1 : 0) : 1;
+    if (n_zones > 0) {
+        const size_t plane = (size_t)(width + 1) * (height + 1);
+        int32_t* sat = nullptr;
+        uint8_t* d_fill = nullptr;
+        HIPCHK(hipMalloc((void**)&sat, plane * n_zones * 4));
+        HIPCHK(hipMalloc((void**)&d_fill, (size_t)width * height * n_zones));
+        HIPCHK(hipMemcpy(d_fill, zone_fill, (size_t)width * height * n_zones, hipMemcpyHostToDevice));
+        wz_launch_sat(d_fill, sat, width, height, n_zones, e->stream);
+        HIPCHK(hipStreamSynchronize(e->stream));
+        (void)hipFree(d_fill);
+        e->cam_sat[cam] = sat;
+        c.sat = sat;
+    }
+    HIPCHK(hipMemcpy(e->d_cams + cam, &c, sizeof(WzCamFilter), hipMemcpyHostToDevice));
+    return WZ_OK;
+}
+
+extern "C" int wz_clear_camera_filter(wz_engine_t* e, int cam) {
+    if (!e || cam < 0 || cam >= WZ_MAX_CAMS) return wz_fail(WZ_EINVAL, "wz_clear_camera_filter: bad argument");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    memset(&e->h_cams[cam], 0, sizeof(WzCamFilter));
+    HIPCHK(hipMemcpy(e->d_cams + cam, &e->h_cams[cam], sizeof(WzCamFilter), hipMemcpyHostToDevice));
+    if (e->cam_sat[cam]) {
+        (void)hipFree(e->cam_sat[cam]);
+        e->cam_sat[cam] = nullptr;
+    }
+    return WZ_OK;
+}
+
+extern "C" int wz_filter_rows(wz_engine_t* e, int cam, wz_detection_t* rows, uint8_t* pass) {
+    if (!e || !rows || !pass || cam < 0 || cam >= WZ_MAX_CAMS) return wz_fail(WZ_EINVAL, "wz_filter_rows: bad argument");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpyAsync(e->d_tmp_rows, rows, sizeof(wz_detection_t) * WZ_MAX_DETECTIONS, hipMemcpyHostToDevice, e->stream));
+    wz_launch_filter_rows(e->d_cams, cam, e->d_tmp_rows, e->d_tmp_pass, e->stream);
+    HIPCHK(hipMemcpyAsync(rows, e->d_tmp_rows, sizeof(wz_detection_t) * WZ_MAX_DETECTIONS, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(pass, e->d_tmp_pass, WZ_MAX_DETECTIONS, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return WZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// introspection / profiling
+// ------------------------------------------------------------------------------------------------
+extern "C" int wz_input_size(wz_engine_t* e) { return e ? (int)e->hdr.input_size : 0; }
+extern "C" int wz_num_anchors(wz_engine_t* e) { return e ? (int)e->hdr.num_anchors : 0; }
+extern "C" int wz_num_classes(wz_engine_t* e) { return e ? (int)e->hdr.num_classes : 0; }
+extern "C" int wz_num_tensors(wz_engine_t* e) { return e ? (int)e->hdr.n_tensors : 0; }
+extern "C" int wz_num_ops(wz_engine_t* e) { return e ? (int)e->hdr.n_ops : 0; }
+
+extern "C" int wz_tensor_info(wz_engine_t* e, int idx, char* name, int namelen, int* h, int* w, int* c) {
+    if (!e || idx < 0 || idx >= (int)e->hdr.n_tensors) return wz_fail(WZ_EINVAL, "tensor index %d", idx);
+    const WzTensorDesc& t = e->tensors[idx];
+    if (name && namelen > 0) snprintf(name, namelen, "%s", t.name);
+    if (h) *h = t.h;
+    if (w) *w = t.w;
+    if (c) *c = t.c;
+    return WZ_OK;
+}
+
+extern "C" int wz_op_info(wz_engine_t* e, int idx, char* name, int namelen, int* dims) {
+    if (!e || idx < 0 || idx >= (int)e->hdr.n_ops) return wz_fail(WZ_EINVAL, "op index %d", idx);
+    const WzOpDesc& o = e->ops[idx];
+    if (name && namelen > 0) snprintf(name, namelen, "%s", o.name);
+    if (dims) {
+        const int v[12] = {o.kind, o.cin, o.cout, o.ksize, o.stride, o.hin, o.win, o.hout, o.wout, o.n_pad, o.kc, 0};
+        memcpy(dims, v, sizeof(v));
+    }
+    return WZ_OK;
+}
+
+extern "C" int wz_num_stages(wz_engine_t* e) { return e ? (int)e->stage_names.size() : 0; }
+extern "C" int wz_stage_name(wz_engine_t* e, int stage, char* name, int namelen) {
+    if (!e || stage < 0 || stage >= (int)e->stage_names.size()) return wz_fail(WZ_EINVAL, "stage index %d", stage);
+    snprintf(name, namelen, "%s", e->stage_names[stage].c_str());
+    return WZ_OK;
+}
+
+extern "C" int wz_profile_device(wz_engine_t* e, int n, const uint8_t* const* d_rgb, const int* w, const int* h,
+                                 int reps, float* stage_ms) {
+    if (!e || !stage_ms || reps < 1) return wz_fail(WZ_EINVAL, "wz_profile_device: bad argument");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    int rc = fill_desc(e, 0, n, d_rgb, w, h, nullptr);
+    if (rc != WZ_OK) return rc;
+    const size_t ns = e->stage_names.size();
+    std::vector<double> acc(ns, 0.0);
+    StageTimer t;
+    t.s = e->stream;
+    for (int r = 0; r < reps + 1; ++r) {   // first repetition is an untimed warm-up
+        t.used = 0;
+        t.mark();
+        enqueue_batch(e, 0, n, &t);
+        HIPCHK(hipStreamSynchronize(e->stream));
+        if (t.used != ns + 1) return wz_fail(WZ_EINVAL, "profile: %zu marks for %zu stages", t.used, ns);
+        if (r == 0) continue;
+        for (size_t i = 0; i < ns; ++i) {
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, t.ev[i], t.ev[i + 1]));
+            acc[i] += ms;
+        }
+    }
+    for (size_t i = 0; i < ns; ++i) stage_ms[i] = (float)(acc[i] / reps);
+    for (hipEvent_t ev : t.ev) (void)hipEventDestroy(ev);
+    return WZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// device memory helpers
+// ------------------------------------------------------------------------------------------------
+extern "C" int wz_dev_alloc(wz_engine_t* e, uint64_t bytes, void** d_ptr) {
+    if (!e || !d_ptr) return wz_fail(WZ_EINVAL, "wz_dev_alloc: null argument");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMalloc(d_ptr, bytes));
+    return WZ_OK;
+}
+extern "C" int wz_dev_free(wz_engine_t* e, void* d_ptr) {
+    if (!e) return wz_fail(WZ_EINVAL, "wz_dev_free: null engine");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipFree(d_ptr));
+    return WZ_OK;
+}
+extern "C" int wz_dev_upload(wz_engine_t* e, void* d_dst, const void* h_src, uint64_t bytes) {
+    if (!e) return wz_fail(WZ_EINVAL, "wz_dev_upload: null engine");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+    return WZ_OK;
+}
+extern "C" int wz_dev_download(wz_engine_t* e, void* h_dst, const void* d_src, uint64_t bytes) {
+    if (!e) return wz_fail(WZ_EINVAL, "wz_dev_download: null engine");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return WZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage-level entry points (parity tests)
+// ------------------------------------------------------------------------------------------------
+extern "C" int wz_stage_preprocess(wz_engine_t* e, const uint8_t* rgb, int w, int h, uint16_t* out_half) {
+    if (!e || !rgb || !out_half) return wz_fail(WZ_EINVAL, "wz_stage_preprocess: null argument");
+    if (w > e->max_w || h > e->max_h || (size_t)w * h * 3 > e->frame_stride) return wz_fail(WZ_ELIMIT, "frame too large");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(e->d_frames, rgb, (size_t)w * h * 3, hipMemcpyHostToDevice));
+    const uint8_t* p = e->d_frames;
+    int rc = fill_desc(e, 0, 1, &p, &w, &h, nullptr);
+    if (rc != WZ_OK) return rc;
+    HIPCHK(hipMemcpyAsync(e->d_desc[0], e->h_desc[0], sizeof(WzFrameDesc), hipMemcpyHostToDevice, e->stream));
+    const int S = (int)e->hdr.input_size;
+    wz_launch_preprocess(e->d_desc[0], 1, S, e->tptr[input_tensor_index(e)], e->stream);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(out_half, e->tptr[input_tensor_index(e)], (size_t)S * S * 4 * 2, hipMemcpyDeviceToHost));
+    return WZ_OK;
+}
+
+extern "C" int wz_stage_forward(wz_engine_t* e, int n, const uint16_t* in_half, float* box_enc, float* logits) {
+    if (!e || !in_half) return wz_fail(WZ_EINVAL, "wz_stage_forward: null argument");
+    if (n < 1 || n > e->max_batch) return wz_fail(WZ_ELIMIT, "batch %d exceeds max_batch %d", n, e->max_batch);
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const int S = (int)e->hdr.input_size;
+    HIPCHK(hipMemcpy(e->tptr[input_tensor_index(e)], in_half, (size_t)n * S * S * 4 * 2, hipMemcpyHostToDevice));
+    enqueue_network(e, n, nullptr);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipGetLastError());
+    if (box_enc) HIPCHK(hipMemcpy(box_enc, e->d_box_enc, (size_t)n * e->hdr.num_anchors * 16, hipMemcpyDeviceToHost));
+    if (logits)
+        HIPCHK(hipMemcpy(logits, e->d_logits, (size_t)n * e->hdr.num_anchors * e->hdr.num_classes * 4, hipMemcpyDeviceToHost));
+    return WZ_OK;
+}
+
+extern "C" int wz_stage_read_tensor(wz_engine_t* e, int idx, int frame, uint16_t* out_half) {
+    if (!e || !out_half || idx < 0 || idx >= (int)e->hdr.n_tensors || frame < 0 || frame >= e->max_batch)
+        return wz_fail(WZ_EINVAL, "wz_stage_read_tensor: bad argument");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const WzTensorDesc& t = e->tensors[idx];
+    const size_t per = (size_t)t.h * t.w * t.c;
+    HIPCHK(hipMemcpy(out_half, e->tptr[idx] + per * frame, per * 2, hipMemcpyDeviceToHost));
+    return WZ_OK;
+}
+
+extern "C" int wz_stage_postprocess(wz_engine_t* e, int n, const float* box_enc, const float* logits, float* boxes,
+                                    float* scores, int32_t* classes, int32_t* num) {
+    if (!e || !box_enc || !logits) return wz_fail(WZ_EINVAL, "wz_stage_postprocess: null argument");
+    if (n < 1 || n > e->max_batch) return wz_fail(WZ_ELIMIT, "batch %d exceeds max_batch %d", n, e->max_batch);
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const size_t A = e->hdr.num_anchors, C = e->hdr.num_classes, T = e->hdr.max_total;
+    HIPCHK(hipMemcpy(e->d_box_enc, box_enc, n * A * 16, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_logits, logits, n * A * C * 4, hipMemcpyHostToDevice));
+    enqueue_post(e, -1, n, nullptr);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipGetLastError());
+    if (boxes) HIPCHK(hipMemcpy(boxes, e->post.det_boxes, n * T * 16, hipMemcpyDeviceToHost));
+    if (scores) HIPCHK(hipMemcpy(scores, e->post.det_scores, n * T * 4, hipMemcpyDeviceToHost));
+    if (classes) HIPCHK(hipMemcpy(classes, e->post.det_classes, n * T * 4, hipMemcpyDeviceToHost));
+    if (num) HIPCHK(hipMemcpy(num, e->post.det_num, n * 4, hipMemcpyDeviceToHost));
+    return WZ_OK;
+}
+
+extern "C" int wz_stage_rows(wz_engine_t* e, int w, int h, const float* boxes, const float* scores,
+                             const int32_t* classes, wz_detection_t* rows) {
+    if (!e || !boxes || !scores || !classes || !rows) return wz_fail(WZ_EINVAL, "wz_stage_rows: null argument");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const size_t T = e->hdr.max_total;
+    HIPCHK(hipMemcpy(e->post.det_boxes, boxes, T * 16, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->post.det_scores, scores, T * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->post.det_classes, classes, T * 4, hipMemcpyHostToDevice));
+    WzFrameDesc& d = e->h_desc[0][0];
+    memset(&d, 0, sizeof(d));
+    d.w = w;
+    d.h = h;
+    d.cam = -1;
+    HIPCHK(hipMemcpyAsync(e->d_desc[0], e->h_desc[0], sizeof(WzFrameDesc), hipMemcpyHostToDevice, e->stream));
+    wz_launch_rows(e->post, e->d_desc[0], e->d_cams, 1, e->pc.max_total, e->d_rows[0], e->d_pass[0], e->stream);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(rows, e->d_rows[0], sizeof(wz_detection_t) * WZ_MAX_DETECTIONS, hipMemcpyDeviceToHost));
+    return WZ_OK;
+}

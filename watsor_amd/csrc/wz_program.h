@@ -1,0 +1,56 @@
+// Engine file format ("mi355x.bin") shared by the packer (watsor_amd/engine.py) and the runtime.
+//
+// The reference's GPU plugin loads an opaque serialized TensorRT engine (`watsor/engine.py:54-65`,
+// `watsor/detection/tensorrt_gpu.py:28-34`); this is the MI355X analogue: a flat, little-endian,
+// position-independent image holding the op program, the anchors, the post-processing constants and
+// the weights already BatchNorm-folded, fp16-rounded and laid out for the HIP kernels.
+#pragma once
+#include <stdint.h>
+
+#define WZ_MAGIC 0x35335A57u /* "WZ35" */
+#define WZ_FORMAT_VERSION 3u
+
+enum WzOpKind { WZ_OP_STEM = 1, WZ_OP_DW = 2, WZ_OP_CONV = 3 };
+enum WzOutMode { WZ_OUT_ACT = 0, WZ_OUT_BOX = 1, WZ_OUT_CLS = 2 };
+enum WzAct { WZ_ACT_NONE = 0, WZ_ACT_RELU6 = 1 };
+
+#pragma pack(push, 1)
+struct WzBlobHeader {  // 160 bytes
+    uint32_t magic, version, precision, input_size;
+    uint32_t num_classes;     // class-head columns per anchor, background included (91)
+    uint32_t num_anchors;     // 1917
+    uint32_t n_tensors, n_ops;
+    uint32_t max_total, max_per_class;
+    float score_threshold, iou_threshold;
+    float scale_y, scale_x, scale_h, scale_w;   // box coder scale factors (10,10,5,5)
+    uint64_t tensors_off, ops_off, anchors_off, weights_off, weights_bytes, total_bytes;
+    uint32_t n_slots;         // activation buffer slots after liveness packing
+    uint32_t reserved[11];
+};
+
+struct WzTensorDesc {  // 64 bytes
+    int32_t h, w, c;          // per frame, NHWC; c is the stored channel count (input: 4)
+    int32_t slot;             // buffer slot (tensors with disjoint lifetimes share one)
+    char name[48];
+};
+
+struct WzOpDesc {  // 192 bytes
+    int32_t kind, src, dst, res;            // tensor indices, res = -1 when absent
+    int32_t cin, cout, ksize, stride;
+    int32_t hin, win, hout, wout;
+    int32_t pad_t, pad_l, act, out_mode;
+    int32_t anchor_off, anchors_per_loc;    // head ops: first anchor of this feature map
+    int32_t n_pad;                          // packed output columns (multiple of 32) for WZ_OP_CONV
+    int32_t kc;                             // 32-channel K chunks per filter tap (ceil(cin/32))
+    int64_t w_off, b_off;                   // byte offsets from weights_off
+    int32_t reserved[8];
+    char name[64];
+};
+#pragma pack(pop)
+
+// Weight layouts (all offsets 256-byte aligned):
+//  WZ_OP_STEM : float  w[27][32]  (k = (ky*3+kx)*3 + c), float bias[32]
+//  WZ_OP_DW   : half   w[9][C]    (tap-major, channel innermost), float bias[C]
+//  WZ_OP_CONV : half   w[n_pad/16][taps][kc][64 lanes][8]  where lane l of N-tile t holds
+//               W[k = chunk*32 + (l>>4)*8 + j][n = t*16 + (l&15)], zero beyond cin / cout
+//               (exactly the A-operand fragment of v_mfma_f32_16x16x32_f16), float bias[n_pad]

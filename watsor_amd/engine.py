@@ -1,0 +1,241 @@
+"""Engine builder: model weights -> `mi355x.bin`, the file `HipObjectDetector` loads.
+
+MI355X analogue of `watsor/engine.py:17-107` (TensorRT engine builder CLI, run once before the
+application starts, auto-invoked by `watsor/main_for_gpu.py:17-26` when `gpu.uff`/`gpu.onnx` exists
+without `gpu.trt`).  Same command line shape (`-i/--input`, `-p/--precision {32,16}`, `-w`, `-mw`,
+`-mh`, `-o/--output`); the input is an `.npz` of TF variables (names as in the frozen graph of
+`ssd_mobilenet_v2_coco`, TF layouts, BatchNorm unfolded) or the literal `synthetic[:seed]`.
+
+What building does: fold every FusedBatchNorm into its convolution (fp64), round to fp16, lay the
+weights out in the MFMA fragment order the HIP kernels read (csrc/wz_program.h), generate the anchor
+table, assign activation tensors to HBM buffer slots by liveness, and write one flat image.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import struct
+import sys
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from . import arch
+from .anchors import ssd_anchor_table
+
+MAGIC = 0x35335A57
+FORMAT_VERSION = 3
+BN_EPSILON = 1e-3          # watsor/test/model/prepare.py:48
+
+DEFAULT_POST = dict(max_total=100, max_per_class=100, score_threshold=1e-8, iou_threshold=0.6,
+                    scales=(10.0, 10.0, 5.0, 5.0))   # prepare.py:54-61,120-128; SURVEY.md App. B.5
+
+
+def _align(n: int, a: int = 256) -> int:
+    return (n + a - 1) // a * a
+
+
+def fold_batch_norm(W: Dict[str, np.ndarray], op: "arch.Op"):
+    """(weights float64 in TF layout, bias float64[cout]) with BatchNorm folded in."""
+    if op.kind == arch.OP_DW:
+        w = W[op.scope + "/depthwise_weights"].astype(np.float64)        # [k,k,C,1]
+    else:
+        w = W[op.scope + "/weights"].astype(np.float64)                  # [k,k,cin,cout]
+    if not op.has_bn:
+        return w, W[op.scope + "/biases"].astype(np.float64)
+    g = W[op.scope + "/BatchNorm/gamma"].astype(np.float64)
+    b = W[op.scope + "/BatchNorm/beta"].astype(np.float64)
+    m = W[op.scope + "/BatchNorm/moving_mean"].astype(np.float64)
+    v = W[op.scope + "/BatchNorm/moving_variance"].astype(np.float64)
+    s = g / np.sqrt(v + BN_EPSILON)
+    w = w * (s[None, None, :, None] if op.kind == arch.OP_DW else s[None, None, None, :])
+    return w, b - m * s
+
+
+def pack_conv_weights(w: np.ndarray, n_pad: int, kc: int) -> np.ndarray:
+    """[k,k,cin,cout] -> fp16 [n_pad/16][taps][kc][64][8] (A-operand fragments of mfma_f32_16x16x32_f16)."""
+    k, _, cin, cout = w.shape
+    taps = k * k
+    wp = np.zeros((taps, kc * 32, n_pad), np.float32)
+    wp[:, :cin, :cout] = w.reshape(taps, cin, cout)
+    # k index = c*32 + g*8 + j ; n index = t*16 + r ; lane = g*16 + r
+    wp = wp.reshape(taps, kc, 4, 8, n_pad // 16, 16)            # [tap][c][g][j][t][r]
+    wp = wp.transpose(4, 0, 1, 2, 5, 3)                         # [t][tap][c][g][r][j]
+    return np.ascontiguousarray(wp).astype(np.float16).reshape(-1)
+
+
+def assign_slots(prog: "arch.Program", tensor_names: List[str]) -> List[int]:
+    """Liveness-based buffer sharing: tensors whose lifetimes do not overlap reuse one HBM buffer."""
+    index = {n: i for i, n in enumerate(tensor_names)}
+    last_use = {n: -1 for n in tensor_names}
+    for oi, op in enumerate(prog.ops):
+        last_use[op.src] = oi
+        if op.res:
+            last_use[op.res] = oi
+    size = {n: prog.tensors[n].h * prog.tensors[n].w * (4 if n == "input" else prog.tensors[n].c) for n in tensor_names}
+    slot_of = [-1] * len(tensor_names)
+    slot_size: List[int] = []
+    free: List[int] = []
+    slot_of[index["input"]] = 0
+    slot_size.append(size["input"])
+    for oi, op in enumerate(prog.ops):
+        if op.out_mode == arch.OUT_ACT:
+            need = size[op.dst]
+            best = None
+            for s in free:                                   # best fit among free slots
+                if best is None or abs(slot_size[s] - need) < abs(slot_size[best] - need):
+                    best = s
+            if best is None:
+                best = len(slot_size)
+                slot_size.append(need)
+            else:
+                free.remove(best)
+                slot_size[best] = max(slot_size[best], need)
+            slot_of[index[op.dst]] = best
+            if last_use[op.dst] < 0:                         # never read (cannot happen in this graph)
+                free.append(best)
+        for n in {op.src, op.res} - {None}:
+            if last_use[n] == oi:
+                free.append(slot_of[index[n]])
+    return slot_of
+
+
+def build_engine(weights: Dict[str, np.ndarray], precision: int = 16, model_width: int = 300,
+                 model_height: int = 300, post: Optional[dict] = None) -> bytes:
+    """Returns the engine image.  Mirrors `build_engine` of watsor/engine.py:17-51."""
+    if precision != 16:
+        raise ValueError("only -p 16 (fp16 storage, fp32 accumulate) is implemented on MI355X")
+    if model_width != model_height:
+        raise ValueError("square model input expected")
+    cfg = dict(DEFAULT_POST)
+    cfg.update(post or {})
+    prog = arch.build(model_width)
+    missing = [n for n in prog.variable_shapes() if n not in weights]
+    if missing:
+        raise KeyError("model is missing %d variables, e.g. %s" % (len(missing), missing[0]))
+    for name, shape in prog.variable_shapes().items():
+        if tuple(weights[name].shape) != tuple(shape):
+            raise ValueError("%s has shape %s, expected %s" % (name, weights[name].shape, shape))
+
+    tensor_names = ["input"] + [op.dst for op in prog.ops if op.out_mode == arch.OUT_ACT]
+    tindex = {n: i for i, n in enumerate(tensor_names)}
+    slots = assign_slots(prog, tensor_names)
+
+    wblob = bytearray()
+
+    def put(arr: np.ndarray) -> int:
+        off = _align(len(wblob))
+        wblob.extend(b"\0" * (off - len(wblob)))
+        wblob.extend(arr.tobytes())
+        return off
+
+    op_recs = []
+    for op in prog.ops:
+        w, b = fold_batch_norm(weights, op)
+        n_pad, kc = 0, 0
+        if op.kind == arch.OP_STEM:
+            w_off = put(w.reshape(27, 32).astype(np.float32))
+            b_off = put(b.astype(np.float32))
+        elif op.kind == arch.OP_DW:
+            w_off = put(w.reshape(9, op.cin).astype(np.float16))
+            b_off = put(b.astype(np.float32))
+        else:
+            n_pad = _align(op.cout, 32)
+            kc = (op.cin + 31) // 32
+            w_off = put(pack_conv_weights(w.astype(np.float32), n_pad, kc))
+            bp = np.zeros(n_pad, np.float32)
+            bp[:op.cout] = b
+            b_off = put(bp)
+        op_recs.append(struct.pack(
+            "<20i2q8i64s",
+            op.kind, tindex[op.src], tindex.get(op.dst, -1) if op.out_mode == arch.OUT_ACT else -1,
+            tindex[op.res] if op.res else -1,
+            op.cin, op.cout, op.k, op.stride,
+            op.hin, op.win, op.hout, op.wout,
+            op.pad_t, op.pad_l, op.act, op.out_mode,
+            op.anchor_offset, op.anchors_per_loc, n_pad, kc,
+            w_off, b_off, *([0] * 8), op.scope.encode()[:63]))
+    assert all(len(r) == 192 for r in op_recs)
+
+    tensor_recs = []
+    for n, s in zip(tensor_names, slots):
+        t = prog.tensors[n]
+        tensor_recs.append(struct.pack("<4i48s", t.h, t.w, 4 if n == "input" else t.c, s, n.encode()[:47]))
+
+    anchors = ssd_anchor_table([g for _, g, _ in prog.feature_maps], [a for _, _, a in prog.feature_maps])
+    assert anchors.shape == (prog.num_anchors, 4)
+
+    header_size = 160
+    tensors_off = _align(header_size)
+    ops_off = _align(tensors_off + 64 * len(tensor_recs))
+    anchors_off = _align(ops_off + 192 * len(op_recs))
+    weights_off = _align(anchors_off + anchors.nbytes)
+    total = weights_off + len(wblob)
+    sy, sx, sh, sw = cfg["scales"]
+    header = struct.pack(
+        "<10I6f6Q12I",
+        MAGIC, FORMAT_VERSION, precision, model_width,
+        arch.NUM_CLASSES, prog.num_anchors, len(tensor_recs), len(op_recs),
+        cfg["max_total"], cfg["max_per_class"],
+        cfg["score_threshold"], cfg["iou_threshold"], sy, sx, sh, sw,
+        tensors_off, ops_off, anchors_off, weights_off, len(wblob), total,
+        max(slots) + 1, *([0] * 11))
+    assert len(header) == header_size
+    out = bytearray(total)
+    out[:header_size] = header
+    out[tensors_off:tensors_off + 64 * len(tensor_recs)] = b"".join(tensor_recs)
+    out[ops_off:ops_off + 192 * len(op_recs)] = b"".join(op_recs)
+    out[anchors_off:anchors_off + anchors.nbytes] = anchors.tobytes()
+    out[weights_off:] = wblob
+    return bytes(out)
+
+
+def save_engine(engine: bytes, engine_dest_path: str) -> None:
+    """watsor/engine.py:54-58."""
+    os.makedirs(os.path.dirname(os.path.abspath(engine_dest_path)), exist_ok=True)
+    tmp = engine_dest_path + ".tmp%d" % os.getpid()
+    with open(tmp, "wb") as f:
+        f.write(engine)
+    os.replace(tmp, engine_dest_path)
+
+
+def load_weights(model_path: str) -> Dict[str, np.ndarray]:
+    if model_path.startswith("synthetic"):
+        from .synth import synthetic_weights
+        seed = int(model_path.split(":")[1]) if ":" in model_path else 1234
+        return synthetic_weights(seed)
+    if not os.path.isfile(model_path):
+        raise FileNotFoundError(model_path)
+    ext = os.path.splitext(model_path)[1].lower()
+    if ext == ".npz":
+        with np.load(model_path) as z:
+            return {k: z[k] for k in z.files}
+    if ext == ".pb":
+        from .frozen_graph import read_frozen_graph_variables
+        return read_frozen_graph_variables(model_path)
+    raise AssertionError("Unsupported model format")          # watsor/engine.py:44
+
+
+def main(argv=None) -> int:
+    parser = argparse.ArgumentParser(description="Utility to build the MI355X engine prior to inference.",
+                                     formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    parser.add_argument("-i", "--input", dest="model_path", metavar="MODEL_PATH", required=True,
+                        help="TF variables as .npz, a frozen_inference_graph.pb, or synthetic[:seed]")
+    parser.add_argument("-p", "--precision", type=int, choices=[32, 16], default=16,
+                        help="activation/weight storage precision of the engine")
+    parser.add_argument("-w", "--workspace", default=1024, type=int,
+                        help="accepted for command-line compatibility with watsor/engine.py; unused")
+    parser.add_argument("-mw", "--model-width", type=int, default=300, help="model image width")
+    parser.add_argument("-mh", "--model-height", type=int, default=300, help="model image height")
+    parser.add_argument("-o", "--output", dest="engine_path", help="path of the output file",
+                        default=os.path.join(os.getcwd(), "model", "mi355x.bin"))
+    args = parser.parse_args(argv)
+    print("Building MI355X engine from {}.".format(args.model_path))
+    engine = build_engine(load_weights(args.model_path), args.precision, args.model_width, args.model_height)
+    save_engine(engine, args.engine_path)
+    print("MI355X engine saved to {} ({:.1f} MB)".format(args.engine_path, len(engine) / 1e6))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,270 @@
+"""Thin Python handle around one `wz_engine_t` (one MI355X).  numpy in, numpy / ctypes rows out.
+
+Used by the detector plugin (`watsor_amd/detection/hip_gpu.py`), by `bench.py` and by the parity
+tests.  No torch here: device memory, streams and graphs are owned by libwatsor_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Iterable, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .share import Detection, DetectionArray, MAX_DETECTIONS
+
+ROW_DTYPE = np.dtype([("label", "<i4"), ("zones", "<i4", (10,)), ("_pad", "<i4"), ("confidence", "<f8"),
+                      ("x_min", "<i4"), ("y_min", "<i4"), ("x_max", "<i4"), ("y_max", "<i4")])
+assert ROW_DTYPE.itemsize == C.sizeof(Detection) == 72
+
+
+def device_count() -> int:
+    return int(_lib.load().wz_device_count())
+
+
+def device_name(device: int) -> str:
+    buf = C.create_string_buffer(256)
+    _lib.check(_lib.load().wz_device_name_of(device, buf, 256))
+    return buf.value.decode()
+
+
+class HipEngine:
+    def __init__(self, engine_path: str, device: int = 0, max_batch: int = 8, max_width: int = 1920,
+                 max_height: int = 1080):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        self.max_batch = max_batch
+        rc = self._lib.wz_create(os.fsencode(engine_path), device, max_batch, max_width, max_height, C.byref(self._h))
+        _lib.check(rc, "wz_create")
+        self.input_size = self._lib.wz_input_size(self._h)
+        self.num_anchors = self._lib.wz_num_anchors(self._h)
+        self.num_classes = self._lib.wz_num_classes(self._h)
+        self._dev_allocs: List[int] = []
+
+    # -- lifecycle ------------------------------------------------------------------------------
+    def close(self) -> None:
+        if self._h:
+            for p in self._dev_allocs:
+                self._lib.wz_dev_free(self._h, C.c_void_p(p))
+            self._dev_allocs = []
+            self._lib.wz_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def device_name(self) -> str:
+        return self._lib.wz_device_name(self._h).decode()
+
+    # -- hot call -------------------------------------------------------------------------------
+    @staticmethod
+    def _addr(obj) -> int:
+        if isinstance(obj, np.ndarray):
+            return obj.ctypes.data
+        if isinstance(obj, int):
+            return obj
+        return C.addressof(obj)
+
+    def detect_batch(self, frames: Sequence[np.ndarray], out_rows: Sequence, cams: Optional[Sequence[int]] = None,
+                     out_pass: Optional[Sequence[np.ndarray]] = None) -> float:
+        """frames: (H,W,3) uint8 C-contiguous arrays (host); out_rows[i]: ctypes Detection[100] (or a
+        ROW_DTYPE array of 100) written in place.  Returns the batch wall time in ms."""
+        n = len(frames)
+        ptrs = (C.c_void_p * n)()
+        ws = (C.c_int32 * n)()
+        hs = (C.c_int32 * n)()
+        outs = (C.c_void_p * n)()
+        keep = []
+        for i, f in enumerate(frames):
+            if f.dtype != np.uint8 or f.ndim != 3 or f.shape[2] != 3:
+                raise ValueError("frame %d must be (H,W,3) uint8" % i)
+            if not f.flags["C_CONTIGUOUS"]:
+                f = np.ascontiguousarray(f)
+            keep.append(f)
+            ptrs[i] = f.ctypes.data
+            hs[i], ws[i] = f.shape[0], f.shape[1]
+            outs[i] = self._addr(out_rows[i])
+        camv = None
+        if cams is not None:
+            camv = (C.c_int32 * n)(*[int(c) for c in cams])
+        passv = None
+        if out_pass is not None:
+            passv = (C.c_void_p * n)(*[p.ctypes.data for p in out_pass])
+        ms = (C.c_float * n)()
+        _lib.check(self._lib.wz_detect_batch(self._h, n, ptrs, ws, hs, camv, outs, passv, ms))
+        return float(ms[0])
+
+    def submit_device(self, slot: int, d_frames: Sequence[int], widths: Sequence[int], heights: Sequence[int],
+                      cams: Optional[Sequence[int]] = None) -> None:
+        n = len(d_frames)
+        ptrs = (C.c_void_p * n)(*d_frames)
+        ws = (C.c_int32 * n)(*widths)
+        hs = (C.c_int32 * n)(*heights)
+        camv = (C.c_int32 * n)(*cams) if cams is not None else None
+        _lib.check(self._lib.wz_submit_device(self._h, slot, n, ptrs, ws, hs, camv))
+
+    def wait(self, slot: int) -> None:
+        _lib.check(self._lib.wz_wait(self._h, slot))
+
+    def slot_rows(self, slot: int, n: int) -> np.ndarray:
+        """View (no copy) of the pinned result rows of `slot`: ROW_DTYPE [n,100]."""
+        p = self._lib.wz_slot_rows(self._h, slot)
+        buf = (C.c_uint8 * (72 * MAX_DETECTIONS * n)).from_address(p)
+        return np.frombuffer(buf, dtype=ROW_DTYPE).reshape(n, MAX_DETECTIONS)
+
+    def sync(self) -> None:
+        _lib.check(self._lib.wz_sync(self._h))
+
+    # -- device memory --------------------------------------------------------------------------
+    def upload(self, arr: np.ndarray) -> int:
+        arr = np.ascontiguousarray(arr)
+        p = C.c_void_p()
+        _lib.check(self._lib.wz_dev_alloc(self._h, arr.nbytes, C.byref(p)))
+        self._dev_allocs.append(p.value)
+        _lib.check(self._lib.wz_dev_upload(self._h, p, C.c_void_p(arr.ctypes.data), arr.nbytes))
+        return p.value
+
+    def free(self, d_ptr: int) -> None:
+        self._dev_allocs.remove(d_ptr)
+        _lib.check(self._lib.wz_dev_free(self._h, C.c_void_p(d_ptr)))
+
+    # -- filters --------------------------------------------------------------------------------
+    def set_camera_filter(self, cam: int, width: int, height: int, conf_thr: np.ndarray, area_thr: np.ndarray,
+                          zone_fill: Optional[np.ndarray] = None, zone_allow: Optional[np.ndarray] = None) -> None:
+        conf = np.ascontiguousarray(conf_thr, np.float64)
+        area = np.ascontiguousarray(area_thr, np.float64)
+        assert conf.shape == (_lib.WZ_NUM_LABELS,) and area.shape == (_lib.WZ_NUM_LABELS,)
+        nz = 0 if zone_fill is None else int(zone_fill.shape[0])
+        fill_p = allow_p = None
+        if nz:
+            zone_fill = np.ascontiguousarray(zone_fill, np.uint8)
+            assert zone_fill.shape == (nz, height, width)
+            fill_p = C.c_void_p(zone_fill.ctypes.data)
+            if zone_allow is not None:
+                zone_allow = np.ascontiguousarray(zone_allow, np.uint8)
+                assert zone_allow.shape == (_lib.WZ_NUM_LABELS, nz)
+                allow_p = C.c_void_p(zone_allow.ctypes.data)
+        _lib.check(self._lib.wz_set_camera_filter(
+            self._h, cam, width, height, conf.ctypes.data_as(_lib.c_f64p), area.ctypes.data_as(_lib.c_f64p),
+            nz, allow_p, fill_p))
+
+    def clear_camera_filter(self, cam: int) -> None:
+        _lib.check(self._lib.wz_clear_camera_filter(self._h, cam))
+
+    def filter_rows(self, cam: int, rows) -> np.ndarray:
+        """Runs Confidence/Area/Mask of camera `cam` on 100 rows in place; returns pass[100] (uint8)."""
+        out = np.zeros(MAX_DETECTIONS, np.uint8)
+        _lib.check(self._lib.wz_filter_rows(self._h, cam, C.c_void_p(self._addr(rows)), C.c_void_p(out.ctypes.data)))
+        return out
+
+    # -- introspection / profiling ---------------------------------------------------------------
+    def tensors(self):
+        out = []
+        name = C.create_string_buffer(64)
+        h, w, c = C.c_int32(), C.c_int32(), C.c_int32()
+        for i in range(self._lib.wz_num_tensors(self._h)):
+            _lib.check(self._lib.wz_tensor_info(self._h, i, name, 64, C.byref(h), C.byref(w), C.byref(c)))
+            out.append((name.value.decode(), h.value, w.value, c.value))
+        return out
+
+    def ops(self):
+        out = []
+        name = C.create_string_buffer(80)
+        dims = (C.c_int32 * 12)()
+        keys = ("kind", "cin", "cout", "ksize", "stride", "hin", "win", "hout", "wout", "n_pad", "kc", "splitk")
+        for i in range(self._lib.wz_num_ops(self._h)):
+            _lib.check(self._lib.wz_op_info(self._h, i, name, 80, dims))
+            d = dict(zip(keys, list(dims)))
+            d["name"] = name.value.decode()
+            out.append(d)
+        return out
+
+    def stage_names(self) -> List[str]:
+        name = C.create_string_buffer(96)
+        out = []
+        for i in range(self._lib.wz_num_stages(self._h)):
+            _lib.check(self._lib.wz_stage_name(self._h, i, name, 96))
+            out.append(name.value.decode())
+        return out
+
+    def profile_device(self, d_frames: Sequence[int], widths: Sequence[int], heights: Sequence[int], reps: int = 10):
+        n = len(d_frames)
+        ns = self._lib.wz_num_stages(self._h)
+        ms = (C.c_float * ns)()
+        _lib.check(self._lib.wz_profile_device(self._h, n, (C.c_void_p * n)(*d_frames), (C.c_int32 * n)(*widths),
+                                               (C.c_int32 * n)(*heights), reps, ms))
+        return list(zip(self.stage_names(), [float(x) for x in ms]))
+
+    # -- stage-level entry points (parity tests) --------------------------------------------------
+    def stage_preprocess(self, frame: np.ndarray) -> np.ndarray:
+        frame = np.ascontiguousarray(frame, np.uint8)
+        S = self.input_size
+        out = np.empty((S, S, 4), np.float16)
+        _lib.check(self._lib.wz_stage_preprocess(self._h, C.c_void_p(frame.ctypes.data), frame.shape[1],
+                                                 frame.shape[0], C.c_void_p(out.ctypes.data)))
+        return out
+
+    def stage_forward(self, x_half: np.ndarray):
+        """x_half float16 [n,S,S,4] -> (box_enc float32 [n,A,4], logits float32 [n,A,C])."""
+        x = np.ascontiguousarray(x_half, np.float16)
+        n = x.shape[0]
+        be = np.empty((n, self.num_anchors, 4), np.float32)
+        lg = np.empty((n, self.num_anchors, self.num_classes), np.float32)
+        _lib.check(self._lib.wz_stage_forward(self._h, n, C.c_void_p(x.ctypes.data), C.c_void_p(be.ctypes.data),
+                                              C.c_void_p(lg.ctypes.data)))
+        return be, lg
+
+    def stage_read_tensor(self, idx: int, frame: int = 0) -> np.ndarray:
+        name, h, w, c = self.tensors()[idx]
+        out = np.empty((h, w, c), np.float16)
+        _lib.check(self._lib.wz_stage_read_tensor(self._h, idx, frame, C.c_void_p(out.ctypes.data)))
+        return out
+
+    def stage_postprocess(self, box_enc: np.ndarray, logits: np.ndarray):
+        be = np.ascontiguousarray(box_enc, np.float32)
+        lg = np.ascontiguousarray(logits, np.float32)
+        n = be.shape[0]
+        boxes = np.empty((n, MAX_DETECTIONS, 4), np.float32)
+        scores = np.empty((n, MAX_DETECTIONS), np.float32)
+        classes = np.empty((n, MAX_DETECTIONS), np.int32)
+        num = np.empty((n,), np.int32)
+        _lib.check(self._lib.wz_stage_postprocess(
+            self._h, n, C.c_void_p(be.ctypes.data), C.c_void_p(lg.ctypes.data), C.c_void_p(boxes.ctypes.data),
+            C.c_void_p(scores.ctypes.data), C.c_void_p(classes.ctypes.data), C.c_void_p(num.ctypes.data)))
+        return boxes, scores, classes, num
+
+    def stage_rows(self, width: int, height: int, boxes: np.ndarray, scores: np.ndarray, classes: np.ndarray):
+        b = np.ascontiguousarray(boxes, np.float32)
+        s = np.ascontiguousarray(scores, np.float32)
+        c = np.ascontiguousarray(classes, np.int32)
+        rows = np.zeros(MAX_DETECTIONS, ROW_DTYPE)
+        _lib.check(self._lib.wz_stage_rows(self._h, width, height, C.c_void_p(b.ctypes.data),
+                                           C.c_void_p(s.ctypes.data), C.c_void_p(c.ctypes.data),
+                                           C.c_void_p(rows.ctypes.data)))
+        return rows
+
+
+def zones_from_alpha(alpha: np.ndarray, max_zones: int = 40):
+    """Host-side: alpha plane (H,W) uint8 -> (zone_fill uint8 [nz,H,W], centroids int32 [nz,2])."""
+    a = np.ascontiguousarray(alpha, np.uint8)
+    h, w = a.shape
+    fill = np.zeros((max_zones, h, w), np.uint8)
+    cent = np.zeros((max_zones, 2), np.int32)
+    rc = _lib.load().wz_zones_from_alpha(C.c_void_p(a.ctypes.data), w, h, max_zones, C.c_void_p(fill.ctypes.data),
+                                         C.c_void_p(cent.ctypes.data))
+    if rc == _lib.WZ_EFORMAT:
+        raise ZeroDivisionError("float division by zero")     # what mask.py:80 raises for a degenerate contour
+    if rc < 0:
+        raise ValueError("wz_zones_from_alpha failed (%d)" % rc)
+    return fill[:rc].copy(), cent[:rc].copy()

@@ -1,0 +1,85 @@
+"""Seeded synthetic SSD-MobileNet-v2 weights (TF variable names, TF layouts, unfolded BatchNorm).
+
+There is no model file anywhere in the reference tree (`watsor/test/model/cpu.pb` is a stripped
+blob) and no network to fetch `ssd_mobilenet_v2_coco_2018_03_29` (README.md:450), so benchmarks,
+smoke and parity tests run on random-init weights *of that architecture*: same shapes, same
+BatchNorm-then-ReLU6 structure, He-scaled so activations stay in the range a trained network
+produces, class-head bias at logit(0.01) so that scores are sparse like a real detector's.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import numpy as np
+
+from . import arch
+
+
+def synthetic_weights(seed: int = 1234, program: "arch.Program | None" = None) -> Dict[str, np.ndarray]:
+    prog = program or arch.build()
+    rng = np.random.Generator(np.random.PCG64(seed))
+    W: Dict[str, np.ndarray] = {}
+
+    def normal(shape, std):
+        return (rng.standard_normal(shape, dtype=np.float32) * np.float32(std)).astype(np.float32)
+
+    for op in prog.ops:
+        if op.kind == arch.OP_DW:
+            fan_in = op.k * op.k
+            W[op.scope + "/depthwise_weights"] = normal((op.k, op.k, op.cin, 1), math.sqrt(2.0 / fan_in))
+        else:
+            fan_in = op.k * op.k * op.cin
+            if op.out_mode == arch.OUT_CLS:
+                std = 0.45 / math.sqrt(fan_in)
+            elif op.out_mode == arch.OUT_BOX:
+                std = 0.4 / math.sqrt(fan_in)
+            elif op.act == arch.ACT_RELU6:
+                std = math.sqrt(2.0 / fan_in)
+            else:
+                std = math.sqrt(1.0 / fan_in)
+            W[op.scope + "/weights"] = normal((op.k, op.k, op.cin, op.cout), std)
+        if op.has_bn:
+            c = op.cout
+            W[op.scope + "/BatchNorm/gamma"] = (1.0 + 0.1 * rng.standard_normal(c, dtype=np.float32)).astype(np.float32)
+            W[op.scope + "/BatchNorm/beta"] = normal((c,), 0.1) + np.float32(0.2 if op.act == arch.ACT_RELU6 else 0.0)
+            W[op.scope + "/BatchNorm/moving_mean"] = normal((c,), 0.1)
+            W[op.scope + "/BatchNorm/moving_variance"] = (
+                0.75 + 0.5 * rng.random(c, dtype=np.float32)).astype(np.float32)
+        else:
+            if op.out_mode == arch.OUT_CLS:
+                b = normal((op.cout,), 0.3) + np.float32(-4.6)
+            else:
+                b = normal((op.cout,), 0.05)
+            W[op.scope + "/biases"] = b.astype(np.float32)
+    return W
+
+
+def synthetic_frame(width: int, height: int, seed: int, n_shapes: int = 4) -> np.ndarray:
+    """One packed RGB24 frame (H,W,3 uint8): low-frequency noise + a few filled shapes.
+
+    Mirrors the spirit of the reference's `Artist` test source (`watsor/test/detect_stream.py:43-70`:
+    4 random shapes per frame) while giving the bilinear taps non-trivial content.
+    """
+    rng = np.random.Generator(np.random.PCG64(seed))
+    gh, gw = max(2, height // 40), max(2, width // 40)
+    coarse = rng.random((gh, gw, 3), dtype=np.float32)
+    ys = np.linspace(0, gh - 1, height, dtype=np.float32)
+    xs = np.linspace(0, gw - 1, width, dtype=np.float32)
+    y0 = np.floor(ys).astype(np.int64); y1 = np.minimum(y0 + 1, gh - 1); fy = (ys - y0)[:, None, None]
+    x0 = np.floor(xs).astype(np.int64); x1 = np.minimum(x0 + 1, gw - 1); fx = (xs - x0)[None, :, None]
+    top = coarse[y0][:, x0] * (1 - fx) + coarse[y0][:, x1] * fx
+    bot = coarse[y1][:, x0] * (1 - fx) + coarse[y1][:, x1] * fx
+    img = (top * (1 - fy) + bot * fy) * 200.0 + 20.0
+    img += rng.standard_normal((height, width, 3), dtype=np.float32) * 6.0
+    yy, xx = np.mgrid[0:height, 0:width]
+    for _ in range(n_shapes):
+        cx, cy = rng.integers(0, width), rng.integers(0, height)
+        rw, rh = rng.integers(width // 16, width // 4), rng.integers(height // 16, height // 4)
+        color = rng.integers(0, 256, 3).astype(np.float32)
+        if rng.random() < 0.5:
+            m = (np.abs(xx - cx) <= rw) & (np.abs(yy - cy) <= rh)
+        else:
+            m = ((xx - cx) / float(rw)) ** 2 + ((yy - cy) / float(rh)) ** 2 <= 1.0
+        img[m] = color
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
