@@ -1,0 +1,241 @@
+"""Throughput / latency / roofline bench of the MI355X detection hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A *step* is one pass of the hot path (resize+normalise -> SSD-MobileNet-v2 -> decode -> NMS -> 100
+Detection rows per frame, D2H of the rows included) over one batch of synthetic frames that are
+already resident in HBM.  Workload at N=1 = BASELINE.json configs[1]: one synthetic 640x480 RGB
+stream, batch = 8 frames, 1 x MI355X.  For N > 1 every rank is an independent replica with its own
+camera (cameras are the shard; no data-path collective -- SURVEY.md 8e), value = frames of all ranks
+/ max-over-ranks time, scaling "weak".
+
+Rank 0 prints ONE JSON line (contract in the task description) extended with
+  "p50_ms"      : median per-step latency of synchronous steps (the other half of BASELINE's metric)
+  "roofline"    : dominant kernel of the step, timed live with HIP events on the engine's own stream
+  "cpu_baseline": the oracle (CPU restatement of the reference's TF detector) on this host's cores
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_PEAK_TFLOPS = 2500.0    # dense fp16/bf16 MFMA
+WIDTH, HEIGHT, BATCH = 640, 480, 8
+
+
+def kernel_class(op):
+    from watsor_amd import arch
+    if op["kind"] == arch.OP_STEM:
+        return "wz_k_stem"
+    if op["kind"] == arch.OP_DW:
+        return "wz_k_dw"
+    return "wz_k_conv<%d>" % op["ksize"]
+
+
+def algorithmic_cost(op, n):
+    """(flops, bytes) of one launch per the per-layer rule of SURVEY.md 8(d): every tensor once."""
+    from watsor_amd import arch
+    M = n * op["hout"] * op["wout"]
+    if op["kind"] == arch.OP_DW:
+        c = op["cin"]
+        return 2.0 * M * c * 9, 2.0 * (n * op["hin"] * op["win"] * c + 9 * c + M * c)
+    if op["kind"] == arch.OP_STEM:
+        return 2.0 * M * 32 * 27, 2.0 * (n * op["hin"] * op["win"] * 4 + M * 32) + 27 * 32 * 4
+    K = op["ksize"] ** 2 * op["cin"]
+    N = op["cout"]
+    out_bytes = 4.0 if op["name"].startswith("BoxPredictor") else 2.0     # head outputs are fp32
+    return 2.0 * M * N * K, 2.0 * (n * op["hin"] * op["win"] * op["cin"] + K * N) + out_bytes * M * N
+
+
+def roofline_from_stages(stages, ops, n, frame_bytes, size):
+    """Aggregate event-bracketed stage times by kernel; return (roofline dict of the dominant kernel, table)."""
+    by_name = {o["name"]: o for o in ops}
+    agg = {}
+    for name, ms in stages:
+        if name.endswith("#splitk_reduce"):
+            k, fl, by = "wz_k_splitk_reduce", 0.0, 0.0
+            if ms < 1e-4:
+                continue
+        elif name in by_name:
+            o = by_name[name]
+            k = kernel_class(o)
+            fl, by = algorithmic_cost(o, n)
+        elif name == "preprocess":
+            k, fl, by = "wz_k_preprocess", 0.0, float(n * (frame_bytes + size * size * 4 * 2))
+        elif name.startswith("post/"):
+            k, fl, by = "wz_k_" + name.split("/")[1], 0.0, 0.0
+        else:
+            continue
+        a = agg.setdefault(k, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+        a["ms"] += ms; a["flops"] += fl; a["bytes"] += by; a["launches"] += 1
+    table = []
+    for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+        t = a["ms"] * 1e-3
+        t_hbm = a["bytes"] / (HBM_PEAK_GBS * 1e9)
+        t_mfma = a["flops"] / (MFMA_PEAK_TFLOPS * 1e12)
+        table.append(dict(kernel=k, launches=a["launches"], ms_per_step=a["ms"], avg_us=a["ms"] * 1e3 / a["launches"],
+                          gbs=a["bytes"] / t / 1e9 if t > 0 else 0.0, tflops=a["flops"] / t / 1e12 if t > 0 else 0.0,
+                          t_roof_frac=max(t_hbm, t_mfma) / t if t > 0 else 0.0,
+                          bound="mfma" if t_mfma > t_hbm else "hbm",
+                          bytes_per_launch=a["bytes"] / a["launches"], flops_per_launch=a["flops"] / a["launches"]))
+    dom = table[0]
+    if dom["bound"] == "hbm":
+        ach, peak, unit = dom["gbs"], HBM_PEAK_GBS, "GB/s"
+    else:
+        ach, peak, unit = dom["tflops"], MFMA_PEAK_TFLOPS, "TFLOP/s"
+    roof = dict(kernel=dom["kernel"], bound=dom["bound"], achieved=round(ach, 3), peak=peak, unit=unit,
+                frac=round(ach / peak, 5), traffic=None, avg_launch_us=round(dom["avg_us"], 3),
+                launches_per_step=dom["launches"], time_frac_of_roofline=round(dom["t_roof_frac"], 5),
+                algorithmic_bytes_per_launch=dom["bytes_per_launch"], algorithmic_flops_per_launch=dom["flops_per_launch"])
+    return roof, table
+
+
+def cpu_baseline(weights, frames, budget_s=12.0):
+    """Oracle detector (kind 'port') on this host's cores over a bounded sample of the same frames."""
+    import torch
+    from oracle.detect import OracleObjectDetector
+    from watsor_amd.share import DetectionArray
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    det = OracleObjectDetector(weights=weights)
+    rows = DetectionArray()
+    det.detect(frames[0].shape, frames[0], rows)           # warm-up (thread pools, allocations)
+    t0 = time.perf_counter()
+    done = 0
+    lat = []
+    while True:
+        f = frames[done % len(frames)]
+        t1 = time.perf_counter()
+        det.detect(f.shape, f, rows)
+        lat.append((time.perf_counter() - t1) * 1e3)
+        done += 1
+        if time.perf_counter() - t0 >= budget_s and done >= 4:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=round(done / dt, 3), unit="frames/s", cores=cores, kind="port",
+                p50_ms=round(float(np.median(lat)), 2),
+                sample="%d synthetic %dx%d frames, oracle (torch-CPU fp32 restatement of the reference TF detector), "
+                       "%.1f s" % (done, WIDTH, HEIGHT, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--table", default=None, help="write the per-kernel roofline table (JSON) here")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch                                            # before libwatsor_hip.so: one HIP runtime per process
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    have_torch_gpu = torch.cuda.is_available()
+
+    from watsor_amd import engine as builder
+    from watsor_amd.runtime import HipEngine
+    from watsor_amd.synth import synthetic_frame, synthetic_weights
+
+    weights = synthetic_weights(1234)
+    model_dir = "/tmp/wz_bench_%d_%d" % (os.getpid(), rank)
+    os.makedirs(model_dir, exist_ok=True)
+    engine_path = os.path.join(model_dir, "mi355x.bin")
+    builder.save_engine(builder.build_engine(weights), engine_path)
+
+    eng = HipEngine(engine_path, local_rank, BATCH, WIDTH, HEIGHT)
+    # camera `rank`: a ring of 4 batches of distinct frames, pre-staged in HBM
+    ring = 4
+    host_frames = [synthetic_frame(WIDTH, HEIGHT, 1234 + rank * 1000 + i) for i in range(ring * BATCH)]
+    d_frames = [eng.upload(f) for f in host_frames]
+    ws, hs = [WIDTH] * BATCH, [HEIGHT] * BATCH
+
+    def submit(step):
+        b = step % ring
+        eng.submit_device(step % 4, d_frames[b * BATCH:(b + 1) * BATCH], ws, hs)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        if have_torch_gpu:
+            torch.cuda.synchronize()
+        eng.sync()
+
+    for s in range(args.warmup):
+        submit(s)
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        submit(s)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-step latency (synchronous steps), outside the timed region
+    lat = []
+    for s in range(min(args.steps, 50)):
+        t1 = time.perf_counter()
+        submit(s)
+        eng.wait(s % 4)
+        lat.append((time.perf_counter() - t1) * 1e3)
+    rows = eng.slot_rows((min(args.steps, 50) - 1) % 4, BATCH)
+    detections_per_frame = float((rows["confidence"] > 0).sum()) / BATCH
+
+    out = None
+    if rank == 0:
+        stages = eng.profile_device(d_frames[:BATCH], ws, hs, reps=20)
+        roof, table = roofline_from_stages(stages, eng.ops(), BATCH, WIDTH * HEIGHT * 3, eng.input_size)
+        if args.table:
+            json.dump(dict(stages=stages, kernels=table), open(args.table, "w"), indent=1)
+        frames_total = args.steps * BATCH * world
+        out = {
+            "metric": "detected frames/sec (whole node) + p50 per-frame latency, SSD-MobileNet 300x300",
+            "value": round(frames_total / elapsed, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "p50_ms": round(float(np.median(lat)), 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "1 synthetic 640x480 RGB stream per GPU, batch=8 frames, SSD-MobileNet-v2 300x300 "
+                                   "(seeded random-init weights), frames resident in HBM, rows copied back to host",
+                       "batch": BATCH, "frame": "%dx%d" % (WIDTH, HEIGHT), "parallelism": "replica-per-gpu x%d" % world,
+                       "detections_per_frame": detections_per_frame},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            eng.close()
+            out["cpu_baseline"] = cpu_baseline(weights, host_frames[:BATCH])
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+    try:
+        os.remove(engine_path)
+        os.rmdir(model_dir)
+    except OSError:
+        pass
+
+
+if __name__ == "__main__":
+    main()

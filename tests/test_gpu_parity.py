@@ -1,0 +1,228 @@
+"""HIP path vs the CPU oracle, stage by stage and end to end, all through the C ABI (ctypes).
+
+Tolerances (stated here, measured in profiles/r01_parity.txt):
+  * resize+normalise ............ bit-exact fp16 (integer/byte stage of the oracle, fp32 ops in TF order)
+  * row fill (int truncation) .... bit-exact
+  * post-processing on identical fp32 head outputs: same (class, anchor) rows, |score| <= 1e-6,
+    |box| <= 2e-6 (GPU expf vs numpy expf differ by <= 2 ulp)
+  * network (fp16 storage, fp32 accumulate) vs fp32 oracle: scores within SCORE_TOL of the oracle
+"""
+import os
+
+import numpy as np
+import pytest
+
+import parity_utils as pu
+from conftest import make_engine
+from oracle import detect as odet
+from oracle import preprocess as pre
+from watsor_amd.runtime import ROW_DTYPE
+from watsor_amd.synth import synthetic_frame
+
+pytestmark = pytest.mark.gpu
+
+SCORE_TOL = 2e-3        # |sigmoid(logit_gpu) - sigmoid(logit_oracle)| over all 1917*91 entries
+LOGIT_TOL = 0.03        # max abs logit error of the fp16 engine vs the fp32 oracle
+BOXENC_TOL = 0.02
+
+
+@pytest.fixture(scope="module")
+def eng(model_dir):
+    e = make_engine(model_dir)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def eng_keep(model_dir):
+    """Engine whose activation tensors do not share buffers (every layer readable after a forward)."""
+    os.environ["WZ_NO_BUFFER_REUSE"] = "1"
+    try:
+        e = make_engine(model_dir, max_batch=2)
+    finally:
+        os.environ.pop("WZ_NO_BUFFER_REUSE")
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def head_outputs(oracle_net, frames_640):
+    x_half = pu.oracle_input_half(frames_640[:2])
+    rbe, rlg, T = pu.oracle_forward_from_half(oracle_net, x_half, keep=True)
+    return x_half, rbe, rlg, T
+
+
+@pytest.mark.parametrize("wh", [(640, 480), (1280, 720), (1920, 1080), (300, 300), (301, 299), (64, 48)])
+def test_preprocess_bit_exact(eng, wh):
+    f = synthetic_frame(wh[0], wh[1], 7 + wh[0])
+    got = eng.stage_preprocess(f)
+    ref = pre.preprocess_fp16(f)
+    np.testing.assert_array_equal(got[..., :3].view(np.uint16), ref.view(np.uint16))
+    assert not got[..., 3].any()
+
+
+def test_every_layer_close_to_oracle(eng_keep, head_outputs):
+    x_half, rbe, rlg, T = head_outputs
+    be, lg = eng_keep.stage_forward(x_half)
+    worst = 0.0
+    for idx, (name, h, w, c) in enumerate(eng_keep.tensors()):
+        if name == "input":
+            continue
+        got = np.stack([eng_keep.stage_read_tensor(idx, f) for f in range(2)]).astype(np.float32)
+        ref = T[name]
+        assert got.shape == ref.shape
+        err = np.abs(got - ref).max()
+        scale = np.abs(ref).max()
+        worst = max(worst, err / scale)
+        assert err <= 0.01 * scale + 0.01, "%s: max abs err %.4f (max|ref| %.3f)" % (name, err, scale)
+    assert np.abs(be - rbe).max() <= BOXENC_TOL
+    assert np.abs(lg - rlg).max() <= LOGIT_TOL
+
+
+def test_scores_within_tolerance(eng, head_outputs):
+    from oracle.postprocess import sigmoid
+    x_half, rbe, rlg, _ = head_outputs
+    be, lg = eng.stage_forward(x_half)
+    assert np.abs(sigmoid(lg) - sigmoid(rlg)).max() <= SCORE_TOL
+
+
+def test_buffer_sharing_changes_nothing(eng, eng_keep, head_outputs):
+    x_half = head_outputs[0]
+    a = eng.stage_forward(x_half)
+    b = eng_keep.stage_forward(x_half)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+
+
+def test_forward_is_deterministic_and_batch_invariant(eng, head_outputs):
+    x_half = head_outputs[0]
+    a = eng.stage_forward(x_half)
+    b = eng.stage_forward(x_half)
+    np.testing.assert_array_equal(a[1], b[1])
+    x8 = np.concatenate([x_half] * 4)          # batch 8: other split-K / tiling choices, same math per frame
+    c = eng.stage_forward(x8)
+    np.testing.assert_allclose(c[1][:2], a[1], rtol=0, atol=2e-3)
+    np.testing.assert_array_equal(c[1][0], c[1][2])
+
+
+def _check_post(eng, be, lg):
+    B, S, C, N = eng.stage_postprocess(be, lg)
+    rB, rS, rC, rN = pu.oracle_postprocess(be, lg)
+    np.testing.assert_array_equal(N, rN)
+    np.testing.assert_array_equal(C, rC)
+    np.testing.assert_allclose(S, rS, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(B, rB, rtol=0, atol=2e-6)
+    return N
+
+
+def test_postprocess_matches_literal_per_class_nms(eng, head_outputs):
+    _, rbe, rlg, _ = head_outputs
+    n = _check_post(eng, rbe, rlg)
+    assert (n == 100).all()
+
+
+def test_postprocess_dense_scores_force_suppression(eng, head_outputs):
+    """Shift logits up so thousands of candidates tie for the top and NMS has to suppress a lot."""
+    _, rbe, rlg, _ = head_outputs
+    _check_post(eng, rbe[:1] * 0.2, rlg[:1] + 4.0)
+
+
+def test_postprocess_all_equal_logits_takes_exact_slow_path(eng, head_outputs):
+    _, rbe, rlg, _ = head_outputs
+    _check_post(eng, np.zeros_like(rbe[:1]), np.zeros_like(rlg[:1]))
+
+
+def test_postprocess_empty_and_sparse(eng, head_outputs):
+    _, rbe, rlg, _ = head_outputs
+    lg = np.full_like(rlg[:1], -60.0)           # sigmoid < 1e-8 everywhere -> nothing survives the score filter
+    B, S, C, N = eng.stage_postprocess(rbe[:1], lg)
+    assert N[0] == 0 and not S.any() and not B.any() and (C == 1).all()   # zero padding carries label offset 1
+    lg[0, 5, 3] = 2.0
+    lg[0, 900, 17] = 1.0
+    lg[0, 901, 17] = 0.5
+    n = _check_post(eng, rbe[:1], lg)
+    assert 1 <= n[0] <= 3
+
+
+def test_postprocess_zero_area_boxes_are_dropped(eng, head_outputs):
+    _, rbe, rlg, _ = head_outputs
+    be = rbe[:1].copy()
+    be[0, :, 2] = -80.0                          # exp(-16) * ha: height collapses; after clipping area may be 0
+    be[0, :, 0] = 200.0                          # centre pushed far below the window -> clipped to a line
+    B, S, C, N = eng.stage_postprocess(be, rlg[:1])
+    rB, rS, rC, rN = pu.oracle_postprocess(be, rlg[:1])
+    assert N[0] == rN[0] == 0
+
+
+@pytest.mark.parametrize("wh", [(640, 480), (1280, 720), (1920, 1080), (1, 1)])
+def test_row_fill_bit_exact(eng, head_outputs, wh):
+    _, rbe, rlg, _ = head_outputs
+    rB, rS, rC, rN = pu.oracle_postprocess(rbe[:1], rlg[:1])
+    rB = rB[0].copy()
+    rB[7] = (0.0, 0.0, 1.0, 1.0)                 # exact corners
+    rB[8] = np.nextafter(np.float32(1.0), np.float32(0.0))
+    rows = eng.stage_rows(wh[0], wh[1], rB, rS[0], rC[0])
+    ref = odet.rows_as_array((wh[1], wh[0], 3), rB, rC[0], rS[0])
+    np.testing.assert_array_equal(rows["label"], ref["label"])
+    np.testing.assert_array_equal(rows["confidence"], ref["confidence"])
+    np.testing.assert_array_equal(np.stack([rows["x_min"], rows["y_min"], rows["x_max"], rows["y_max"]], 1), ref["box"])
+    assert not rows["zones"].any() and not rows["_pad"].any()
+
+
+def test_detect_end_to_end_matches_oracle_detector(model_dir, synth_weights, frames_640):
+    """`detect()` through the plugin class on full-resolution frames vs the oracle plugin."""
+    from watsor_amd.detection.hip_gpu import HipObjectDetector
+    from watsor_amd.share import DetectionArray
+    oracle = odet.OracleObjectDetector(weights=synth_weights)
+    with HipObjectDetector(model_dir, 0) as det:
+        assert "gfx950" in det.device_name or "MI3" in det.device_name
+        for f in frames_640[:2]:
+            rows = DetectionArray()
+            ms = det.detect(f.shape, f, rows)
+            assert ms > 0
+            ref_rows = DetectionArray()
+            oracle.detect(f.shape, f, ref_rows)
+            got = np.frombuffer(rows, dtype=ROW_DTYPE)
+            b, c, s, _, _ = oracle.raw(f)
+            ref = odet.rows_as_array(f.shape, b, c, s)
+            pairs, missing = pu.match_rows(got, ref, min_score=0.1)
+            n_ref = int((ref["confidence"] > 0.1).sum())
+            assert n_ref > 0 and len(missing) <= max(1, n_ref // 20), (n_ref, missing)
+            assert max(abs(p[3]) for p in pairs) <= SCORE_TOL
+            assert got["label"][0] == ref_rows[0].label
+
+
+def test_batch_of_mixed_resolutions_equals_single_calls(eng):
+    frames = [synthetic_frame(640, 480, 1), synthetic_frame(1920, 1080, 2), synthetic_frame(1280, 720, 3),
+              synthetic_frame(640, 480, 4)]
+    single = []
+    for f in frames:
+        r = np.zeros(100, ROW_DTYPE)
+        eng.detect_batch([f], [r])
+        single.append(r)
+    batch = [np.zeros(100, ROW_DTYPE) for _ in frames]
+    eng.detect_batch(frames, batch)
+    for a, b in zip(single, batch):
+        pairs, missing = pu.match_rows(b, {"label": a["label"], "confidence": a["confidence"],
+                                           "box": np.stack([a["x_min"], a["y_min"], a["x_max"], a["y_max"]], 1)},
+                                       min_score=0.1)
+        assert not missing
+        assert max(abs(p[3]) for p in pairs) <= SCORE_TOL
+
+
+def test_limits_and_errors(model_dir):
+    e = make_engine(model_dir, max_batch=2, max_width=640, max_height=480)
+    try:
+        f = synthetic_frame(640, 480, 5)
+        rows = [np.zeros(100, ROW_DTYPE) for _ in range(3)]
+        with pytest.raises(ValueError):
+            e.detect_batch([f, f, f], rows)                    # batch > max_batch
+        with pytest.raises(ValueError):
+            e.detect_batch([synthetic_frame(1280, 720, 6)], rows[:1])   # frame larger than reserved
+        e.detect_batch([f, f], rows[:2])
+        assert rows[0]["label"][0] >= 1
+    finally:
+        e.close()
+    with pytest.raises(FileNotFoundError):
+        from watsor_amd.detection.hip_gpu import HipObjectDetector
+        HipObjectDetector(os.path.join(model_dir, "nope"), 0)

@@ -141,11 +141,13 @@ static void enqueue_network(wz_engine* e, int n, StageTimer* t) {
             if (sk > 1) {
                 a.out = e->d_ws;
                 wz_launch_conv(a, s);
+                if (t) t->mark();
                 a.out = final_out;
                 wz_launch_splitk_reduce(a, e->d_ws, s);
             } else {
                 a.out = final_out;
                 wz_launch_conv(a, s);
+                if (t) t->mark();
             }
         }
         if (t) t->mark();
@@ -394,7 +396,10 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
 
     e->stage_names.push_back("h2d_descriptors");
     e->stage_names.push_back("preprocess");
-    for (uint32_t i = 0; i < h.n_ops; ++i) e->stage_names.push_back(e->ops[i].name);
+    for (uint32_t i = 0; i < h.n_ops; ++i) {
+        e->stage_names.push_back(e->ops[i].name);
+        if (e->ops[i].kind == WZ_OP_CONV) e->stage_names.push_back(std::string(e->ops[i].name) + "#splitk_reduce");
+    }
     e->stage_names.push_back("post/decode");
     e->stage_names.push_back("post/hist");
     e->stage_names.push_back("post/compact");
