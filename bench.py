@@ -61,11 +61,17 @@ def algorithmic_cost(op, n):
 def roofline_from_stages(stages, ops, n, frame_bytes, size):
     """Aggregate event-bracketed stage times by kernel; return (roofline dict of the dominant kernel, table)."""
     by_name = {o["name"]: o for o in ops}
+    # A hipEventRecord pair with nothing in between reads ~5 us on this stack (the record itself is a
+    # barrier packet).  Brackets of unused split-K slots are exactly that: calibrate on them and
+    # subtract, so a stage time is the kernel's own duration as rocprofv3's kernel trace reports it.
+    empty = sorted(ms for name, ms in stages if name.endswith("#splitk_reduce"))
+    overhead = empty[len(empty) // 4] if empty else 0.0
     agg = {}
     for name, ms in stages:
+        ms = max(ms - overhead, 0.0)
         if name.endswith("#splitk_reduce"):
             k, fl, by = "wz_k_splitk_reduce", 0.0, 0.0
-            if ms < 1e-4:
+            if ms < 5e-4:
                 continue
         elif name in by_name:
             o = by_name[name]
@@ -94,7 +100,7 @@ def roofline_from_stages(stages, ops, n, frame_bytes, size):
         ach, peak, unit = dom["gbs"], HBM_PEAK_GBS, "GB/s"
     else:
         ach, peak, unit = dom["tflops"], MFMA_PEAK_TFLOPS, "TFLOP/s"
-    roof = dict(kernel=dom["kernel"], bound=dom["bound"], achieved=round(ach, 3), peak=peak, unit=unit,
+    roof = dict(kernel=dom["kernel"], event_overhead_us=round(overhead * 1e3, 3), bound=dom["bound"], achieved=round(ach, 3), peak=peak, unit=unit,
                 frac=round(ach / peak, 5), traffic=None, avg_launch_us=round(dom["avg_us"], 3),
                 launches_per_step=dom["launches"], time_frac_of_roofline=round(dom["t_roof_frac"], 5),
                 algorithmic_bytes_per_launch=dom["bytes_per_launch"], algorithmic_flops_per_launch=dom["flops_per_launch"])
@@ -106,7 +112,8 @@ def cpu_baseline(weights, frames, budget_s=12.0):
     import torch
     from oracle.detect import OracleObjectDetector
     from watsor_amd.share import DetectionArray
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, int(os.environ.get("WZ_CPU_BASELINE_THREADS", "64")))
     torch.set_num_threads(cores)
     det = OracleObjectDetector(weights=weights)
     rows = DetectionArray()
@@ -129,6 +136,14 @@ def cpu_baseline(weights, frames, budget_s=12.0):
                        "%.1f s" % (done, WIDTH, HEIGHT, dt))
 
 
+T_START = time.perf_counter()
+
+
+def note(msg):
+    if os.environ.get("WZ_BENCH_VERBOSE", "1") != "0":
+        print("[bench %7.2fs] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -142,17 +157,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
 
-    import torch                                            # before libwatsor_hip.so: one HIP runtime per process
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    have_torch_gpu = torch.cuda.is_available()
-
+    # libwatsor_hip.so owns the GPU side (its own HIP stream, events, graphs): load it FIRST so it binds
+    # to /opt/rocm's HIP runtime, and never initialise torch's bundled copy of that runtime in this
+    # process.  torch is used for its CPU side only: the rendezvous/barrier/max-over-ranks (gloo -- the
+    # path has no data-path collective) and the oracle's conv2d in the cpu_baseline leg.
     from watsor_amd import engine as builder
     from watsor_amd.runtime import HipEngine
     from watsor_amd.synth import synthetic_frame, synthetic_weights
+    from watsor_amd import _lib
+    _lib.load()
+    note("library loaded")
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        note("process group up (gloo)")
 
     weights = synthetic_weights(1234)
     model_dir = "/tmp/wz_bench_%d_%d" % (os.getpid(), rank)
@@ -160,7 +181,9 @@ def main():
     engine_path = os.path.join(model_dir, "mi355x.bin")
     builder.save_engine(builder.build_engine(weights), engine_path)
 
+    note("engine file built")
     eng = HipEngine(engine_path, local_rank, BATCH, WIDTH, HEIGHT)
+    note("engine created on " + eng.device_name)
     # camera `rank`: a ring of 4 batches of distinct frames, pre-staged in HBM
     ring = 4
     host_frames = [synthetic_frame(WIDTH, HEIGHT, 1234 + rank * 1000 + i) for i in range(ring * BATCH)]
@@ -172,22 +195,25 @@ def main():
         eng.submit_device(step % 4, d_frames[b * BATCH:(b + 1) * BATCH], ws, hs)
 
     def barrier():
+        # barrier + device synchronize on both sides of the timed region (eng.sync() = hipStreamSynchronize
+        # of the only stream this process ever enqueues GPU work on)
+        eng.sync()
         if dist is not None:
             dist.barrier()
-        if have_torch_gpu:
-            torch.cuda.synchronize()
-        eng.sync()
 
+    note("frames staged in HBM")
     for s in range(args.warmup):
         submit(s)
     barrier()
+    note("warm-up done")
     t0 = time.perf_counter()
     for s in range(args.steps):
         submit(s)
     barrier()
     elapsed = time.perf_counter() - t0
+    note("timed region done: %.3f s" % elapsed)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -203,7 +229,9 @@ def main():
 
     out = None
     if rank == 0:
+        note("latency loop done")
         stages = eng.profile_device(d_frames[:BATCH], ws, hs, reps=20)
+        note("stage profile done")
         roof, table = roofline_from_stages(stages, eng.ops(), BATCH, WIDTH * HEIGHT * 3, eng.input_size)
         if args.table:
             json.dump(dict(stages=stages, kernels=table), open(args.table, "w"), indent=1)
@@ -225,6 +253,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             eng.close()
             out["cpu_baseline"] = cpu_baseline(weights, host_frames[:BATCH])
+            note("cpu baseline done")
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

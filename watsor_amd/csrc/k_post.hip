@@ -80,30 +80,51 @@ __global__ __launch_bounds__(256) void wz_k_hist(WzPostBuffers b, WzPostConsts k
 }
 
 // threshold bin: the largest b with (number of candidates in bins >= b) >= target, else 0.
-// Called by all 256*k threads of a block; `sh` is WZ_HIST_BINS+2 uint32 of LDS.  Returns total too.
+// Called by every thread of the block (blockDim.x in {256, 1024}); `sh` = 64 uint32 of LDS scratch.
+// Thread t owns bins [t*per, (t+1)*per); suffix sums run across lanes (shuffles) and waves (LDS).
 __device__ int wz_threshold_bin(const uint32_t* __restrict__ ghist, uint32_t* sh, uint32_t target,
                                 uint32_t* total_out) {
-    const int nth = blockDim.x;
-    for (int i = threadIdx.x; i < WZ_HIST_BINS; i += nth) sh[i] = ghist[i];
-    __syncthreads();
-    if (threadIdx.x == 0) {   // 1024-step serial suffix scan: ~2 us, once per block, simple and exact
-        uint32_t run = 0;
-        int thr = 0;
-        bool found = false;
-        for (int i = WZ_HIST_BINS - 1; i >= 0; --i) {
-            run += sh[i];
-            if (!found && run >= target) { thr = i; found = true; }
-        }
-        sh[WZ_HIST_BINS] = (uint32_t)thr;
-        sh[WZ_HIST_BINS + 1] = run;
+    const int nth = blockDim.x, per = WZ_HIST_BINS / nth;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = nth >> 6;
+    uint32_t v[4] = {0, 0, 0, 0};
+    uint32_t sum = 0;
+    for (int i = 0; i < per; ++i) {
+        v[i] = ghist[tid * per + i];
+        sum += v[i];
     }
+    uint32_t s = sum;   // -> sum over lanes >= lane of this wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t x = __shfl_down(s, o);
+        if (lane + o < 64) s += x;
+    }
+    if (lane == 0) sh[wave] = s;
+    if (tid == 0) sh[32] = 0;
     __syncthreads();
-    if (total_out) *total_out = sh[WZ_HIST_BINS + 1];
-    return (int)sh[WZ_HIST_BINS];
+    uint32_t higher = 0, total = 0;
+    for (int w = 0; w < nw; ++w) {
+        total += sh[w];
+        if (w > wave) higher += sh[w];
+    }
+    uint32_t run = s + higher - sum;   // candidates in bins above this thread's bins
+    int best = -1;
+    for (int i = per - 1; i >= 0; --i) {
+        run += v[i];
+        if (run >= target) {
+            best = tid * per + i;
+            break;
+        }
+    }
+    if (best >= 0) atomicMax(&sh[32], (uint32_t)(best + 1));
+    __syncthreads();
+    if (total_out) *total_out = total;
+    const uint32_t r = sh[32];
+    __syncthreads();
+    return r ? (int)r - 1 : 0;
 }
 
 __global__ __launch_bounds__(256) void wz_k_compact(WzPostBuffers b, WzPostConsts k) {
-    __shared__ uint32_t sh[WZ_HIST_BINS + 2];
+    __shared__ uint32_t sh[64];
     const int f = blockIdx.y, total = k.num_anchors * k.num_classes;
     const uint32_t thr = (uint32_t)wz_threshold_bin(b.hist + (size_t)f * WZ_HIST_BINS, sh, WZ_CAND_TARGET, nullptr);
     const int base = blockIdx.x * 256 * POST_ITEMS;
@@ -147,15 +168,17 @@ __device__ __forceinline__ float wz_iou(const float4_t a, const float4_t c) {
 
 #define NMS_THREADS 1024
 #define NMS_KEEP_MAX 128   // >= max_total (100)
+#define NMS_RANK_MAX 1536  // up to here an O(n^2/threads) rank sort beats the barrier-bound bitonic network
 
 struct NmsShared {   // carved from dynamic LDS, every member 16-byte aligned
     unsigned long long keys[WZ_CAND_CAP];   // 32 KiB
+    unsigned long long keys2[WZ_CAND_CAP];  // 32 KiB (rank-sort destination)
     float4_t sbox[WZ_CAND_CAP];             // 64 KiB
     float4_t kbox[NMS_KEEP_MAX];
     float kscore[NMS_KEEP_MAX];
     int32_t kcls[NMS_KEEP_MAX];
     unsigned long long red[NMS_THREADS / 64];
-    uint32_t hist[WZ_HIST_BINS + 2];
+    uint32_t hist[64];
     int32_t kept;
     int32_t pad[3];
 };
@@ -200,39 +223,58 @@ __global__ __launch_bounds__(NMS_THREADS) void wz_k_nms(WzPostBuffers b, WzPostC
 
     int kept = 0;
     if (cnt > 0) {
-        int npow = 64;
-        while (npow < cnt) npow <<= 1;
-        for (int i = tid; i < npow; i += NMS_THREADS) {
-            unsigned long long v = 0ull;
-            if (i < cnt) {
+        unsigned long long* sorted = S->keys;
+        if (cnt <= NMS_RANK_MAX) {
+            // rank sort: keys are unique (the tie index is), so rank = #larger keys is a permutation.
+            // Every thread streams the whole list from LDS (same address per step = broadcast).
+            for (int i = tid; i < cnt; i += NMS_THREADS) {
                 const uint2 c = b.cand[(size_t)f * WZ_CAND_CAP + i];
-                v = ((unsigned long long)c.x << 32) | (unsigned long long)(0xFFFFFFFFu - c.y);
+                S->keys[i] = ((unsigned long long)c.x << 32) | (unsigned long long)(0xFFFFFFFFu - c.y);
             }
-            S->keys[i] = v;
-        }
-        __syncthreads();
-        // bitonic sort, descending
-        for (int size = 2; size <= npow; size <<= 1) {
-            for (int stride = size >> 1; stride > 0; stride >>= 1) {
-                for (int i = tid; i < (npow >> 1); i += NMS_THREADS) {
-                    const int lo = 2 * i - (i & (stride - 1));
-                    const int hi = lo + stride;
-                    const bool desc = ((lo & size) == 0);
-                    const unsigned long long x = S->keys[lo], y = S->keys[hi];
-                    if ((x < y) == desc) { S->keys[lo] = y; S->keys[hi] = x; }
+            __syncthreads();
+            for (int i = tid; i < cnt; i += NMS_THREADS) {
+                const unsigned long long mine = S->keys[i];
+                int r = 0;
+                for (int j = 0; j < cnt; ++j) r += (S->keys[j] > mine) ? 1 : 0;
+                S->keys2[r] = mine;
+            }
+            __syncthreads();
+            sorted = S->keys2;
+        } else {
+            int npow = 64;
+            while (npow < cnt) npow <<= 1;
+            for (int i = tid; i < npow; i += NMS_THREADS) {
+                unsigned long long v = 0ull;
+                if (i < cnt) {
+                    const uint2 c = b.cand[(size_t)f * WZ_CAND_CAP + i];
+                    v = ((unsigned long long)c.x << 32) | (unsigned long long)(0xFFFFFFFFu - c.y);
                 }
-                __syncthreads();
+                S->keys[i] = v;
+            }
+            __syncthreads();
+            // bitonic sort, descending
+            for (int size = 2; size <= npow; size <<= 1) {
+                for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                    for (int i = tid; i < (npow >> 1); i += NMS_THREADS) {
+                        const int lo = 2 * i - (i & (stride - 1));
+                        const int hi = lo + stride;
+                        const bool desc = ((lo & size) == 0);
+                        const unsigned long long x = S->keys[lo], y = S->keys[hi];
+                        if ((x < y) == desc) { S->keys[lo] = y; S->keys[hi] = x; }
+                    }
+                    __syncthreads();
+                }
             }
         }
         for (int i = tid; i < cnt; i += NMS_THREADS) {
-            const uint32_t tie = 0xFFFFFFFFu - (uint32_t)(S->keys[i] & 0xFFFFFFFFull);
+            const uint32_t tie = 0xFFFFFFFFu - (uint32_t)(sorted[i] & 0xFFFFFFFFull);
             const int a = (int)(tie % (uint32_t)A);
             S->sbox[i] = *reinterpret_cast<const float4_t*>(b.boxes + ((size_t)f * A + a) * 4);
         }
         __syncthreads();
         if (wave == 0) {
             for (int i = 0; i < cnt && kept < k.max_total; ++i) {
-                const unsigned long long comp = S->keys[i];
+                const unsigned long long comp = sorted[i];
                 const uint32_t tie = 0xFFFFFFFFu - (uint32_t)(comp & 0xFFFFFFFFull);
                 const int cls = (int)(tie / (uint32_t)A);
                 kept = wz_try_keep(S, kept, S->sbox[i], cls, __uint_as_float((uint32_t)(comp >> 32)), k, lane);

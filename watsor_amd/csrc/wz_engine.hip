@@ -259,7 +259,8 @@ static int load_blob(wz_engine* e, const char* path) {
         const WzOpDesc& op = e->ops[i];
         if (op.src < 0 || op.src >= (int)h.n_tensors || op.dst >= (int)h.n_tensors || op.res >= (int)h.n_tensors ||
             (op.out_mode == WZ_OUT_ACT && op.dst < 0) || op.w_off < 0 || (uint64_t)op.w_off >= h.weights_bytes ||
-            (op.kind == WZ_OP_CONV && (op.n_pad % 32 != 0 || op.cin % 8 != 0 || op.cout % 4 != 0 ||
+            (op.kind == WZ_OP_CONV && (op.n_pad % 32 != 0 || op.cin % 8 != 0 || op.n_pad < op.cout ||
+                                       (op.out_mode == WZ_OUT_ACT && op.cout % 8 != 0) ||
                                        (op.ksize != 1 && op.ksize != 3))) ||
             (op.kind == WZ_OP_DW && op.cin % 8 != 0))
             return wz_fail(WZ_EFORMAT, "%s: op %u (%s) is malformed", path, i, op.name);
