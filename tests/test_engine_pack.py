@@ -28,7 +28,7 @@ def parse(blob):
     for i in range(hdr["n_ops"]):
         o = struct.unpack_from("<20i2q8i64s", blob, hdr["ops_off"] + 192 * i)
         d = dict(zip(keys, o[:20]))
-        d.update(w_off=o[20], b_off=o[21], name=o[30].split(b"\0")[0].decode())
+        d.update(w_off=o[20], b_off=o[21], n_box=o[22], name=o[30].split(b"\0")[0].decode())
         ops.append(d)
     return hdr, tensors, ops
 
@@ -37,10 +37,10 @@ def test_header(blob):
     hdr, tensors, ops = parse(blob)
     assert hdr["magic"] == engine.MAGIC and hdr["version"] == engine.FORMAT_VERSION
     assert hdr["total"] == len(blob) and hdr["precision"] == 16 and hdr["size"] == 300
-    assert hdr["classes"] == 91 and hdr["anchors"] == 1917 and hdr["n_ops"] == 72
+    assert hdr["classes"] == 91 and hdr["anchors"] == 1917 and hdr["n_ops"] == 66
     assert hdr["max_total"] == 100 and abs(hdr["iou_thr"] - 0.6) < 1e-7 and hdr["scales"] == (10.0, 10.0, 5.0, 5.0)
     assert tensors[0]["name"] == "input" and tensors[0]["c"] == 4
-    assert sum(1 for o in ops if o["out_mode"] != arch.OUT_ACT) == 12
+    assert sum(1 for o in ops if o["out_mode"] == arch.OUT_HEAD) == 6
 
 
 def test_shapes_follow_tf_same_padding(blob):
@@ -56,7 +56,7 @@ def test_shapes_follow_tf_same_padding(blob):
     assert pads["expanded_conv_3"] == (1, 1)                            # 75 -> 38
     assert pads["expanded_conv_6"] == (0, 0)                            # 38 -> 19
     assert pads["expanded_conv_13"] == (1, 1)                           # 19 -> 10
-    heads = [o for o in ops if o["out_mode"] == arch.OUT_CLS]
+    heads = [o for o in ops if o["out_mode"] == arch.OUT_HEAD]
     assert [o["anchor_off"] for o in heads] == [0, 1083, 1683, 1833, 1887, 1911]
 
 
@@ -107,14 +107,25 @@ def test_weight_fragments_round_trip(blob, synth_weights):
 
 
 def test_fold_matches_oracle_fold(synth_weights):
+    """Product-side BN folding / head fusion vs the oracle's independent description of the graph."""
     from oracle import ssd_mobilenet_v2 as net
     prog = arch.build()
-    spec = net.graph_spec()
-    assert len(spec) == len(prog.ops)
-    for s, op in zip(spec, prog.ops):
-        assert s.name == op.scope and s.cin == op.cin and s.cout == op.cout and s.stride == op.stride
-        w1, b1 = net.fold_bn(synth_weights, s)
+    spec = {s.name: s for s in net.graph_spec()}
+    assert len(spec) == 72 and len(prog.ops) == 66
+    for op in prog.ops:
         w2, b2 = engine.fold_batch_norm(synth_weights, op)
+        if op.out_mode == arch.OUT_HEAD:
+            sb, sc = spec[op.scope + "/BoxEncodingPredictor"], spec[op.scope + "/ClassPredictor"]
+            assert (sb.cin, sb.cout, sc.cout, sb.k) == (op.cin, op.n_box, op.cout - op.n_box, op.k)
+            wb, bb = net.fold_bn(synth_weights, sb)
+            wc, bc = net.fold_bn(synth_weights, sc)
+            np.testing.assert_array_equal(np.concatenate([wb, wc], 3), w2.astype(np.float32))
+            np.testing.assert_array_equal(np.concatenate([bb, bc]), b2.astype(np.float32))
+            continue
+        s_ = spec[op.scope]
+        assert (s_.cin, s_.cout, s_.stride, s_.k) == (op.cin, op.cout, op.stride, op.k)
+        assert (s_.res is not None) == (op.res is not None) and s_.relu6 == (op.act == arch.ACT_RELU6)
+        w1, b1 = net.fold_bn(synth_weights, s_)
         np.testing.assert_allclose(w1, w2.astype(np.float32), rtol=1e-6, atol=1e-9)
         np.testing.assert_allclose(b1, b2.astype(np.float32), rtol=1e-6, atol=1e-7)
 

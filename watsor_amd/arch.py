@@ -22,7 +22,7 @@ FE = "FeatureExtractor/MobilenetV2/"
 # op kinds understood by the runtime (keep in sync with csrc/wz_program.h)
 OP_STEM, OP_DW, OP_CONV = 1, 2, 3
 # output modes of OP_CONV
-OUT_ACT, OUT_BOX, OUT_CLS = 0, 1, 2
+OUT_ACT, OUT_BOX, OUT_CLS, OUT_HEAD = 0, 1, 2, 3   # OUT_HEAD: box columns then class columns, one launch
 ACT_NONE, ACT_RELU6 = 0, 1
 
 _INVERTED_RESIDUAL = [  # (t, c, n, s) rows of the MobileNetV2 paper, depth multiplier 1.0
@@ -71,6 +71,7 @@ class Op:
     pad_t: int = 0
     pad_l: int = 0
     anchor_offset: int = 0     # first anchor index of this head's feature map
+    n_box: int = 0             # OUT_HEAD: leading output columns that are box encodings (anchors_per_loc * 4)
 
 
 @dataclass
@@ -85,6 +86,11 @@ class Program:
         """TF variable name -> shape, for every variable the program consumes."""
         out: Dict[str, Tuple[int, ...]] = {}
         for op in self.ops:
+            if op.out_mode == OUT_HEAD:
+                for sub, cols in (("BoxEncodingPredictor", op.n_box), ("ClassPredictor", op.cout - op.n_box)):
+                    out["%s/%s/weights" % (op.scope, sub)] = (op.k, op.k, op.cin, cols)
+                    out["%s/%s/biases" % (op.scope, sub)] = (cols,)
+                continue
             if op.kind == OP_DW:
                 out[op.scope + "/depthwise_weights"] = (op.k, op.k, op.cin, 1)
             else:
@@ -144,18 +150,19 @@ def build(size: int = INPUT_SIZE) -> Program:
         op.wout, op.pad_l = tf_same(src.w, op.k, op.stride)
         p.tensors[op.dst] = Tensor(op.dst, op.hout, op.wout, op.cout)
 
-    # heads (box then class per feature map, 3x3 SAME, biases, no activation)
+    # heads: BoxEncodingPredictor and ClassPredictor of a feature map read the same input, so they run
+    # as ONE 3x3 conv whose output columns are [a*4 box encodings | a*91 class logits] (biases, no activation)
     off = 0
     for i, (tname, a) in enumerate(zip(taps, _ANCHORS_PER_LOCATION)):
         tt = p.tensors[tname]
-        for mode, scope, cols in ((OUT_BOX, "BoxEncodingPredictor", 4), (OUT_CLS, "ClassPredictor", NUM_CLASSES)):
-            op = Op(OP_CONV, "BoxPredictor_%d/%s" % (i, scope), tname, "head_%d_%d" % (i, mode), tt.c, a * cols,
-                    3, 1, ACT_NONE, False, out_mode=mode, head_index=i, anchors_per_loc=a)
-            op.hin, op.win = tt.h, tt.w
-            op.hout, op.pad_t = tf_same(tt.h, 3, 1)
-            op.wout, op.pad_l = tf_same(tt.w, 3, 1)
-            op.anchor_offset = off
-            ops.append(op)
+        op = Op(OP_CONV, "BoxPredictor_%d" % i, tname, "head_%d" % i, tt.c, a * 4 + a * NUM_CLASSES,
+                3, 1, ACT_NONE, False, out_mode=OUT_HEAD, head_index=i, anchors_per_loc=a)
+        op.n_box = a * 4
+        op.hin, op.win = tt.h, tt.w
+        op.hout, op.pad_t = tf_same(tt.h, 3, 1)
+        op.wout, op.pad_l = tf_same(tt.w, 3, 1)
+        op.anchor_offset = off
+        ops.append(op)
         p.feature_maps.append((tname, tt.h, a))
         off += tt.h * tt.w * a
     p.num_anchors = off

@@ -146,12 +146,74 @@ __device__ __forceinline__ void wz_epilogue4(const WzConvArgs& a, int m, int n4,
     } else {
         const int hw = a.hout * a.wout;
         const int b = m / hw, pix = m - b * hw;
-        float* o = reinterpret_cast<float*>(a.out) + (size_t)b * a.out_batch_stride + a.out_off +
-                   (size_t)pix * a.cout + n4;
+        float* o;
+        int cols, n0;
+        if (a.out_mode == WZ_OUT_HEAD && n4 >= a.n_box) {   // n_box is a multiple of 4: no group straddles
+            cols = a.cout - a.n_box;
+            n0 = n4 - a.n_box;
+            o = a.out2 + (size_t)b * a.out2_batch_stride + a.out2_off;
+        } else {
+            cols = (a.out_mode == WZ_OUT_HEAD) ? a.n_box : a.cout;
+            n0 = n4;
+            o = reinterpret_cast<float*>(a.out) + (size_t)b * a.out_batch_stride + a.out_off;
+        }
+        o += (size_t)pix * cols + n0;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            if (n4 + r < a.cout) o[r] = v[r];
+            if (n0 + r < cols) o[r] = v[r];
     }
+}
+
+#define CONV_U 4   // K chunks (32 channels each) per register buffer; two buffers are in flight
+
+struct ConvFrags {
+    half8_t xa[CONV_U][CONV_MT];
+    half8_t wf[CONV_U][CONV_NT];
+};
+
+// Issue the loads of the next CONV_U K-chunks (flattened index ql = tap * kc + c) into `f`.
+// (t, c) walk the chunk order; chunks at or beyond q1 load nothing and contribute zeros.
+template <int KS>
+__device__ __forceinline__ void wz_conv_load(const WzConvArgs& a, ConvFrags& f, int& ql, const int q1, int& t,
+                                             int& c, const int (&iy0)[CONV_MT], const int (&ix0)[CONV_MT],
+                                             const int (&boff)[CONV_MT], const bool (&mv)[CONV_MT],
+                                             const half_t* wlane, const int nt0, const int cg8) {
+    constexpr int taps = KS * KS;
+    const half8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < CONV_U; ++u) {
+        const bool live = ql < q1;   // wave-uniform
+        const int ky = (KS == 1) ? 0 : t / KS, kx = (KS == 1) ? 0 : t - ky * KS;
+        const bool cin_ok = (c * 32 + cg8) < a.cin;
+#pragma unroll
+        for (int mt = 0; mt < CONV_MT; ++mt) {
+            const int iy = iy0[mt] + ky, ix = ix0[mt] + kx;
+            const bool ok = live && cin_ok && mv[mt] && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
+            f.xa[u][mt] = ok ? *reinterpret_cast<const half8_t*>(
+                                   a.in + ((size_t)(boff[mt] + iy) * a.win + ix) * a.cin + c * 32 + cg8)
+                             : zero;
+        }
+#pragma unroll
+        for (int nt = 0; nt < CONV_NT; ++nt)
+            f.wf[u][nt] = live ? *reinterpret_cast<const half8_t*>(
+                                     wlane + ((size_t)((nt0 + nt) * taps + t) * a.kc + c) * 512)
+                               : zero;
+        ++ql;
+        if (++c == a.kc) {
+            c = 0;
+            ++t;
+        }
+    }
+}
+
+__device__ __forceinline__ void wz_conv_mfma(const ConvFrags& f, float4_t (&acc)[CONV_MT][CONV_NT]) {
+#pragma unroll
+    for (int u = 0; u < CONV_U; ++u)
+#pragma unroll
+        for (int mt = 0; mt < CONV_MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < CONV_NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.wf[u][nt], f.xa[u][mt], acc[mt][nt], 0, 0, 0);
 }
 
 template <int KS>
@@ -188,44 +250,21 @@ __global__ __launch_bounds__(256) void wz_k_conv(const WzConvArgs a) {
     const int per = (a.kchunks + a.splitk - 1) / a.splitk;
     const int q0 = blockIdx.z * per;
     const int q1 = min(q0 + per, a.kchunks);
-    constexpr int taps = KS * KS;
     const half_t* wlane = a.w + (size_t)lane * 8;
     const int cg8 = g * 8;
 
-    int t = q0 / a.kc, c = q0 - t * a.kc;
+    // software pipeline: while the MFMAs of one register buffer run, the loads of the other are in flight
+    int ql = q0, t = (KS == 1) ? 0 : q0 / a.kc, c = (KS == 1) ? q0 : q0 - t * a.kc;
+    ConvFrags fa, fb;
+    wz_conv_load<KS>(a, fa, ql, q1, t, c, iy0, ix0, boff, mv, wlane, nt0, cg8);
     for (int q = q0; q < q1;) {
-        const int ky = t / KS, kx = t - ky * KS;
-        const half_t* ap[CONV_MT];
-        bool ok[CONV_MT];
-#pragma unroll
-        for (int mt = 0; mt < CONV_MT; ++mt) {
-            const int iy = iy0[mt] + ky, ix = ix0[mt] + kx;
-            ok[mt] = mv[mt] && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
-            ap[mt] = a.in + ((size_t)(boff[mt] + iy) * a.win + ix) * a.cin + cg8;
-        }
-        const int c_end = min(a.kc, c + (q1 - q));
-#pragma unroll 2
-        for (; c < c_end; ++c, ++q) {
-            half8_t xa[CONV_MT], wf[CONV_NT];
-            const bool cin_ok = (c * 32 + cg8) < a.cin;
-#pragma unroll
-            for (int mt = 0; mt < CONV_MT; ++mt) {
-                if (ok[mt] && cin_ok)
-                    xa[mt] = *reinterpret_cast<const half8_t*>(ap[mt] + c * 32);
-                else
-                    xa[mt] = (half8_t){0, 0, 0, 0, 0, 0, 0, 0};
-            }
-#pragma unroll
-            for (int nt = 0; nt < CONV_NT; ++nt)
-                wf[nt] = *reinterpret_cast<const half8_t*>(wlane + ((size_t)((nt0 + nt) * taps + t) * a.kc + c) * 512);
-#pragma unroll
-            for (int mt = 0; mt < CONV_MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < CONV_NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], xa[mt], acc[mt][nt], 0, 0, 0);
-        }
-        c = 0;
-        ++t;
+        wz_conv_load<KS>(a, fb, ql, q1, t, c, iy0, ix0, boff, mv, wlane, nt0, cg8);
+        wz_conv_mfma(fa, acc);
+        q += CONV_U;
+        if (q >= q1) break;
+        wz_conv_load<KS>(a, fa, ql, q1, t, c, iy0, ix0, boff, mv, wlane, nt0, cg8);
+        wz_conv_mfma(fb, acc);
+        q += CONV_U;
     }
 
     // D layout: lane holds rows (n) g*4..g*4+3 of column (m) r16

@@ -125,26 +125,33 @@ __device__ int wz_threshold_bin(const uint32_t* __restrict__ ghist, uint32_t* sh
 
 __global__ __launch_bounds__(256) void wz_k_compact(WzPostBuffers b, WzPostConsts k) {
     __shared__ uint32_t sh[64];
+    __shared__ uint32_t s_cnt, s_base;
     const int f = blockIdx.y, total = k.num_anchors * k.num_classes;
+    if (threadIdx.x == 0) s_cnt = 0;
     const uint32_t thr = (uint32_t)wz_threshold_bin(b.hist + (size_t)f * WZ_HIST_BINS, sh, WZ_CAND_TARGET, nullptr);
     const int base = blockIdx.x * 256 * POST_ITEMS;
-    const int lane = threadIdx.x & 63;
+    uint32_t keys[POST_ITEMS], ties[POST_ITEMS], pos[POST_ITEMS];
+    uint32_t mask = 0;
 #pragma unroll
     for (int it = 0; it < POST_ITEMS; ++it) {
         const int j = base + it * 256 + threadIdx.x;
-        uint32_t key = 0, tie = 0;
-        const bool p = j < total && wz_candidate(b, k, f, j, key, tie) && (key >> 20) >= thr;
-        const unsigned long long m = __ballot(p);
-        if (m) {
-            uint32_t pos0 = 0;
-            const int leader = __ffsll((long long)m) - 1;
-            if (lane == leader) pos0 = atomicAdd(&b.count[f], (uint32_t)__popcll(m));
-            pos0 = __shfl(pos0, leader);
-            if (p) {
-                const uint32_t pos = pos0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (pos < WZ_CAND_CAP) b.cand[(size_t)f * WZ_CAND_CAP + pos] = make_uint2(key, tie);
-            }
+        keys[it] = ties[it] = pos[it] = 0;
+        if (j < total && wz_candidate(b, k, f, j, keys[it], ties[it]) && (keys[it] >> 20) >= thr) {
+            mask |= 1u << it;
+            pos[it] = atomicAdd(&s_cnt, 1u);     // LDS atomic: order is irrelevant, the list gets sorted
         }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt) s_base = atomicAdd(&b.count[f], s_cnt);   // one global atomic per block
+    __syncthreads();
+    if (mask) {
+        const uint32_t g0 = s_base;
+#pragma unroll
+        for (int it = 0; it < POST_ITEMS; ++it)
+            if ((mask >> it) & 1u) {
+                const uint32_t p = g0 + pos[it];
+                if (p < WZ_CAND_CAP) b.cand[(size_t)f * WZ_CAND_CAP + p] = make_uint2(keys[it], ties[it]);
+            }
     }
 }
 
@@ -273,12 +280,47 @@ __global__ __launch_bounds__(NMS_THREADS) void wz_k_nms(WzPostBuffers b, WzPostC
         }
         __syncthreads();
         if (wave == 0) {
-            for (int i = 0; i < cnt && kept < k.max_total; ++i) {
-                const unsigned long long comp = sorted[i];
-                const uint32_t tie = 0xFFFFFFFFu - (uint32_t)(comp & 0xFFFFFFFFull);
-                const int cls = (int)(tie / (uint32_t)A);
-                kept = wz_try_keep(S, kept, S->sbox[i], cls, __uint_as_float((uint32_t)(comp >> 32)), k, lane);
+            // The kept list lives in registers (lane j holds entries j and j+64); candidates are
+            // pre-loaded 64 at a time, one per lane, and broadcast with v_readlane: no LDS round
+            // trips on the serial chain.
+            float4_t kb0 = {0.f, 0.f, 0.f, 0.f}, kb1 = {0.f, 0.f, 0.f, 0.f};
+            int kc0 = -1, kc1 = -1;
+            float ks0 = 0.f, ks1 = 0.f;
+            const bool count_classes = k.max_per_class < k.max_total;
+            for (int base = 0; base < cnt && kept < k.max_total; base += 64) {
+                const int i = base + lane;
+                const unsigned long long comp = (i < cnt) ? sorted[i] : 0ull;
+                const float4_t cb = (i < cnt) ? S->sbox[i] : (float4_t){0.f, 0.f, 0.f, 0.f};
+                const int lim = min(64, cnt - base);
+                for (int tq = 0; tq < lim && kept < k.max_total; ++tq) {
+                    const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(comp >> 32), tq);
+                    const uint32_t tie = 0xFFFFFFFFu - (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)comp, tq);
+                    float4_t box;
+                    box[0] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb[0]), tq));
+                    box[1] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb[1]), tq));
+                    box[2] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb[2]), tq));
+                    box[3] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb[3]), tq));
+                    const int cls = (int)(tie / (uint32_t)A);
+                    const bool sup = (kc0 == cls && wz_iou(box, kb0) > k.iou_thr) ||
+                                     (kc1 == cls && wz_iou(box, kb1) > k.iou_thr);
+                    bool ok = !__any(sup);
+                    if (ok && count_classes) {
+                        int same = (kc0 == cls ? 1 : 0) + (kc1 == cls ? 1 : 0);
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) same += __shfl_xor(same, o);
+                        ok = same < k.max_per_class;
+                    }
+                    if (ok) {
+                        if (lane == (kept & 63)) {
+                            if (kept < 64) { kb0 = box; kc0 = cls; ks0 = __uint_as_float(key); }
+                            else { kb1 = box; kc1 = cls; ks1 = __uint_as_float(key); }
+                        }
+                        ++kept;
+                    }
+                }
             }
+            if (lane < kept) { S->kbox[lane] = kb0; S->kcls[lane] = kc0; S->kscore[lane] = ks0; }
+            if (lane + 64 < kept) { S->kbox[lane + 64] = kb1; S->kcls[lane + 64] = kc1; S->kscore[lane + 64] = ks1; }
             if (lane == 0) S->kept = kept;
         }
         __syncthreads();

@@ -36,6 +36,9 @@ struct WzConvArgs {
     int32_t kchunks;       // ksize*ksize*kc
     int64_t out_batch_stride;   // head modes: floats per frame in the concat buffer
     int64_t out_off;            // head modes: first float of this feature map
+    float* out2;                // WZ_OUT_HEAD: class-logit buffer (out = box-encoding buffer)
+    int64_t out2_batch_stride, out2_off;
+    int32_t n_box;              // WZ_OUT_HEAD: columns [0, n_box) are box encodings, the rest class logits
 };
 
 // Per-camera filter state resident in HBM (see wz_set_camera_filter).

@@ -51,7 +51,7 @@ struct StageTimer {
 
 struct wz_engine {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;            // = lanes[0].stream (stage-level entry points, filters)
     std::string name;
     std::vector<uint8_t> blob;
     WzBlobHeader hdr;
@@ -62,27 +62,36 @@ struct wz_engine {
 
     uint8_t* d_weights = nullptr;
     float* d_anchors = nullptr;
-    std::vector<void*> bufs;                 // owned activation buffers
-    std::vector<half_t*> tptr;               // tensor index -> device pointer
     uint8_t* d_frames = nullptr;             // staging for host frames [max_batch][max_w*max_h*3]
     size_t frame_stride = 0;
-    float* d_box_enc = nullptr;
-    float* d_logits = nullptr;
-    float* d_ws = nullptr;
-    WzPostBuffers post;
     WzPostConsts pc;
-    void* d_post_scratch = nullptr;          // hist + count (memset per batch)
     size_t post_scratch_bytes = 0;
 
-    WzFrameDesc* h_desc[WZ_SLOTS] = {};      // pinned
-    WzFrameDesc* d_desc[WZ_SLOTS] = {};
-    wz_detection_t* d_rows[WZ_SLOTS] = {};
-    uint8_t* d_pass[WZ_SLOTS] = {};
-    wz_detection_t* h_rows[WZ_SLOTS] = {};   // pinned
-    uint8_t* h_pass[WZ_SLOTS] = {};
-    hipEvent_t slot_done[WZ_SLOTS] = {};
-    int slot_n[WZ_SLOTS] = {};
-    std::map<int, hipGraphExec_t> graphs;    // key = slot * 4096 + n
+    // A lane is everything one in-flight batch needs: its own stream, activation buffers, head
+    // outputs, post-processing scratch, descriptor/result blocks and captured graphs.  Lanes run
+    // concurrently on the GPU (a batch-8 layer fills only a fraction of the 256 CUs), slot i of the
+    // API is lane i.
+    struct Lane {
+        hipStream_t stream = nullptr;
+        std::vector<void*> bufs;             // owned activation buffers
+        std::vector<half_t*> tptr;           // tensor index -> device pointer
+        float* d_box_enc = nullptr;
+        float* d_logits = nullptr;
+        float* d_ws = nullptr;
+        WzPostBuffers post;
+        void* d_post_scratch = nullptr;      // hist + count (memset per batch)
+        WzFrameDesc* h_desc = nullptr;       // pinned
+        WzFrameDesc* d_desc = nullptr;
+        wz_detection_t* d_rows = nullptr;
+        uint8_t* d_pass = nullptr;
+        wz_detection_t* h_rows = nullptr;    // pinned
+        uint8_t* h_pass = nullptr;
+        hipEvent_t done = nullptr;
+        int n = 0;
+        std::map<int, hipGraphExec_t> graphs;    // key = batch size
+    };
+    Lane lanes[WZ_SLOTS];
+    int n_lanes = WZ_SLOTS;
 
     std::vector<WzCamFilter> h_cams;
     WzCamFilter* d_cams = nullptr;
@@ -94,29 +103,30 @@ struct wz_engine {
 };
 
 static int input_tensor_index(wz_engine* e) { return e->ops[0].src; }
+typedef wz_engine::Lane Lane;
 
 // ------------------------------------------------------------------------------------------------
 // pipeline
 // ------------------------------------------------------------------------------------------------
-static void enqueue_network(wz_engine* e, int n, StageTimer* t) {
-    hipStream_t s = e->stream;
+static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t) {
+    hipStream_t s = L.stream;
     for (uint32_t i = 0; i < e->hdr.n_ops; ++i) {
         const WzOpDesc& op = e->ops[i];
         const uint8_t* wbase = e->d_weights;
         if (op.kind == WZ_OP_STEM) {
-            wz_launch_stem(e->tptr[op.src], (const float*)(wbase + op.w_off), (const float*)(wbase + op.b_off),
-                           e->tptr[op.dst], n, op.hin, op.win, op.hout, op.wout, op.pad_t, op.pad_l, s);
+            wz_launch_stem(L.tptr[op.src], (const float*)(wbase + op.w_off), (const float*)(wbase + op.b_off),
+                           L.tptr[op.dst], n, op.hin, op.win, op.hout, op.wout, op.pad_t, op.pad_l, s);
         } else if (op.kind == WZ_OP_DW) {
-            wz_launch_dw(e->tptr[op.src], (const half_t*)(wbase + op.w_off), (const float*)(wbase + op.b_off),
-                         e->tptr[op.dst], n, op.hin, op.win, op.cin, op.hout, op.wout, op.stride, op.pad_t,
+            wz_launch_dw(L.tptr[op.src], (const half_t*)(wbase + op.w_off), (const float*)(wbase + op.b_off),
+                         L.tptr[op.dst], n, op.hin, op.win, op.cin, op.hout, op.wout, op.stride, op.pad_t,
                          op.pad_l, op.act, s);
         } else {
             WzConvArgs a;
             memset(&a, 0, sizeof(a));
-            a.in = e->tptr[op.src];
+            a.in = L.tptr[op.src];
             a.w = (const half_t*)(wbase + op.w_off);
             a.bias = (const float*)(wbase + op.b_off);
-            a.res = op.res >= 0 ? e->tptr[op.res] : nullptr;
+            a.res = op.res >= 0 ? L.tptr[op.res] : nullptr;
             a.M = n * op.hout * op.wout;
             a.hin = op.hin; a.win = op.win; a.cin = op.cin;
             a.hout = op.hout; a.wout = op.wout; a.cout = op.cout; a.n_pad = op.n_pad;
@@ -125,25 +135,33 @@ static void enqueue_network(wz_engine* e, int n, StageTimer* t) {
             a.kchunks = op.ksize * op.ksize * op.kc;
             void* final_out;
             if (op.out_mode == WZ_OUT_ACT) {
-                final_out = e->tptr[op.dst];
+                final_out = L.tptr[op.dst];
             } else if (op.out_mode == WZ_OUT_BOX) {
-                final_out = e->d_box_enc;
+                final_out = L.d_box_enc;
                 a.out_batch_stride = (int64_t)e->hdr.num_anchors * 4;
                 a.out_off = (int64_t)op.anchor_off * 4;
-            } else {
-                final_out = e->d_logits;
+            } else if (op.out_mode == WZ_OUT_CLS) {
+                final_out = L.d_logits;
                 a.out_batch_stride = (int64_t)e->hdr.num_anchors * e->hdr.num_classes;
                 a.out_off = (int64_t)op.anchor_off * e->hdr.num_classes;
+            } else {   // WZ_OUT_HEAD: box columns -> d_box_enc, class columns -> d_logits
+                final_out = L.d_box_enc;
+                a.out_batch_stride = (int64_t)e->hdr.num_anchors * 4;
+                a.out_off = (int64_t)op.anchor_off * 4;
+                a.out2 = L.d_logits;
+                a.out2_batch_stride = (int64_t)e->hdr.num_anchors * e->hdr.num_classes;
+                a.out2_off = (int64_t)op.anchor_off * e->hdr.num_classes;
+                a.n_box = op.n_box;
             }
             int sk = e->use_splitk ? wz_choose_splitk(a.M, a.n_pad, a.kchunks) : 1;
             while (sk > 1 && (size_t)sk * a.M * a.n_pad * 4 > WZ_WS_BYTES) --sk;
             a.splitk = sk;
             if (sk > 1) {
-                a.out = e->d_ws;
+                a.out = L.d_ws;
                 wz_launch_conv(a, s);
                 if (t) t->mark();
                 a.out = final_out;
-                wz_launch_splitk_reduce(a, e->d_ws, s);
+                wz_launch_splitk_reduce(a, L.d_ws, s);
             } else {
                 a.out = final_out;
                 wz_launch_conv(a, s);
@@ -154,58 +172,58 @@ static void enqueue_network(wz_engine* e, int n, StageTimer* t) {
     }
 }
 
-static void enqueue_post(wz_engine* e, int slot, int n, StageTimer* t) {
-    hipStream_t s = e->stream;
-    (void)hipMemsetAsync(e->d_post_scratch, 0, e->post_scratch_bytes, s);
-    wz_launch_decode(e->post, e->pc, n, s);
+static void enqueue_post(wz_engine* e, Lane& L, bool rows, int n, StageTimer* t) {
+    hipStream_t s = L.stream;
+    (void)hipMemsetAsync(L.d_post_scratch, 0, e->post_scratch_bytes, s);
+    wz_launch_decode(L.post, e->pc, n, s);
     if (t) t->mark();
-    wz_launch_hist(e->post, e->pc, n, s);
+    wz_launch_hist(L.post, e->pc, n, s);
     if (t) t->mark();
-    wz_launch_compact(e->post, e->pc, n, s);
+    wz_launch_compact(L.post, e->pc, n, s);
     if (t) t->mark();
-    wz_launch_nms(e->post, e->pc, n, s);
+    wz_launch_nms(L.post, e->pc, n, s);
     if (t) t->mark();
-    if (slot >= 0) {
-        wz_launch_rows(e->post, e->d_desc[slot], e->d_cams, n, e->pc.max_total, e->d_rows[slot], e->d_pass[slot], s);
+    if (rows) {
+        wz_launch_rows(L.post, L.d_desc, e->d_cams, n, e->pc.max_total, L.d_rows, L.d_pass, s);
         if (t) t->mark();
     }
 }
 
 // everything between "descriptors are in h_desc[slot]" and "rows are in h_rows[slot]"
-static void enqueue_batch(wz_engine* e, int slot, int n, StageTimer* t) {
-    hipStream_t s = e->stream;
-    (void)hipMemcpyAsync(e->d_desc[slot], e->h_desc[slot], sizeof(WzFrameDesc) * n, hipMemcpyHostToDevice, s);
+static void enqueue_batch(wz_engine* e, Lane& L, int n, StageTimer* t) {
+    hipStream_t s = L.stream;
+    (void)hipMemcpyAsync(L.d_desc, L.h_desc, sizeof(WzFrameDesc) * n, hipMemcpyHostToDevice, s);
     if (t) t->mark();
-    wz_launch_preprocess(e->d_desc[slot], n, (int)e->hdr.input_size, e->tptr[input_tensor_index(e)], s);
+    wz_launch_preprocess(L.d_desc, n, (int)e->hdr.input_size, L.tptr[input_tensor_index(e)], s);
     if (t) t->mark();
-    enqueue_network(e, n, t);
-    enqueue_post(e, slot, n, t);
-    (void)hipMemcpyAsync(e->h_rows[slot], e->d_rows[slot], sizeof(wz_detection_t) * WZ_MAX_DETECTIONS * n,
+    enqueue_network(e, L, n, t);
+    enqueue_post(e, L, true, n, t);
+    (void)hipMemcpyAsync(L.h_rows, L.d_rows, sizeof(wz_detection_t) * WZ_MAX_DETECTIONS * n,
                          hipMemcpyDeviceToHost, s);
-    (void)hipMemcpyAsync(e->h_pass[slot], e->d_pass[slot], (size_t)WZ_MAX_DETECTIONS * n, hipMemcpyDeviceToHost, s);
+    (void)hipMemcpyAsync(L.h_pass, L.d_pass, (size_t)WZ_MAX_DETECTIONS * n, hipMemcpyDeviceToHost, s);
 }
 
 static int run_batch(wz_engine* e, int slot, int n) {
+    Lane& L = e->lanes[slot];
     if (e->use_graph) {
-        const int key = slot * 4096 + n;
-        auto it = e->graphs.find(key);
-        if (it == e->graphs.end()) {
+        auto it = L.graphs.find(n);
+        if (it == L.graphs.end()) {
             hipGraph_t g = nullptr;
-            HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
-            enqueue_batch(e, slot, n, nullptr);
-            HIPCHK(hipStreamEndCapture(e->stream, &g));
+            HIPCHK(hipStreamBeginCapture(L.stream, hipStreamCaptureModeThreadLocal));
+            enqueue_batch(e, L, n, nullptr);
+            HIPCHK(hipStreamEndCapture(L.stream, &g));
             hipGraphExec_t ge = nullptr;
             HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
             (void)hipGraphDestroy(g);
-            it = e->graphs.emplace(key, ge).first;
+            it = L.graphs.emplace(n, ge).first;
         }
-        HIPCHK(hipGraphLaunch(it->second, e->stream));
+        HIPCHK(hipGraphLaunch(it->second, L.stream));
     } else {
-        enqueue_batch(e, slot, n, nullptr);
+        enqueue_batch(e, L, n, nullptr);
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipEventRecord(e->slot_done[slot], e->stream));
-    e->slot_n[slot] = n;
+    HIPCHK(hipEventRecord(L.done, L.stream));
+    L.n = n;
     return WZ_OK;
 }
 
@@ -261,7 +279,8 @@ static int load_blob(wz_engine* e, const char* path) {
             (op.out_mode == WZ_OUT_ACT && op.dst < 0) || op.w_off < 0 || (uint64_t)op.w_off >= h.weights_bytes ||
             (op.kind == WZ_OP_CONV && (op.n_pad % 32 != 0 || op.cin % 8 != 0 || op.n_pad < op.cout ||
                                        (op.out_mode == WZ_OUT_ACT && op.cout % 8 != 0) ||
-                                       (op.ksize != 1 && op.ksize != 3))) ||
+                                       (op.ksize != 1 && op.ksize != 3) ||
+                                       (op.out_mode == WZ_OUT_HEAD && (op.n_box % 4 != 0 || op.n_box <= 0 || op.n_box >= op.cout)))) ||
             (op.kind == WZ_OP_DW && op.cin % 8 != 0))
             return wz_fail(WZ_EFORMAT, "%s: op %u (%s) is malformed", path, i, op.name);
     }
@@ -292,6 +311,7 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     e->no_reuse = (env = getenv("WZ_NO_BUFFER_REUSE")) && atoi(env) != 0;
     e->use_graph = !((env = getenv("WZ_GRAPH")) && atoi(env) == 0);
     e->use_splitk = !((env = getenv("WZ_SPLITK")) && atoi(env) == 0);
+    if ((env = getenv("WZ_LANES")) && atoi(env) >= 1 && atoi(env) <= WZ_SLOTS) e->n_lanes = atoi(env);
 
 #define CK(expr)                                                                                        \
     do {                                                                                                \
@@ -307,7 +327,6 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     char nm[256];
     wz_device_name_of(device, nm, sizeof(nm));
     e->name = nm;
-    CK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     wz_post_init();
 
     const WzBlobHeader& h = e->hdr;
@@ -315,42 +334,8 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     CK(hipMemcpy(e->d_weights, e->blob.data() + h.weights_off, h.weights_bytes, hipMemcpyHostToDevice));
     CK(hipMalloc((void**)&e->d_anchors, (size_t)h.num_anchors * 16));
     CK(hipMemcpy(e->d_anchors, e->blob.data() + h.anchors_off, (size_t)h.num_anchors * 16, hipMemcpyHostToDevice));
-
-    // activation buffers: one per slot (tensors with disjoint lifetimes share), or one per tensor
-    e->tptr.assign(h.n_tensors, nullptr);
-    if (e->no_reuse) {
-        for (uint32_t i = 0; i < h.n_tensors; ++i) {
-            const WzTensorDesc& t = e->tensors[i];
-            void* p = nullptr;
-            CK(hipMalloc(&p, (size_t)max_batch * t.h * t.w * t.c * 2 + 256));
-            e->bufs.push_back(p);
-            e->tptr[i] = (half_t*)p;
-        }
-    } else {
-        std::vector<size_t> slot_bytes(h.n_slots, 0);
-        for (uint32_t i = 0; i < h.n_tensors; ++i) {
-            const WzTensorDesc& t = e->tensors[i];
-            if (t.slot < 0 || t.slot >= (int)h.n_slots) {
-                wz_fail(WZ_EFORMAT, "tensor %u has a bad slot", i);
-                wz_destroy(e);
-                return WZ_EFORMAT;
-            }
-            size_t b = (size_t)max_batch * t.h * t.w * t.c * 2 + 256;
-            if (b > slot_bytes[t.slot]) slot_bytes[t.slot] = b;
-        }
-        for (uint32_t sidx = 0; sidx < h.n_slots; ++sidx) {
-            void* p = nullptr;
-            CK(hipMalloc(&p, slot_bytes[sidx]));
-            e->bufs.push_back(p);
-        }
-        for (uint32_t i = 0; i < h.n_tensors; ++i) e->tptr[i] = (half_t*)e->bufs[e->tensors[i].slot];
-    }
-
     e->frame_stride = ((size_t)max_width * max_height * 3 + 255) & ~(size_t)255;
     CK(hipMalloc((void**)&e->d_frames, e->frame_stride * max_batch));
-    CK(hipMalloc((void**)&e->d_box_enc, (size_t)max_batch * h.num_anchors * 4 * 4));
-    CK(hipMalloc((void**)&e->d_logits, (size_t)max_batch * h.num_anchors * h.num_classes * 4));
-    CK(hipMalloc((void**)&e->d_ws, WZ_WS_BYTES));
 
     e->pc.num_anchors = h.num_anchors;
     e->pc.num_classes = h.num_classes;
@@ -359,33 +344,68 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     e->pc.score_thr = h.score_threshold;
     e->pc.iou_thr = h.iou_threshold;
     e->pc.scale_y = h.scale_y; e->pc.scale_x = h.scale_x; e->pc.scale_h = h.scale_h; e->pc.scale_w = h.scale_w;
-
-    WzPostBuffers& pb = e->post;
-    pb.box_enc = e->d_box_enc;
-    pb.logits = e->d_logits;
-    pb.anchors = e->d_anchors;
-    CK(hipMalloc((void**)&pb.boxes, (size_t)max_batch * h.num_anchors * 16));
-    CK(hipMalloc((void**)&pb.valid, (size_t)max_batch * h.num_anchors));
     e->post_scratch_bytes = (size_t)max_batch * (WZ_HIST_BINS + 1) * 4;
-    CK(hipMalloc(&e->d_post_scratch, e->post_scratch_bytes));
-    pb.hist = (uint32_t*)e->d_post_scratch;
-    pb.count = pb.hist + (size_t)max_batch * WZ_HIST_BINS;
-    CK(hipMalloc((void**)&pb.cand, (size_t)max_batch * WZ_CAND_CAP * sizeof(uint2)));
-    CK(hipMalloc((void**)&pb.det_boxes, (size_t)max_batch * h.max_total * 16));
-    CK(hipMalloc((void**)&pb.det_scores, (size_t)max_batch * h.max_total * 4));
-    CK(hipMalloc((void**)&pb.det_classes, (size_t)max_batch * h.max_total * 4));
-    CK(hipMalloc((void**)&pb.det_num, (size_t)max_batch * 4));
 
-    for (int sidx = 0; sidx < WZ_SLOTS; ++sidx) {
-        CK(hipHostMalloc((void**)&e->h_desc[sidx], sizeof(WzFrameDesc) * max_batch, hipHostMallocDefault));
-        CK(hipMalloc((void**)&e->d_desc[sidx], sizeof(WzFrameDesc) * max_batch));
-        CK(hipMalloc((void**)&e->d_rows[sidx], sizeof(wz_detection_t) * WZ_MAX_DETECTIONS * max_batch));
-        CK(hipMalloc((void**)&e->d_pass[sidx], (size_t)WZ_MAX_DETECTIONS * max_batch));
-        CK(hipHostMalloc((void**)&e->h_rows[sidx], sizeof(wz_detection_t) * WZ_MAX_DETECTIONS * max_batch,
-                         hipHostMallocDefault));
-        CK(hipHostMalloc((void**)&e->h_pass[sidx], (size_t)WZ_MAX_DETECTIONS * max_batch, hipHostMallocDefault));
-        CK(hipEventCreateWithFlags(&e->slot_done[sidx], hipEventDisableTiming));
+    for (uint32_t i = 0; i < h.n_tensors; ++i)
+        if (e->tensors[i].slot < 0 || e->tensors[i].slot >= (int)h.n_slots) {
+            wz_fail(WZ_EFORMAT, "tensor %u has a bad slot", i);
+            wz_destroy(e);
+            return WZ_EFORMAT;
+        }
+
+    for (int li = 0; li < e->n_lanes; ++li) {
+        Lane& L = e->lanes[li];
+        CK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+        // activation buffers: one per slot (tensors with disjoint lifetimes share), or one per tensor
+        L.tptr.assign(h.n_tensors, nullptr);
+        if (e->no_reuse) {
+            for (uint32_t i = 0; i < h.n_tensors; ++i) {
+                const WzTensorDesc& t = e->tensors[i];
+                void* p = nullptr;
+                CK(hipMalloc(&p, (size_t)max_batch * t.h * t.w * t.c * 2 + 256));
+                L.bufs.push_back(p);
+                L.tptr[i] = (half_t*)p;
+            }
+        } else {
+            std::vector<size_t> slot_bytes(h.n_slots, 0);
+            for (uint32_t i = 0; i < h.n_tensors; ++i) {
+                const WzTensorDesc& t = e->tensors[i];
+                const size_t b = (size_t)max_batch * t.h * t.w * t.c * 2 + 256;
+                if (b > slot_bytes[t.slot]) slot_bytes[t.slot] = b;
+            }
+            for (uint32_t sidx = 0; sidx < h.n_slots; ++sidx) {
+                void* p = nullptr;
+                CK(hipMalloc(&p, slot_bytes[sidx]));
+                L.bufs.push_back(p);
+            }
+            for (uint32_t i = 0; i < h.n_tensors; ++i) L.tptr[i] = (half_t*)L.bufs[e->tensors[i].slot];
+        }
+        CK(hipMalloc((void**)&L.d_box_enc, (size_t)max_batch * h.num_anchors * 4 * 4));
+        CK(hipMalloc((void**)&L.d_logits, (size_t)max_batch * h.num_anchors * h.num_classes * 4));
+        CK(hipMalloc((void**)&L.d_ws, WZ_WS_BYTES));
+        WzPostBuffers& pb = L.post;
+        pb.box_enc = L.d_box_enc;
+        pb.logits = L.d_logits;
+        pb.anchors = e->d_anchors;
+        CK(hipMalloc((void**)&pb.boxes, (size_t)max_batch * h.num_anchors * 16));
+        CK(hipMalloc((void**)&pb.valid, (size_t)max_batch * h.num_anchors));
+        CK(hipMalloc(&L.d_post_scratch, e->post_scratch_bytes));
+        pb.hist = (uint32_t*)L.d_post_scratch;
+        pb.count = pb.hist + (size_t)max_batch * WZ_HIST_BINS;
+        CK(hipMalloc((void**)&pb.cand, (size_t)max_batch * WZ_CAND_CAP * sizeof(uint2)));
+        CK(hipMalloc((void**)&pb.det_boxes, (size_t)max_batch * h.max_total * 16));
+        CK(hipMalloc((void**)&pb.det_scores, (size_t)max_batch * h.max_total * 4));
+        CK(hipMalloc((void**)&pb.det_classes, (size_t)max_batch * h.max_total * 4));
+        CK(hipMalloc((void**)&pb.det_num, (size_t)max_batch * 4));
+        CK(hipHostMalloc((void**)&L.h_desc, sizeof(WzFrameDesc) * max_batch, hipHostMallocDefault));
+        CK(hipMalloc((void**)&L.d_desc, sizeof(WzFrameDesc) * max_batch));
+        CK(hipMalloc((void**)&L.d_rows, sizeof(wz_detection_t) * WZ_MAX_DETECTIONS * max_batch));
+        CK(hipMalloc((void**)&L.d_pass, (size_t)WZ_MAX_DETECTIONS * max_batch));
+        CK(hipHostMalloc((void**)&L.h_rows, sizeof(wz_detection_t) * WZ_MAX_DETECTIONS * max_batch, hipHostMallocDefault));
+        CK(hipHostMalloc((void**)&L.h_pass, (size_t)WZ_MAX_DETECTIONS * max_batch, hipHostMallocDefault));
+        CK(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
     }
+    e->stream = e->lanes[0].stream;
 
     e->h_cams.resize(WZ_MAX_CAMS);
     memset(e->h_cams.data(), 0, sizeof(WzCamFilter) * WZ_MAX_CAMS);
@@ -412,29 +432,36 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     return WZ_OK;
 }
 
+static int sync_all(wz_engine* e) {
+    for (int li = 0; li < e->n_lanes; ++li)
+        if (e->lanes[li].stream) HIPCHK(hipStreamSynchronize(e->lanes[li].stream));
+    return WZ_OK;
+}
+
 extern "C" void wz_destroy(wz_engine_t* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
-    if (e->stream) (void)hipStreamSynchronize(e->stream);
-    for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
-    for (void* p : e->bufs) (void)hipFree(p);
+    (void)sync_all(e);
     for (int32_t* p : e->cam_sat)
         if (p) (void)hipFree(p);
-    void* devp[] = {e->d_weights, e->d_anchors, e->d_frames, e->d_box_enc, e->d_logits, e->d_ws, e->post.boxes,
-                    e->post.valid, e->d_post_scratch, e->post.cand, e->post.det_boxes, e->post.det_scores,
-                    e->post.det_classes, e->post.det_num, e->d_cams, e->d_tmp_rows, e->d_tmp_pass};
+    void* devp[] = {e->d_weights, e->d_anchors, e->d_frames, e->d_cams, e->d_tmp_rows, e->d_tmp_pass};
     for (void* p : devp)
         if (p) (void)hipFree(p);
-    for (int s = 0; s < WZ_SLOTS; ++s) {
-        if (e->h_desc[s]) (void)hipHostFree(e->h_desc[s]);
-        if (e->d_desc[s]) (void)hipFree(e->d_desc[s]);
-        if (e->d_rows[s]) (void)hipFree(e->d_rows[s]);
-        if (e->d_pass[s]) (void)hipFree(e->d_pass[s]);
-        if (e->h_rows[s]) (void)hipHostFree(e->h_rows[s]);
-        if (e->h_pass[s]) (void)hipHostFree(e->h_pass[s]);
-        if (e->slot_done[s]) (void)hipEventDestroy(e->slot_done[s]);
+    for (int li = 0; li < WZ_SLOTS; ++li) {
+        Lane& L = e->lanes[li];
+        for (auto& kv : L.graphs) (void)hipGraphExecDestroy(kv.second);
+        for (void* p : L.bufs) (void)hipFree(p);
+        void* lp[] = {L.d_box_enc, L.d_logits, L.d_ws, L.post.boxes, L.post.valid, L.d_post_scratch, L.post.cand,
+                      L.post.det_boxes, L.post.det_scores, L.post.det_classes, L.post.det_num, L.d_desc, L.d_rows,
+                      L.d_pass};
+        for (void* p : lp)
+            if (p) (void)hipFree(p);
+        if (L.h_desc) (void)hipHostFree(L.h_desc);
+        if (L.h_rows) (void)hipHostFree(L.h_rows);
+        if (L.h_pass) (void)hipHostFree(L.h_pass);
+        if (L.done) (void)hipEventDestroy(L.done);
+        if (L.stream) (void)hipStreamDestroy(L.stream);
     }
-    if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
 
@@ -445,7 +472,7 @@ extern "C" const char* wz_device_name(wz_engine_t* e) { return e ? e->name.c_str
 // ------------------------------------------------------------------------------------------------
 static int fill_desc(wz_engine* e, int slot, int n, const uint8_t* const* d_rgb, const int* w, const int* h,
                      const int* cam) {
-    if (slot < 0 || slot >= WZ_SLOTS) return wz_fail(WZ_EINVAL, "slot %d out of range", slot);
+    if (slot < 0 || slot >= e->n_lanes) return wz_fail(WZ_EINVAL, "slot %d out of range [0,%d)", slot, e->n_lanes);
     if (n < 1 || n > e->max_batch) return wz_fail(WZ_ELIMIT, "batch %d exceeds max_batch %d", n, e->max_batch);
     const float size = (float)e->hdr.input_size;
     for (int i = 0; i < n; ++i) {
@@ -455,7 +482,7 @@ static int fill_desc(wz_engine* e, int slot, int n, const uint8_t* const* d_rgb,
         if (c >= 0 && e->h_cams[c].enabled && (e->h_cams[c].width != w[i] || e->h_cams[c].height != h[i]))
             return wz_fail(WZ_EINVAL, "frame %d is %dx%d but camera %d filter was set for %dx%d", i, w[i], h[i], c,
                            e->h_cams[c].width, e->h_cams[c].height);
-        WzFrameDesc& d = e->h_desc[slot][i];
+        WzFrameDesc& d = e->lanes[slot].h_desc[i];
         d.rgb = d_rgb[i];
         d.w = w[i];
         d.h = h[i];
@@ -470,40 +497,40 @@ static int fill_desc(wz_engine* e, int slot, int n, const uint8_t* const* d_rgb,
 extern "C" int wz_submit_device(wz_engine_t* e, int slot, int n, const uint8_t* const* d_rgb, const int* w,
                                 const int* h, const int* cam) {
     if (!e || !d_rgb || !w || !h) return wz_fail(WZ_EINVAL, "wz_submit_device: null argument");
+    if (slot < 0 || slot >= e->n_lanes) return wz_fail(WZ_EINVAL, "slot %d out of range [0,%d)", slot, e->n_lanes);
     HIPCHK(hipSetDevice(e->device));
-    if (slot >= 0 && slot < WZ_SLOTS) HIPCHK(hipEventSynchronize(e->slot_done[slot]));  // slot free again?
+    HIPCHK(hipEventSynchronize(e->lanes[slot].done));   // the lane's previous batch has fully drained
     int rc = fill_desc(e, slot, n, d_rgb, w, h, cam);
     if (rc != WZ_OK) return rc;
     return run_batch(e, slot, n);
 }
 
 extern "C" int wz_wait(wz_engine_t* e, int slot) {
-    if (!e || slot < 0 || slot >= WZ_SLOTS) return wz_fail(WZ_EINVAL, "wz_wait: bad argument");
-    HIPCHK(hipEventSynchronize(e->slot_done[slot]));
+    if (!e || slot < 0 || slot >= e->n_lanes) return wz_fail(WZ_EINVAL, "wz_wait: bad argument");
+    HIPCHK(hipEventSynchronize(e->lanes[slot].done));
     return WZ_OK;
 }
 
 extern "C" const wz_detection_t* wz_slot_rows(wz_engine_t* e, int slot) {
-    if (!e || slot < 0 || slot >= WZ_SLOTS) return nullptr;
-    return e->h_rows[slot];
+    if (!e || slot < 0 || slot >= e->n_lanes) return nullptr;
+    return e->lanes[slot].h_rows;
 }
 
 extern "C" int wz_collect(wz_engine_t* e, int slot, wz_detection_t* const* out, uint8_t* const* pass) {
     int rc = wz_wait(e, slot);
     if (rc != WZ_OK) return rc;
-    const int n = e->slot_n[slot];
-    for (int i = 0; i < n; ++i) {
+    const Lane& L = e->lanes[slot];
+    for (int i = 0; i < L.n; ++i) {
         if (out && out[i])
-            memcpy(out[i], e->h_rows[slot] + (size_t)i * WZ_MAX_DETECTIONS, sizeof(wz_detection_t) * WZ_MAX_DETECTIONS);
-        if (pass && pass[i]) memcpy(pass[i], e->h_pass[slot] + (size_t)i * WZ_MAX_DETECTIONS, WZ_MAX_DETECTIONS);
+            memcpy(out[i], L.h_rows + (size_t)i * WZ_MAX_DETECTIONS, sizeof(wz_detection_t) * WZ_MAX_DETECTIONS);
+        if (pass && pass[i]) memcpy(pass[i], L.h_pass + (size_t)i * WZ_MAX_DETECTIONS, WZ_MAX_DETECTIONS);
     }
     return WZ_OK;
 }
 
 extern "C" int wz_sync(wz_engine_t* e) {
     if (!e) return wz_fail(WZ_EINVAL, "wz_sync: null engine");
-    HIPCHK(hipStreamSynchronize(e->stream));
-    return WZ_OK;
+    return sync_all(e);
 }
 
 extern "C" int wz_detect_batch(wz_engine_t* e, int n, const uint8_t* const* rgb, const int* w, const int* h,
@@ -512,6 +539,7 @@ extern "C" int wz_detect_batch(wz_engine_t* e, int n, const uint8_t* const* rgb,
     if (n < 1 || n > e->max_batch) return wz_fail(WZ_ELIMIT, "batch %d exceeds max_batch %d", n, e->max_batch);
     const auto t0 = std::chrono::steady_clock::now();
     HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipEventSynchronize(e->lanes[0].done));
     std::vector<const uint8_t*> dptr(n);
     for (int i = 0; i < n; ++i) {
         if (!rgb[i] || w[i] < 1 || h[i] < 1) return wz_fail(WZ_EINVAL, "frame %d: bad pointer or size", i);
@@ -519,7 +547,7 @@ extern "C" int wz_detect_batch(wz_engine_t* e, int n, const uint8_t* const* rgb,
             return wz_fail(WZ_ELIMIT, "frame %d is %dx%d, engine was created for at most %dx%d", i, w[i], h[i],
                            e->max_w, e->max_h);
         uint8_t* dst = e->d_frames + e->frame_stride * i;
-        HIPCHK(hipMemcpyAsync(dst, rgb[i], (size_t)w[i] * h[i] * 3, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(hipMemcpyAsync(dst, rgb[i], (size_t)w[i] * h[i] * 3, hipMemcpyHostToDevice, e->lanes[0].stream));
         dptr[i] = dst;
     }
     int rc = wz_submit_device(e, 0, n, dptr.data(), w, h, cam);
@@ -543,7 +571,7 @@ extern "C" int wz_set_camera_filter(wz_engine_t* e, int cam, int width, int heig
     if (n_zones < 0 || n_zones > WZ_MAX_ZONES_PER_CAM) return wz_fail(WZ_ELIMIT, "%d zones > %d", n_zones, WZ_MAX_ZONES_PER_CAM);
     if (n_zones > 0 && !zone_fill) return wz_fail(WZ_EINVAL, "zone_fill is null");
     HIPCHK(hipSetDevice(e->device));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    { int _rc = sync_all(e); if (_rc != WZ_OK) return _rc; }
     WzCamFilter& c = e->h_cams[cam];
     if (e->cam_sat[cam]) {
         (void)hipFree(e->cam_sat[cam]);
@@ -578,7 +606,7 @@ extern "C" int wz_set_camera_filter(wz_engine_t* e, int cam, int width, int heig
 extern "C" int wz_clear_camera_filter(wz_engine_t* e, int cam) {
     if (!e || cam < 0 || cam >= WZ_MAX_CAMS) return wz_fail(WZ_EINVAL, "wz_clear_camera_filter: bad argument");
     HIPCHK(hipSetDevice(e->device));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    { int _rc = sync_all(e); if (_rc != WZ_OK) return _rc; }
     memset(&e->h_cams[cam], 0, sizeof(WzCamFilter));
     HIPCHK(hipMemcpy(e->d_cams + cam, &e->h_cams[cam], sizeof(WzCamFilter), hipMemcpyHostToDevice));
     if (e->cam_sat[cam]) {
@@ -640,7 +668,7 @@ extern "C" int wz_profile_device(wz_engine_t* e, int n, const uint8_t* const* d_
                                  int reps, float* stage_ms) {
     if (!e || !stage_ms || reps < 1) return wz_fail(WZ_EINVAL, "wz_profile_device: bad argument");
     HIPCHK(hipSetDevice(e->device));
-    HIPCHK(hipStreamSynchronize(e->stream));
+    { int _rc = sync_all(e); if (_rc != WZ_OK) return _rc; }
     int rc = fill_desc(e, 0, n, d_rgb, w, h, nullptr);
     if (rc != WZ_OK) return rc;
     const size_t ns = e->stage_names.size();
@@ -650,7 +678,7 @@ extern "C" int wz_profile_device(wz_engine_t* e, int n, const uint8_t* const* d_
     for (int r = 0; r < reps + 1; ++r) {   // first repetition is an untimed warm-up
         t.used = 0;
         t.mark();
-        enqueue_batch(e, 0, n, &t);
+        enqueue_batch(e, e->lanes[0], n, &t);
         HIPCHK(hipStreamSynchronize(e->stream));
         if (t.used != ns + 1) return wz_fail(WZ_EINVAL, "profile: %zu marks for %zu stages", t.used, ns);
         if (r == 0) continue;
@@ -705,11 +733,11 @@ extern "C" int wz_stage_preprocess(wz_engine_t* e, const uint8_t* rgb, int w, in
     const uint8_t* p = e->d_frames;
     int rc = fill_desc(e, 0, 1, &p, &w, &h, nullptr);
     if (rc != WZ_OK) return rc;
-    HIPCHK(hipMemcpyAsync(e->d_desc[0], e->h_desc[0], sizeof(WzFrameDesc), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(e->lanes[0].d_desc, e->lanes[0].h_desc, sizeof(WzFrameDesc), hipMemcpyHostToDevice, e->stream));
     const int S = (int)e->hdr.input_size;
-    wz_launch_preprocess(e->d_desc[0], 1, S, e->tptr[input_tensor_index(e)], e->stream);
+    wz_launch_preprocess(e->lanes[0].d_desc, 1, S, e->lanes[0].tptr[input_tensor_index(e)], e->stream);
     HIPCHK(hipStreamSynchronize(e->stream));
-    HIPCHK(hipMemcpy(out_half, e->tptr[input_tensor_index(e)], (size_t)S * S * 4 * 2, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out_half, e->lanes[0].tptr[input_tensor_index(e)], (size_t)S * S * 4 * 2, hipMemcpyDeviceToHost));
     return WZ_OK;
 }
 
@@ -719,13 +747,13 @@ extern "C" int wz_stage_forward(wz_engine_t* e, int n, const uint16_t* in_half, 
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
     const int S = (int)e->hdr.input_size;
-    HIPCHK(hipMemcpy(e->tptr[input_tensor_index(e)], in_half, (size_t)n * S * S * 4 * 2, hipMemcpyHostToDevice));
-    enqueue_network(e, n, nullptr);
+    HIPCHK(hipMemcpy(e->lanes[0].tptr[input_tensor_index(e)], in_half, (size_t)n * S * S * 4 * 2, hipMemcpyHostToDevice));
+    enqueue_network(e, e->lanes[0], n, nullptr);
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipGetLastError());
-    if (box_enc) HIPCHK(hipMemcpy(box_enc, e->d_box_enc, (size_t)n * e->hdr.num_anchors * 16, hipMemcpyDeviceToHost));
+    if (box_enc) HIPCHK(hipMemcpy(box_enc, e->lanes[0].d_box_enc, (size_t)n * e->hdr.num_anchors * 16, hipMemcpyDeviceToHost));
     if (logits)
-        HIPCHK(hipMemcpy(logits, e->d_logits, (size_t)n * e->hdr.num_anchors * e->hdr.num_classes * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(logits, e->lanes[0].d_logits, (size_t)n * e->hdr.num_anchors * e->hdr.num_classes * 4, hipMemcpyDeviceToHost));
     return WZ_OK;
 }
 
@@ -736,7 +764,7 @@ extern "C" int wz_stage_read_tensor(wz_engine_t* e, int idx, int frame, uint16_t
     HIPCHK(hipStreamSynchronize(e->stream));
     const WzTensorDesc& t = e->tensors[idx];
     const size_t per = (size_t)t.h * t.w * t.c;
-    HIPCHK(hipMemcpy(out_half, e->tptr[idx] + per * frame, per * 2, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out_half, e->lanes[0].tptr[idx] + per * frame, per * 2, hipMemcpyDeviceToHost));
     return WZ_OK;
 }
 
@@ -747,15 +775,15 @@ extern "C" int wz_stage_postprocess(wz_engine_t* e, int n, const float* box_enc,
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
     const size_t A = e->hdr.num_anchors, C = e->hdr.num_classes, T = e->hdr.max_total;
-    HIPCHK(hipMemcpy(e->d_box_enc, box_enc, n * A * 16, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(e->d_logits, logits, n * A * C * 4, hipMemcpyHostToDevice));
-    enqueue_post(e, -1, n, nullptr);
+    HIPCHK(hipMemcpy(e->lanes[0].d_box_enc, box_enc, n * A * 16, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->lanes[0].d_logits, logits, n * A * C * 4, hipMemcpyHostToDevice));
+    enqueue_post(e, e->lanes[0], false, n, nullptr);
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipGetLastError());
-    if (boxes) HIPCHK(hipMemcpy(boxes, e->post.det_boxes, n * T * 16, hipMemcpyDeviceToHost));
-    if (scores) HIPCHK(hipMemcpy(scores, e->post.det_scores, n * T * 4, hipMemcpyDeviceToHost));
-    if (classes) HIPCHK(hipMemcpy(classes, e->post.det_classes, n * T * 4, hipMemcpyDeviceToHost));
-    if (num) HIPCHK(hipMemcpy(num, e->post.det_num, n * 4, hipMemcpyDeviceToHost));
+    if (boxes) HIPCHK(hipMemcpy(boxes, e->lanes[0].post.det_boxes, n * T * 16, hipMemcpyDeviceToHost));
+    if (scores) HIPCHK(hipMemcpy(scores, e->lanes[0].post.det_scores, n * T * 4, hipMemcpyDeviceToHost));
+    if (classes) HIPCHK(hipMemcpy(classes, e->lanes[0].post.det_classes, n * T * 4, hipMemcpyDeviceToHost));
+    if (num) HIPCHK(hipMemcpy(num, e->lanes[0].post.det_num, n * 4, hipMemcpyDeviceToHost));
     return WZ_OK;
 }
 
@@ -765,17 +793,17 @@ extern "C" int wz_stage_rows(wz_engine_t* e, int w, int h, const float* boxes, c
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
     const size_t T = e->hdr.max_total;
-    HIPCHK(hipMemcpy(e->post.det_boxes, boxes, T * 16, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(e->post.det_scores, scores, T * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(e->post.det_classes, classes, T * 4, hipMemcpyHostToDevice));
-    WzFrameDesc& d = e->h_desc[0][0];
+    HIPCHK(hipMemcpy(e->lanes[0].post.det_boxes, boxes, T * 16, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->lanes[0].post.det_scores, scores, T * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->lanes[0].post.det_classes, classes, T * 4, hipMemcpyHostToDevice));
+    WzFrameDesc& d = e->lanes[0].h_desc[0];
     memset(&d, 0, sizeof(d));
     d.w = w;
     d.h = h;
     d.cam = -1;
-    HIPCHK(hipMemcpyAsync(e->d_desc[0], e->h_desc[0], sizeof(WzFrameDesc), hipMemcpyHostToDevice, e->stream));
-    wz_launch_rows(e->post, e->d_desc[0], e->d_cams, 1, e->pc.max_total, e->d_rows[0], e->d_pass[0], e->stream);
+    HIPCHK(hipMemcpyAsync(e->lanes[0].d_desc, e->lanes[0].h_desc, sizeof(WzFrameDesc), hipMemcpyHostToDevice, e->stream));
+    wz_launch_rows(e->lanes[0].post, e->lanes[0].d_desc, e->d_cams, 1, e->pc.max_total, e->lanes[0].d_rows, e->lanes[0].d_pass, e->stream);
     HIPCHK(hipStreamSynchronize(e->stream));
-    HIPCHK(hipMemcpy(rows, e->d_rows[0], sizeof(wz_detection_t) * WZ_MAX_DETECTIONS, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(rows, e->lanes[0].d_rows, sizeof(wz_detection_t) * WZ_MAX_DETECTIONS, hipMemcpyDeviceToHost));
     return WZ_OK;
 }

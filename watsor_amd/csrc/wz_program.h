@@ -8,10 +8,10 @@
 #include <stdint.h>
 
 #define WZ_MAGIC 0x35335A57u /* "WZ35" */
-#define WZ_FORMAT_VERSION 3u
+#define WZ_FORMAT_VERSION 4u
 
 enum WzOpKind { WZ_OP_STEM = 1, WZ_OP_DW = 2, WZ_OP_CONV = 3 };
-enum WzOutMode { WZ_OUT_ACT = 0, WZ_OUT_BOX = 1, WZ_OUT_CLS = 2 };
+enum WzOutMode { WZ_OUT_ACT = 0, WZ_OUT_BOX = 1, WZ_OUT_CLS = 2, WZ_OUT_HEAD = 3 };
 enum WzAct { WZ_ACT_NONE = 0, WZ_ACT_RELU6 = 1 };
 
 #pragma pack(push, 1)
@@ -43,7 +43,8 @@ struct WzOpDesc {  // 192 bytes
     int32_t n_pad;                          // packed output columns (multiple of 32) for WZ_OP_CONV
     int32_t kc;                             // 32-channel K chunks per filter tap (ceil(cin/32))
     int64_t w_off, b_off;                   // byte offsets from weights_off
-    int32_t reserved[8];
+    int32_t n_box;                          // WZ_OUT_HEAD: leading columns that go to the box-encoding buffer
+    int32_t reserved[7];
     char name[64];
 };
 #pragma pack(pop)

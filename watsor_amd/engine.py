@@ -24,7 +24,7 @@ from . import arch
 from .anchors import ssd_anchor_table
 
 MAGIC = 0x35335A57
-FORMAT_VERSION = 3
+FORMAT_VERSION = 4
 BN_EPSILON = 1e-3          # watsor/test/model/prepare.py:48
 
 DEFAULT_POST = dict(max_total=100, max_per_class=100, score_threshold=1e-8, iou_threshold=0.6,
@@ -37,6 +37,11 @@ def _align(n: int, a: int = 256) -> int:
 
 def fold_batch_norm(W: Dict[str, np.ndarray], op: "arch.Op"):
     """(weights float64 in TF layout, bias float64[cout]) with BatchNorm folded in."""
+    if op.out_mode == arch.OUT_HEAD:                                     # [k,k,cin, a*4 | a*91], biases only
+        w = np.concatenate([W[op.scope + "/BoxEncodingPredictor/weights"], W[op.scope + "/ClassPredictor/weights"]],
+                           axis=3).astype(np.float64)
+        b = np.concatenate([W[op.scope + "/BoxEncodingPredictor/biases"], W[op.scope + "/ClassPredictor/biases"]])
+        return w, b.astype(np.float64)
     if op.kind == arch.OP_DW:
         w = W[op.scope + "/depthwise_weights"].astype(np.float64)        # [k,k,C,1]
     else:
@@ -154,7 +159,7 @@ def build_engine(weights: Dict[str, np.ndarray], precision: int = 16, model_widt
             op.hin, op.win, op.hout, op.wout,
             op.pad_t, op.pad_l, op.act, op.out_mode,
             op.anchor_offset, op.anchors_per_loc, n_pad, kc,
-            w_off, b_off, *([0] * 8), op.scope.encode()[:63]))
+            w_off, b_off, op.n_box, *([0] * 7), op.scope.encode()[:63]))
     assert all(len(r) == 192 for r in op_recs)
 
     tensor_recs = []

@@ -25,6 +25,13 @@ def synthetic_weights(seed: int = 1234, program: "arch.Program | None" = None) -
         return (rng.standard_normal(shape, dtype=np.float32) * np.float32(std)).astype(np.float32)
 
     for op in prog.ops:
+        if op.out_mode == arch.OUT_HEAD:
+            fan_in = op.k * op.k * op.cin
+            for sub, cols, gain, bias_mean, bias_std in (("BoxEncodingPredictor", op.n_box, 0.4, 0.0, 0.05),
+                                                         ("ClassPredictor", op.cout - op.n_box, 0.45, -4.6, 0.3)):
+                W["%s/%s/weights" % (op.scope, sub)] = normal((op.k, op.k, op.cin, cols), gain / math.sqrt(fan_in))
+                W["%s/%s/biases" % (op.scope, sub)] = (normal((cols,), bias_std) + np.float32(bias_mean)).astype(np.float32)
+            continue
         if op.kind == arch.OP_DW:
             fan_in = op.k * op.k
             W[op.scope + "/depthwise_weights"] = normal((op.k, op.k, op.cin, 1), math.sqrt(2.0 / fan_in))
