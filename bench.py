@@ -190,9 +190,11 @@ def main():
     d_frames = [eng.upload(f) for f in host_frames]
     ws, hs = [WIDTH] * BATCH, [HEIGHT] * BATCH
 
+    lanes = eng.num_slots
+
     def submit(step):
         b = step % ring
-        eng.submit_device(step % 4, d_frames[b * BATCH:(b + 1) * BATCH], ws, hs)
+        eng.submit_device(step % lanes, d_frames[b * BATCH:(b + 1) * BATCH], ws, hs)
 
     def barrier():
         # barrier + device synchronize on both sides of the timed region (eng.sync() = hipStreamSynchronize
@@ -222,9 +224,9 @@ def main():
     for s in range(min(args.steps, 50)):
         t1 = time.perf_counter()
         submit(s)
-        eng.wait(s % 4)
+        eng.wait(s % lanes)
         lat.append((time.perf_counter() - t1) * 1e3)
-    rows = eng.slot_rows((min(args.steps, 50) - 1) % 4, BATCH)
+    rows = eng.slot_rows((min(args.steps, 50) - 1) % lanes, BATCH)
     detections_per_frame = float((rows["confidence"] > 0).sum()) / BATCH
 
     out = None
@@ -246,7 +248,7 @@ def main():
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": "1 synthetic 640x480 RGB stream per GPU, batch=8 frames, SSD-MobileNet-v2 300x300 "
                                    "(seeded random-init weights), frames resident in HBM, rows copied back to host",
-                       "batch": BATCH, "frame": "%dx%d" % (WIDTH, HEIGHT), "parallelism": "replica-per-gpu x%d" % world,
+                       "batch": BATCH, "frame": "%dx%d" % (WIDTH, HEIGHT), "parallelism": "replica-per-gpu x%d" % world, "batches_in_flight": lanes,
                        "detections_per_frame": detections_per_frame},
             "roofline": roof,
         }

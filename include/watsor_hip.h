@@ -85,6 +85,7 @@ int wz_collect(wz_engine_t* e, int slot, wz_detection_t* const* out, uint8_t* co
 int wz_wait(wz_engine_t* e, int slot);
 const wz_detection_t* wz_slot_rows(wz_engine_t* e, int slot); /* pinned host, [n][100] */
 int wz_sync(wz_engine_t* e);
+int wz_num_slots(wz_engine_t* e);   /* lanes actually created (WZ_SLOTS unless WZ_LANES in the environment says fewer) */
 
 /* ---- per-camera filters on the GPU: ConfidenceFilter / AreaFilter / MaskFilter
  * (watsor/filter/confidence.py:10-19, area.py:10-26, mask.py:17-59).

@@ -528,6 +528,8 @@ extern "C" int wz_collect(wz_engine_t* e, int slot, wz_detection_t* const* out, 
     return WZ_OK;
 }
 
+extern "C" int wz_num_slots(wz_engine_t* e) { return e ? e->n_lanes : 0; }
+
 extern "C" int wz_sync(wz_engine_t* e) {
     if (!e) return wz_fail(WZ_EINVAL, "wz_sync: null engine");
     return sync_all(e);

@@ -40,6 +40,7 @@ class HipEngine:
         self.input_size = self._lib.wz_input_size(self._h)
         self.num_anchors = self._lib.wz_num_anchors(self._h)
         self.num_classes = self._lib.wz_num_classes(self._h)
+        self.num_slots = self._lib.wz_num_slots(self._h)
         self._dev_allocs: List[int] = []
 
     # -- lifecycle ------------------------------------------------------------------------------
