@@ -121,8 +121,6 @@ void wz_launch_dw(const half_t* in, const half_t* w, const float* bias, half_t* 
 // --------------------------------------------------------------------------------------------
 // implicit-GEMM convolution on MFMA.  Workgroup = 4 waves; wave = (MT*16 pixels) x (NT*16 channels).
 // --------------------------------------------------------------------------------------------
-#define CONV_MT 2
-#define CONV_NT 2
 
 __device__ __forceinline__ void wz_epilogue4(const WzConvArgs& a, int m, int n4, float4_t v) {
     // v = 4 consecutive output channels n4..n4+3 of output pixel m (bias not yet added)
@@ -164,29 +162,32 @@ __device__ __forceinline__ void wz_epilogue4(const WzConvArgs& a, int m, int n4,
     }
 }
 
-#define CONV_U 4   // K chunks (32 channels each) per register buffer; two buffers are in flight
-
+// Tile configuration: a wave computes (MT*16 pixels) x (NT*16 channels); U K-chunks (32 channels each)
+// per register buffer, two buffers in flight.
+//   <2,2,4>  small layers / small N: many waves, 1 KiB of loads per MFMA
+//   <4,4,2>  the 3x3 SSD heads (M >= 128, N >= 256, K in the thousands): 4x the L2->register reuse
+template <int MT, int NT, int U>
 struct ConvFrags {
-    half8_t xa[CONV_U][CONV_MT];
-    half8_t wf[CONV_U][CONV_NT];
+    half8_t xa[U][MT];
+    half8_t wf[U][NT];
 };
 
-// Issue the loads of the next CONV_U K-chunks (flattened index ql = tap * kc + c) into `f`.
+// Issue the loads of the next U K-chunks (flattened index ql = tap * kc + c) into `f`.
 // (t, c) walk the chunk order; chunks at or beyond q1 load nothing and contribute zeros.
-template <int KS>
-__device__ __forceinline__ void wz_conv_load(const WzConvArgs& a, ConvFrags& f, int& ql, const int q1, int& t,
-                                             int& c, const int (&iy0)[CONV_MT], const int (&ix0)[CONV_MT],
-                                             const int (&boff)[CONV_MT], const bool (&mv)[CONV_MT],
+template <int KS, int MT, int NT, int U>
+__device__ __forceinline__ void wz_conv_load(const WzConvArgs& a, ConvFrags<MT, NT, U>& f, int& ql, const int q1, int& t,
+                                             int& c, const int (&iy0)[MT], const int (&ix0)[MT],
+                                             const int (&boff)[MT], const bool (&mv)[MT],
                                              const half_t* wlane, const int nt0, const int cg8) {
     constexpr int taps = KS * KS;
     const half8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int u = 0; u < CONV_U; ++u) {
+    for (int u = 0; u < U; ++u) {
         const bool live = ql < q1;   // wave-uniform
         const int ky = (KS == 1) ? 0 : t / KS, kx = (KS == 1) ? 0 : t - ky * KS;
         const bool cin_ok = (c * 32 + cg8) < a.cin;
 #pragma unroll
-        for (int mt = 0; mt < CONV_MT; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
             const int iy = iy0[mt] + ky, ix = ix0[mt] + kx;
             const bool ok = live && cin_ok && mv[mt] && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
             f.xa[u][mt] = ok ? *reinterpret_cast<const half8_t*>(
@@ -194,7 +195,7 @@ __device__ __forceinline__ void wz_conv_load(const WzConvArgs& a, ConvFrags& f, 
                              : zero;
         }
 #pragma unroll
-        for (int nt = 0; nt < CONV_NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
             f.wf[u][nt] = live ? *reinterpret_cast<const half8_t*>(
                                      wlane + ((size_t)((nt0 + nt) * taps + t) * a.kc + c) * 512)
                                : zero;
@@ -206,30 +207,31 @@ __device__ __forceinline__ void wz_conv_load(const WzConvArgs& a, ConvFrags& f, 
     }
 }
 
-__device__ __forceinline__ void wz_conv_mfma(const ConvFrags& f, float4_t (&acc)[CONV_MT][CONV_NT]) {
+template <int MT, int NT, int U>
+__device__ __forceinline__ void wz_conv_mfma(const ConvFrags<MT, NT, U>& f, float4_t (&acc)[MT][NT]) {
 #pragma unroll
-    for (int u = 0; u < CONV_U; ++u)
+    for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int mt = 0; mt < CONV_MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < CONV_NT; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f.wf[u][nt], f.xa[u][mt], acc[mt][nt], 0, 0, 0);
 }
 
-template <int KS>
+template <int KS, int MT, int NT, int U>
 __global__ __launch_bounds__(256) void wz_k_conv(const WzConvArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
-    const int m_base = (blockIdx.x * 4 + wave) * (CONV_MT * 16);
-    const int nt0 = blockIdx.y * CONV_NT;
+    const int m_base = (blockIdx.x * 4 + wave) * (MT * 16);
+    const int nt0 = blockIdx.y * NT;
     if (m_base >= a.M) return;   // whole wave out of range (no barriers in this kernel)
 
     const int hw = a.hout * a.wout;
-    int iy0[CONV_MT], ix0[CONV_MT], boff[CONV_MT];
-    bool mv[CONV_MT];
+    int iy0[MT], ix0[MT], boff[MT];
+    bool mv[MT];
 #pragma unroll
-    for (int mt = 0; mt < CONV_MT; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
         const int m = m_base + mt * 16 + r16;
         mv[mt] = m < a.M;
         const int mm = mv[mt] ? m : 0;
@@ -240,11 +242,11 @@ __global__ __launch_bounds__(256) void wz_k_conv(const WzConvArgs a) {
         boff[mt] = b * a.hin;
     }
 
-    float4_t acc[CONV_MT][CONV_NT];
+    float4_t acc[MT][NT];
 #pragma unroll
-    for (int mt = 0; mt < CONV_MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < CONV_NT; ++nt) acc[mt][nt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
     // K range of this split (flattened chunk index q = tap * kc + c)
     const int per = (a.kchunks + a.splitk - 1) / a.splitk;
@@ -255,24 +257,24 @@ __global__ __launch_bounds__(256) void wz_k_conv(const WzConvArgs a) {
 
     // software pipeline: while the MFMAs of one register buffer run, the loads of the other are in flight
     int ql = q0, t = (KS == 1) ? 0 : q0 / a.kc, c = (KS == 1) ? q0 : q0 - t * a.kc;
-    ConvFrags fa, fb;
-    wz_conv_load<KS>(a, fa, ql, q1, t, c, iy0, ix0, boff, mv, wlane, nt0, cg8);
+    ConvFrags<MT, NT, U> fa, fb;
+    wz_conv_load<KS, MT, NT, U>(a, fa, ql, q1, t, c, iy0, ix0, boff, mv, wlane, nt0, cg8);
     for (int q = q0; q < q1;) {
-        wz_conv_load<KS>(a, fb, ql, q1, t, c, iy0, ix0, boff, mv, wlane, nt0, cg8);
+        wz_conv_load<KS, MT, NT, U>(a, fb, ql, q1, t, c, iy0, ix0, boff, mv, wlane, nt0, cg8);
         wz_conv_mfma(fa, acc);
-        q += CONV_U;
+        q += U;
         if (q >= q1) break;
-        wz_conv_load<KS>(a, fa, ql, q1, t, c, iy0, ix0, boff, mv, wlane, nt0, cg8);
+        wz_conv_load<KS, MT, NT, U>(a, fa, ql, q1, t, c, iy0, ix0, boff, mv, wlane, nt0, cg8);
         wz_conv_mfma(fb, acc);
-        q += CONV_U;
+        q += U;
     }
 
     // D layout: lane holds rows (n) g*4..g*4+3 of column (m) r16
 #pragma unroll
-    for (int mt = 0; mt < CONV_MT; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
         const int m = m_base + mt * 16 + r16;
 #pragma unroll
-        for (int nt = 0; nt < CONV_NT; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
             const int n4 = (nt0 + nt) * 16 + g * 4;
             if (a.splitk > 1) {
                 if (m < a.M)
@@ -299,24 +301,37 @@ __global__ __launch_bounds__(256) void wz_k_splitk_reduce(const WzConvArgs a, co
     wz_epilogue4(a, m, n4, v);
 }
 
+static inline bool wz_conv_big(int M, int n_pad, int kchunks) { return n_pad % 64 == 0 && n_pad >= 256 && M >= 128 && kchunks >= 16; }
+
 int wz_choose_splitk(int M, int n_pad, int kchunks) {
-    // Enough waves to cover the 1024 SIMDs several times; only long K loops are worth splitting.
-    const long waves = (long)((M + CONV_MT * 16 - 1) / (CONV_MT * 16)) * (n_pad / (CONV_NT * 16));
-    if (kchunks < 32 || waves >= 4096) return 1;
-    int s = (int)(4096 / (waves > 0 ? waves : 1));
+    // Long K loops on few waves are latency-bound: split K until there is about one wave per SIMD
+    // (1024), keeping >= 8 chunks per split so the extra reduce launch stays amortised.
+    const bool big = wz_conv_big(M, n_pad, kchunks);
+    const int tm = big ? 64 : 32, tn = big ? 64 : 32;
+    const long waves = (long)((M + tm - 1) / tm) * (n_pad / tn);
+    if (kchunks < 32 || waves >= 1024) return 1;
+    int s = (int)(1024 / (waves > 0 ? waves : 1));
     const int max_by_k = kchunks / 8;
     if (s > max_by_k) s = max_by_k;
     if (s > 16) s = 16;
     return s < 1 ? 1 : s;
 }
 
-void wz_launch_conv(const WzConvArgs& a, hipStream_t s) {
-    const int mtiles = (a.M + CONV_MT * 16 - 1) / (CONV_MT * 16);
-    dim3 grid((mtiles + 3) / 4, a.n_pad / (CONV_NT * 16), a.splitk);
+template <int MT, int NT, int U>
+static void wz_launch_conv_cfg(const WzConvArgs& a, hipStream_t s) {
+    const int mtiles = (a.M + MT * 16 - 1) / (MT * 16);
+    dim3 grid((mtiles + 3) / 4, a.n_pad / (NT * 16), a.splitk);
     if (a.ksize == 1)
-        hipLaunchKernelGGL(wz_k_conv<1>, grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((wz_k_conv<1, MT, NT, U>), grid, dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL(wz_k_conv<3>, grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((wz_k_conv<3, MT, NT, U>), grid, dim3(256), 0, s, a);
+}
+
+void wz_launch_conv(const WzConvArgs& a, hipStream_t s) {
+    if (wz_conv_big(a.M, a.n_pad, a.kchunks))
+        wz_launch_conv_cfg<4, 4, 2>(a, s);
+    else
+        wz_launch_conv_cfg<2, 2, 4>(a, s);
 }
 
 void wz_launch_splitk_reduce(const WzConvArgs& a, const float* ws, hipStream_t s) {

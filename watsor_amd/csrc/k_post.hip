@@ -79,17 +79,18 @@ __global__ __launch_bounds__(256) void wz_k_hist(WzPostBuffers b, WzPostConsts k
         if (h[i]) atomicAdd(&b.hist[(size_t)f * WZ_HIST_BINS + i], h[i]);
 }
 
-// threshold bin: the largest b with (number of candidates in bins >= b) >= target, else 0.
+// threshold bin: the largest b < hi with (number of candidates in bins [b, hi)) >= target, else 0;
+// *total_out = candidates in bins [0, hi).
 // Called by every thread of the block (blockDim.x in {256, 1024}); `sh` = 64 uint32 of LDS scratch.
 // Thread t owns bins [t*per, (t+1)*per); suffix sums run across lanes (shuffles) and waves (LDS).
 __device__ int wz_threshold_bin(const uint32_t* __restrict__ ghist, uint32_t* sh, uint32_t target,
-                                uint32_t* total_out) {
+                                uint32_t* total_out, int hi = WZ_HIST_BINS) {
     const int nth = blockDim.x, per = WZ_HIST_BINS / nth;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = nth >> 6;
     uint32_t v[4] = {0, 0, 0, 0};
     uint32_t sum = 0;
     for (int i = 0; i < per; ++i) {
-        v[i] = ghist[tid * per + i];
+        v[i] = (tid * per + i < hi) ? ghist[tid * per + i] : 0u;   // bins >= hi are already consumed
         sum += v[i];
     }
     uint32_t s = sum;   // -> sum over lanes >= lane of this wave
@@ -187,7 +188,8 @@ struct NmsShared {   // carved from dynamic LDS, every member 16-byte aligned
     unsigned long long red[NMS_THREADS / 64];
     uint32_t hist[64];
     int32_t kept;
-    int32_t pad[3];
+    uint32_t ncand;
+    int32_t pad[2];
 };
 
 // wave 0: try to keep candidate (box, cls, score); returns new kept count (uniform across the wave)
@@ -216,155 +218,193 @@ __device__ __forceinline__ int wz_try_keep(NmsShared* S, int kept, const float4_
     return kept;
 }
 
-__global__ __launch_bounds__(NMS_THREADS) void wz_k_nms(WzPostBuffers b, WzPostConsts k) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    NmsShared* S = reinterpret_cast<NmsShared*>(smem);
-    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// One band = all candidates whose score bits fall in histogram bins [lo_bin, hi_bin), `cnt` of them in
+// S->keys (unsorted composites).  Sort, gather boxes, walk.  Returns the new kept count (block-uniform).
+__device__ int wz_nms_band(NmsShared* S, const WzPostBuffers& b, const WzPostConsts& k, int f, int cnt, int kept) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int A = k.num_anchors;
-
-    uint32_t total = 0;
-    const int thr_bin = wz_threshold_bin(b.hist + (size_t)f * WZ_HIST_BINS, S->hist, WZ_CAND_TARGET, &total);
-    const uint32_t cnt_raw = b.count[f];
-    const bool overflow = cnt_raw > WZ_CAND_CAP;
-    const int cnt = overflow ? 0 : (int)cnt_raw;
-
-    int kept = 0;
-    if (cnt > 0) {
-        unsigned long long* sorted = S->keys;
-        if (cnt <= NMS_RANK_MAX) {
-            // rank sort: keys are unique (the tie index is), so rank = #larger keys is a permutation.
-            // Every thread streams the whole list from LDS (same address per step = broadcast).
-            for (int i = tid; i < cnt; i += NMS_THREADS) {
-                const uint2 c = b.cand[(size_t)f * WZ_CAND_CAP + i];
-                S->keys[i] = ((unsigned long long)c.x << 32) | (unsigned long long)(0xFFFFFFFFu - c.y);
-            }
-            __syncthreads();
-            for (int i = tid; i < cnt; i += NMS_THREADS) {
-                const unsigned long long mine = S->keys[i];
-                int r = 0;
-                for (int j = 0; j < cnt; ++j) r += (S->keys[j] > mine) ? 1 : 0;
-                S->keys2[r] = mine;
-            }
-            __syncthreads();
-            sorted = S->keys2;
-        } else {
-            int npow = 64;
-            while (npow < cnt) npow <<= 1;
-            for (int i = tid; i < npow; i += NMS_THREADS) {
-                unsigned long long v = 0ull;
-                if (i < cnt) {
-                    const uint2 c = b.cand[(size_t)f * WZ_CAND_CAP + i];
-                    v = ((unsigned long long)c.x << 32) | (unsigned long long)(0xFFFFFFFFu - c.y);
-                }
-                S->keys[i] = v;
-            }
-            __syncthreads();
-            // bitonic sort, descending
-            for (int size = 2; size <= npow; size <<= 1) {
-                for (int stride = size >> 1; stride > 0; stride >>= 1) {
-                    for (int i = tid; i < (npow >> 1); i += NMS_THREADS) {
-                        const int lo = 2 * i - (i & (stride - 1));
-                        const int hi = lo + stride;
-                        const bool desc = ((lo & size) == 0);
-                        const unsigned long long x = S->keys[lo], y = S->keys[hi];
-                        if ((x < y) == desc) { S->keys[lo] = y; S->keys[hi] = x; }
-                    }
-                    __syncthreads();
-                }
-            }
-        }
+    unsigned long long* sorted = S->keys;
+    if (cnt <= NMS_RANK_MAX) {
+        // rank sort: keys are unique (the tie index is), so rank = #larger keys is a permutation.
+        // Every thread streams the whole list from LDS (same address per step = broadcast).
         for (int i = tid; i < cnt; i += NMS_THREADS) {
-            const uint32_t tie = 0xFFFFFFFFu - (uint32_t)(sorted[i] & 0xFFFFFFFFull);
-            const int a = (int)(tie % (uint32_t)A);
-            S->sbox[i] = *reinterpret_cast<const float4_t*>(b.boxes + ((size_t)f * A + a) * 4);
+            const unsigned long long mine = S->keys[i];
+            int r = 0;
+            for (int j = 0; j < cnt; ++j) r += (S->keys[j] > mine) ? 1 : 0;
+            S->keys2[r] = mine;
         }
         __syncthreads();
-        if (wave == 0) {
-            // The kept list lives in registers (lane j holds entries j and j+64); candidates are
-            // pre-loaded 64 at a time, one per lane, and broadcast with v_readlane: no LDS round
-            // trips on the serial chain.
-            float4_t kb0 = {0.f, 0.f, 0.f, 0.f}, kb1 = {0.f, 0.f, 0.f, 0.f};
-            int kc0 = -1, kc1 = -1;
-            float ks0 = 0.f, ks1 = 0.f;
-            const bool count_classes = k.max_per_class < k.max_total;
-            for (int base = 0; base < cnt && kept < k.max_total; base += 64) {
-                const int i = base + lane;
-                const unsigned long long comp = (i < cnt) ? sorted[i] : 0ull;
-                const float4_t cb = (i < cnt) ? S->sbox[i] : (float4_t){0.f, 0.f, 0.f, 0.f};
-                const int lim = min(64, cnt - base);
-                for (int tq = 0; tq < lim && kept < k.max_total; ++tq) {
-                    const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(comp >> 32), tq);
-                    const uint32_t tie = 0xFFFFFFFFu - (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)comp, tq);
-                    float4_t box;
-                    box[0] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb[0]), tq));
-                    box[1] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb[1]), tq));
-                    box[2] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb[2]), tq));
-                    box[3] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb[3]), tq));
-                    const int cls = (int)(tie / (uint32_t)A);
-                    const bool sup = (kc0 == cls && wz_iou(box, kb0) > k.iou_thr) ||
-                                     (kc1 == cls && wz_iou(box, kb1) > k.iou_thr);
-                    bool ok = !__any(sup);
-                    if (ok && count_classes) {
-                        int same = (kc0 == cls ? 1 : 0) + (kc1 == cls ? 1 : 0);
+        sorted = S->keys2;
+    } else {
+        int npow = 64;
+        while (npow < cnt) npow <<= 1;
+        for (int i = cnt + tid; i < npow; i += NMS_THREADS) S->keys[i] = 0ull;
+        __syncthreads();
+        for (int size = 2; size <= npow; size <<= 1) {   // bitonic network, descending
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int i = tid; i < (npow >> 1); i += NMS_THREADS) {
+                    const int lo = 2 * i - (i & (stride - 1));
+                    const int hi = lo + stride;
+                    const bool desc = ((lo & size) == 0);
+                    const unsigned long long x = S->keys[lo], y = S->keys[hi];
+                    if ((x < y) == desc) { S->keys[lo] = y; S->keys[hi] = x; }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    for (int i = tid; i < cnt; i += NMS_THREADS) {
+        const uint32_t tie = 0xFFFFFFFFu - (uint32_t)(sorted[i] & 0xFFFFFFFFull);
+        const int a = (int)(tie % (uint32_t)A);
+        S->sbox[i] = *reinterpret_cast<const float4_t*>(b.boxes + ((size_t)f * A + a) * 4);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        // The kept list lives in registers during the walk (lane j holds entries j and j+64);
+        // candidates are pre-loaded 64 at a time, one per lane, and broadcast with v_readlane:
+        // no LDS round trips on the serial chain.
+        const float4_t z4 = {0.f, 0.f, 0.f, 0.f};
+        float4_t kb0 = lane < kept ? S->kbox[lane] : z4, kb1 = lane + 64 < kept ? S->kbox[lane + 64] : z4;
+        int kc0 = lane < kept ? S->kcls[lane] : -1, kc1 = lane + 64 < kept ? S->kcls[lane + 64] : -1;
+        float ks0 = lane < kept ? S->kscore[lane] : 0.f, ks1 = lane + 64 < kept ? S->kscore[lane + 64] : 0.f;
+        const bool count_classes = k.max_per_class < k.max_total;
+        for (int base = 0; base < cnt && kept < k.max_total; base += 64) {
+            const int i = base + lane;
+            const unsigned long long comp = (i < cnt) ? sorted[i] : 0ull;
+            const float4_t cb = (i < cnt) ? S->sbox[i] : z4;
+            const int lim = min(64, cnt - base);
+            for (int tq = 0; tq < lim && kept < k.max_total; ++tq) {
+                const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(comp >> 32), tq);
+                const uint32_t tie = 0xFFFFFFFFu - (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)comp, tq);
+                float4_t box;
+                box[0] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb[0]), tq));
+                box[1] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb[1]), tq));
+                box[2] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb[2]), tq));
+                box[3] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb[3]), tq));
+                const int cls = (int)(tie / (uint32_t)A);
+                const bool sup = (kc0 == cls && wz_iou(box, kb0) > k.iou_thr) ||
+                                 (kc1 == cls && wz_iou(box, kb1) > k.iou_thr);
+                bool ok = !__any(sup);
+                if (ok && count_classes) {
+                    int same = (kc0 == cls ? 1 : 0) + (kc1 == cls ? 1 : 0);
 #pragma unroll
-                        for (int o = 32; o > 0; o >>= 1) same += __shfl_xor(same, o);
-                        ok = same < k.max_per_class;
+                    for (int o = 32; o > 0; o >>= 1) same += __shfl_xor(same, o);
+                    ok = same < k.max_per_class;
+                }
+                if (ok) {
+                    if (lane == (kept & 63)) {
+                        if (kept < 64) { kb0 = box; kc0 = cls; ks0 = __uint_as_float(key); }
+                        else { kb1 = box; kc1 = cls; ks1 = __uint_as_float(key); }
                     }
-                    if (ok) {
-                        if (lane == (kept & 63)) {
-                            if (kept < 64) { kb0 = box; kc0 = cls; ks0 = __uint_as_float(key); }
-                            else { kb1 = box; kc1 = cls; ks1 = __uint_as_float(key); }
-                        }
-                        ++kept;
-                    }
+                    ++kept;
                 }
             }
-            if (lane < kept) { S->kbox[lane] = kb0; S->kcls[lane] = kc0; S->kscore[lane] = ks0; }
-            if (lane + 64 < kept) { S->kbox[lane + 64] = kb1; S->kcls[lane + 64] = kc1; S->kscore[lane + 64] = ks1; }
+        }
+        if (lane < kept) { S->kbox[lane] = kb0; S->kcls[lane] = kc0; S->kscore[lane] = ks0; }
+        if (lane + 64 < kept) { S->kbox[lane + 64] = kb1; S->kcls[lane + 64] = kc1; S->kscore[lane + 64] = ks1; }
+        if (lane == 0) S->kept = kept;
+    }
+    __syncthreads();
+    return S->kept;
+}
+
+// A band too crowded for the LDS list (massive score ties): exact one-candidate-per-scan walk over
+// composites in [lower, upper).  Slow, only reachable with pathological inputs.
+__device__ int wz_nms_band_serial(NmsShared* S, const WzPostBuffers& b, const WzPostConsts& k, int f, int kept,
+                                  unsigned long long lower, unsigned long long upper) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int A = k.num_anchors, n_entries = A * k.num_classes;
+    unsigned long long bound = upper;
+    while (kept < k.max_total) {
+        unsigned long long best = 0ull;
+        for (int j = tid; j < n_entries; j += NMS_THREADS) {
+            uint32_t key, tie;
+            if (wz_candidate(b, k, f, j, key, tie)) {
+                const unsigned long long comp = ((unsigned long long)key << 32) | (0xFFFFFFFFu - tie);
+                if (comp < bound && comp >= lower && comp > best) best = comp;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(best, o);
+            if (other > best) best = other;
+        }
+        if (lane == 0) S->red[wave] = best;
+        __syncthreads();
+        best = 0ull;
+        for (int w = 0; w < NMS_THREADS / 64; ++w)
+            if (S->red[w] > best) best = S->red[w];
+        __syncthreads();
+        if (best == 0ull) break;
+        bound = best;
+        if (wave == 0) {
+            const uint32_t tie = 0xFFFFFFFFu - (uint32_t)(best & 0xFFFFFFFFull);
+            const int cls = (int)(tie / (uint32_t)A), a = (int)(tie % (uint32_t)A);
+            const float4_t box = *reinterpret_cast<const float4_t*>(b.boxes + ((size_t)f * A + a) * 4);
+            kept = wz_try_keep(S, kept, box, cls, __uint_as_float((uint32_t)(best >> 32)), k, lane);
             if (lane == 0) S->kept = kept;
         }
         __syncthreads();
         kept = S->kept;
     }
+    return kept;
+}
 
-    // exact continuation below the bound (rare): one best candidate per scan
-    const bool more = overflow ? (total > 0) : (total > (uint32_t)cnt);
-    if (kept < k.max_total && more) {
-        unsigned long long bound = overflow ? ~0ull : ((unsigned long long)((uint32_t)thr_bin << 20) << 32);
-        const int n_entries = A * k.num_classes;
-        while (kept < k.max_total) {
-            unsigned long long best = 0ull;
+__global__ __launch_bounds__(NMS_THREADS) void wz_k_nms(WzPostBuffers b, WzPostConsts k) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    NmsShared* S = reinterpret_cast<NmsShared*>(smem);
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int A = k.num_anchors;
+
+    // Bands of the score histogram, highest first.  Band 0 = bins [thr, 1024) was compacted by
+    // wz_k_compact; further bands (needed only when NMS suppresses so much that band 0 runs dry
+    // before max_total rows are kept) are collected here by one scan over the frame's candidates.
+    uint32_t total = 0;
+    int lo_bin = wz_threshold_bin(b.hist + (size_t)f * WZ_HIST_BINS, S->hist, WZ_CAND_TARGET, &total);
+    int hi_bin = WZ_HIST_BINS;
+    uint32_t processed = 0;
+    int kept = 0;
+    if (tid == 0) S->kept = 0;
+    bool first = true;
+    while (total > 0) {
+        uint32_t cnt_raw;
+        if (first) {
+            cnt_raw = b.count[f];
+            for (int i = tid; i < (int)min(cnt_raw, (uint32_t)WZ_CAND_CAP); i += NMS_THREADS) {
+                const uint2 c = b.cand[(size_t)f * WZ_CAND_CAP + i];
+                S->keys[i] = ((unsigned long long)c.x << 32) | (unsigned long long)(0xFFFFFFFFu - c.y);
+            }
+        } else {
+            if (tid == 0) S->ncand = 0;
+            __syncthreads();
+            const int n_entries = A * k.num_classes;
             for (int j = tid; j < n_entries; j += NMS_THREADS) {
                 uint32_t key, tie;
                 if (wz_candidate(b, k, f, j, key, tie)) {
-                    const unsigned long long comp = ((unsigned long long)key << 32) | (0xFFFFFFFFu - tie);
-                    if (comp < bound && comp > best) best = comp;
+                    const int bin = (int)(key >> 20);
+                    if (bin >= lo_bin && bin < hi_bin) {
+                        const uint32_t pos = atomicAdd(&S->ncand, 1u);
+                        if (pos < WZ_CAND_CAP)
+                            S->keys[pos] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - tie);
+                    }
                 }
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const unsigned long long other = __shfl_xor(best, o);
-                if (other > best) best = other;
-            }
-            if (lane == 0) S->red[wave] = best;
             __syncthreads();
-            best = 0ull;
-            for (int w = 0; w < NMS_THREADS / 64; ++w)
-                if (S->red[w] > best) best = S->red[w];
-            __syncthreads();
-            if (best == 0ull) break;
-            bound = best;
-            if (wave == 0) {
-                const uint32_t tie = 0xFFFFFFFFu - (uint32_t)(best & 0xFFFFFFFFull);
-                const int cls = (int)(tie / (uint32_t)A), a = (int)(tie % (uint32_t)A);
-                const float4_t box = *reinterpret_cast<const float4_t*>(b.boxes + ((size_t)f * A + a) * 4);
-                kept = wz_try_keep(S, kept, box, cls, __uint_as_float((uint32_t)(best >> 32)), k, lane);
-                if (lane == 0) S->kept = kept;
-            }
-            __syncthreads();
-            kept = S->kept;
+            cnt_raw = S->ncand;
         }
+        __syncthreads();
+        if (cnt_raw > WZ_CAND_CAP)
+            kept = wz_nms_band_serial(S, b, k, f, kept, (unsigned long long)((uint32_t)lo_bin << 20) << 32,
+                                      (unsigned long long)((uint32_t)hi_bin << 20) << 32);
+        else if (cnt_raw > 0)
+            kept = wz_nms_band(S, b, k, f, (int)cnt_raw, kept);
+        processed += cnt_raw;
+        if (kept >= k.max_total || processed >= total || lo_bin == 0) break;
+        hi_bin = lo_bin;
+        lo_bin = wz_threshold_bin(b.hist + (size_t)f * WZ_HIST_BINS, S->hist, WZ_CAND_TARGET, nullptr, hi_bin);
+        first = false;
     }
+    __syncthreads();
 
     // detection_boxes / scores / classes (+1 label offset on every row, zero padding included)
     for (int i = tid; i < k.max_total; i += NMS_THREADS) {

@@ -70,7 +70,7 @@ int wz_choose_splitk(int M, int n_pad, int kchunks);
 
 #define WZ_HIST_BINS 1024
 #define WZ_CAND_CAP 4096
-#define WZ_CAND_TARGET 512
+#define WZ_CAND_TARGET 192
 struct WzPostBuffers {
     const float* box_enc;     // [n][A][4]
     const float* logits;      // [n][A][C]

@@ -145,7 +145,7 @@ def build_engine(weights: Dict[str, np.ndarray], precision: int = 16, model_widt
             w_off = put(w.reshape(9, op.cin).astype(np.float16))
             b_off = put(b.astype(np.float32))
         else:
-            n_pad = _align(op.cout, 32)
+            n_pad = _align(op.cout, 64 if op.cout >= 256 else 32)   # 64-wide wave tiles for the wide layers
             kc = (op.cin + 31) // 32
             w_off = put(pack_conv_weights(w.astype(np.float32), n_pad, kc))
             bp = np.zeros(n_pad, np.float32)
