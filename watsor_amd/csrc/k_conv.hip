@@ -301,7 +301,9 @@ __global__ __launch_bounds__(256) void wz_k_splitk_reduce(const WzConvArgs a, co
     wz_epilogue4(a, m, n4, v);
 }
 
-static inline bool wz_conv_big(int M, int n_pad, int kchunks) { return n_pad % 64 == 0 && n_pad >= 256 && M >= 128 && kchunks >= 16; }
+// measured (profiles/): the 64x64 tile wins only where M is large enough to keep >= 1 wave per SIMD
+// busy through a long K loop (BoxPredictor_0: M = n*361); at M = n*100 it is latency-bound and loses.
+static inline bool wz_conv_big(int M, int n_pad, int kchunks) { return n_pad % 64 == 0 && n_pad >= 256 && M >= 2048 && kchunks >= 64; }
 
 int wz_choose_splitk(int M, int n_pad, int kchunks) {
     // Long K loops on few waves are latency-bound: split K until there is about one wave per SIMD

@@ -174,6 +174,38 @@ __device__ __forceinline__ float wz_iou(const float4_t a, const float4_t c) {
     return inter / (area_i + area_j - inter);
 }
 
+// Exact, division-free form of `IOU(i, j) > thr` for boxes already normalised to (ymin,xmin,ymax,xmax)
+// with their areas precomputed.  TF evaluates q = RN_f32(inter / uni) > thr.  With m = the midpoint
+// between thr and the next float above it, q > thr  <=>  inter/uni > m, or inter/uni == m when
+// round-to-nearest-even resolves the tie upward (thr's mantissa odd).  inter, uni are floats and m has
+// 25 significant bits, so m * uni is exact in double and the comparison is exact.
+struct WzIouThr {
+    double mid;
+    bool tie_up;
+};
+__device__ __forceinline__ WzIouThr wz_iou_thr(float thr) {
+    WzIouThr t;
+    const float up = __uint_as_float(__float_as_uint(thr) + 1u);   // thr >= 0
+    t.mid = ((double)thr + (double)up) * 0.5;
+    t.tie_up = (__float_as_uint(thr) & 1u) != 0u;
+    return t;
+}
+__device__ __forceinline__ bool wz_iou_exceeds(const float4_t a, float area_a, const float4_t c, float area_c,
+                                               const WzIouThr t) {
+    if (area_a <= 0.0f || area_c <= 0.0f) return false;   // IOU() returns 0 and thr >= 0
+    const float iy0 = fmaxf(a[0], c[0]), ix0 = fmaxf(a[1], c[1]);
+    const float iy1 = fminf(a[2], c[2]), ix1 = fminf(a[3], c[3]);
+    const float inter = fmaxf(iy1 - iy0, 0.0f) * fmaxf(ix1 - ix0, 0.0f);
+    const float uni = area_a + area_c - inter;
+    const double lhs = (double)inter, rhs = t.mid * (double)uni;
+    return lhs > rhs || (t.tie_up && lhs == rhs);
+}
+__device__ __forceinline__ float4_t wz_norm_box(const float4_t b, float& area) {
+    const float4_t n = {fminf(b[0], b[2]), fminf(b[1], b[3]), fmaxf(b[0], b[2]), fmaxf(b[1], b[3])};
+    area = (n[2] - n[0]) * (n[3] - n[1]);
+    return n;
+}
+
 #define NMS_THREADS 1024
 #define NMS_KEEP_MAX 128   // >= max_total (100)
 #define NMS_RANK_MAX 1536  // up to here an O(n^2/threads) rank sort beats the barrier-bound bitonic network
@@ -264,7 +296,10 @@ __device__ int wz_nms_band(NmsShared* S, const WzPostBuffers& b, const WzPostCon
         // candidates are pre-loaded 64 at a time, one per lane, and broadcast with v_readlane:
         // no LDS round trips on the serial chain.
         const float4_t z4 = {0.f, 0.f, 0.f, 0.f};
+        const WzIouThr ithr = wz_iou_thr(k.iou_thr);
         float4_t kb0 = lane < kept ? S->kbox[lane] : z4, kb1 = lane + 64 < kept ? S->kbox[lane + 64] : z4;
+        float ka0, ka1;                                   // normalised corners + areas of the kept boxes
+        float4_t kn0 = wz_norm_box(kb0, ka0), kn1 = wz_norm_box(kb1, ka1);
         int kc0 = lane < kept ? S->kcls[lane] : -1, kc1 = lane + 64 < kept ? S->kcls[lane + 64] : -1;
         float ks0 = lane < kept ? S->kscore[lane] : 0.f, ks1 = lane + 64 < kept ? S->kscore[lane + 64] : 0.f;
         const bool count_classes = k.max_per_class < k.max_total;
@@ -282,8 +317,10 @@ __device__ int wz_nms_band(NmsShared* S, const WzPostBuffers& b, const WzPostCon
                 box[2] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb[2]), tq));
                 box[3] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb[3]), tq));
                 const int cls = (int)(tie / (uint32_t)A);
-                const bool sup = (kc0 == cls && wz_iou(box, kb0) > k.iou_thr) ||
-                                 (kc1 == cls && wz_iou(box, kb1) > k.iou_thr);
+                float barea;
+                const float4_t bn = wz_norm_box(box, barea);
+                bool sup = kc0 == cls && wz_iou_exceeds(bn, barea, kn0, ka0, ithr);
+                if (kept > 64) sup = sup || (kc1 == cls && wz_iou_exceeds(bn, barea, kn1, ka1, ithr));
                 bool ok = !__any(sup);
                 if (ok && count_classes) {
                     int same = (kc0 == cls ? 1 : 0) + (kc1 == cls ? 1 : 0);
@@ -293,8 +330,8 @@ __device__ int wz_nms_band(NmsShared* S, const WzPostBuffers& b, const WzPostCon
                 }
                 if (ok) {
                     if (lane == (kept & 63)) {
-                        if (kept < 64) { kb0 = box; kc0 = cls; ks0 = __uint_as_float(key); }
-                        else { kb1 = box; kc1 = cls; ks1 = __uint_as_float(key); }
+                        if (kept < 64) { kb0 = box; kn0 = bn; ka0 = barea; kc0 = cls; ks0 = __uint_as_float(key); }
+                        else { kb1 = box; kn1 = bn; ka1 = barea; kc1 = cls; ks1 = __uint_as_float(key); }
                     }
                     ++kept;
                 }
