@@ -136,6 +136,38 @@ def cpu_baseline(weights, frames, budget_s=12.0):
                        "%.1f s" % (done, WIDTH, HEIGHT, dt))
 
 
+class _StubEngine:
+    """GPU-less stand-in used only by --dry-run: same surface as HipEngine, a step is a 2 ms sleep."""
+    num_slots = 2
+    input_size = 300
+    device_name = "stub"
+
+    def __init__(self, *a, **k):
+        self._busy = {}
+
+    def upload(self, arr):
+        return 1
+
+    def submit_device(self, slot, d, ws, hs, cams=None):
+        self.wait(slot)
+        self._busy[slot] = time.perf_counter() + 0.002
+
+    def wait(self, slot):
+        t = self._busy.get(slot, 0) - time.perf_counter()
+        if t > 0:
+            time.sleep(t)
+
+    def sync(self):
+        for s in list(self._busy):
+            self.wait(s)
+
+    def slot_rows(self, slot, n):
+        return np.zeros((n, 100), dtype=[("confidence", "<f8")])
+
+    def close(self):
+        pass
+
+
 T_START = time.perf_counter()
 
 
@@ -151,6 +183,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--table", default=None, help="write the per-kernel roofline table (JSON) here")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="harness self-test without a GPU: a stub engine that sleeps 2 ms per step (used by the "
+                         "world_size-2 gloo test; its output is marked invalid)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -162,11 +197,14 @@ def main():
     # process.  torch is used for its CPU side only: the rendezvous/barrier/max-over-ranks (gloo -- the
     # path has no data-path collective) and the oracle's conv2d in the cpu_baseline leg.
     from watsor_amd import engine as builder
-    from watsor_amd.runtime import HipEngine
     from watsor_amd.synth import synthetic_frame, synthetic_weights
-    from watsor_amd import _lib
-    _lib.load()
-    note("library loaded")
+    if args.dry_run:
+        HipEngine = _StubEngine
+    else:
+        from watsor_amd.runtime import HipEngine
+        from watsor_amd import _lib
+        _lib.load()
+        note("library loaded")
 
     dist = None
     if world > 1:
@@ -175,18 +213,24 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
         note("process group up (gloo)")
 
-    weights = synthetic_weights(1234)
     model_dir = "/tmp/wz_bench_%d_%d" % (os.getpid(), rank)
     os.makedirs(model_dir, exist_ok=True)
     engine_path = os.path.join(model_dir, "mi355x.bin")
-    builder.save_engine(builder.build_engine(weights), engine_path)
+    if args.dry_run:
+        weights = None
+        open(engine_path, "wb").close()
+    else:
+        weights = synthetic_weights(1234)
+        builder.save_engine(builder.build_engine(weights), engine_path)
 
     note("engine file built")
     eng = HipEngine(engine_path, local_rank, BATCH, WIDTH, HEIGHT)
     note("engine created on " + eng.device_name)
     # camera `rank`: a ring of 4 batches of distinct frames, pre-staged in HBM
     ring = 4
-    host_frames = [synthetic_frame(WIDTH, HEIGHT, 1234 + rank * 1000 + i) for i in range(ring * BATCH)]
+    host_frames = [synthetic_frame(WIDTH, HEIGHT, 1234 + rank * 1000 + i) for i in range(ring * BATCH if not args.dry_run else 2)]
+    if args.dry_run:
+        host_frames = (host_frames * (ring * BATCH))[:ring * BATCH]
     d_frames = [eng.upload(f) for f in host_frames]
     ws, hs = [WIDTH] * BATCH, [HEIGHT] * BATCH
 
@@ -230,7 +274,14 @@ def main():
     detections_per_frame = float((rows["confidence"] > 0).sum()) / BATCH
 
     out = None
-    if rank == 0:
+    if rank == 0 and args.dry_run:
+        out = {"metric": "DRY RUN (stub engine, no GPU) -- invalid as a measurement",
+               "value": round(args.steps * BATCH * world / elapsed, 2), "unit": "frames/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none",
+               "data": "synthetic", "config": {"workload": "dry-run"},
+               "camera_seeds": [1234 + r * 1000 for r in range(world)]}
+    elif rank == 0:
         note("latency loop done")
         stages = eng.profile_device(d_frames[:BATCH], ws, hs, reps=20)
         note("stage profile done")

@@ -1,0 +1,34 @@
+"""bench.py's multi-process path (N > 1): rendezvous, barrier, max-over-ranks timing and the whole-job
+aggregate -- world_size 2 over gloo on CPU, with the stub engine of `--dry-run` (no GPU here)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(cmd):
+    env = dict(os.environ, WZ_BENCH_VERBOSE="0", MASTER_ADDR="127.0.0.1")
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout          # exactly ONE JSON line, printed by rank 0 only
+    return json.loads(lines[0])
+
+
+def test_single_process_dry_run():
+    out = run([sys.executable, "bench.py", "--gpus", "1", "--steps", "40", "--warmup", "4", "--dry-run"])
+    assert out["n_gpus"] == 1 and out["steps"] == 40 and out["scaling"] == "weak"
+    assert 1500 < out["value"] < 8100                 # 8 frames per 2 ms step, two stub lanes in flight
+
+
+def test_two_ranks_over_gloo():
+    port = 29500 + os.getpid() % 400
+    out = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "40",
+               "--warmup", "4", "--dry-run"])
+    assert out["n_gpus"] == 2
+    assert out["camera_seeds"] == [1234, 2234]        # every rank serves its own camera (cameras are the shard)
+    single = run([sys.executable, "bench.py", "--gpus", "1", "--steps", "40", "--warmup", "4", "--dry-run"])
+    assert 1.5 < out["value"] / single["value"] < 2.5   # whole-job aggregate = frames of all ranks / max time

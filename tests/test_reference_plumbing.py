@@ -1,0 +1,195 @@
+"""BASELINE config 1 ("plumbing, no GPU"): detector plugins under the UNMODIFIED reference worker.
+
+Mirrors `watsor/test/test_detect.py:28-77`: a frame source (the reference's `ReadDetectPublish`, like its
+`Artist` fixture) -> shared-memory `FrameBuffer` -> `ObjectDetector` worker (`detector.py:58-112`) ->
+`DetectionSieve` with a `ConfidenceFilter` -> a counting sink.  Like the reference test it asserts
+liveness / counts, plus that the rows in shared memory are exactly what the plugin wrote.
+
+Needs /root/reference on the path (build container only).
+"""
+import time
+from queue import Empty
+from threading import Thread
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.reference
+
+
+class FakeBatchDetector:
+    """Plugin-protocol detector that needs no model: row d of a frame carries the frame's first pixel."""
+    max_batch = 4
+    calls = []
+
+    def __init__(self, model_path, device=0):
+        self.model_path = model_path
+
+    @property
+    def device_name(self):
+        return "fake"
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        pass
+
+    def _fill(self, image_np, detections):
+        detections[0].label = 1
+        detections[0].confidence = 0.9
+        detections[0].bounding_box.x_min = int(image_np.reshape(-1)[0])
+        detections[0].bounding_box.x_max = 10
+
+    def detect(self, image_shape, image_np, detections):
+        FakeBatchDetector.calls.append(1)
+        self._fill(image_np, detections)
+        return 1.0
+
+    def detect_batch(self, shapes, images, detections):
+        FakeBatchDetector.calls.append(len(images))
+        for im, d in zip(images, detections):
+            self._fill(im, d)
+        return 2.0
+
+
+def build_pipeline(reference_on_path, detector_factory, n_cameras, frame_fn, width=64, height=48, want=12):
+    from logging import getLogger
+    from logging.handlers import QueueHandler
+    from multiprocessing import Event, Queue
+
+    from watsor.filter.confidence import ConfidenceFilter
+    from watsor.filter.sieve import DetectionSieve
+    from watsor.filter.track import TrackFilter
+    from watsor.stream.log import LogHandler
+    from watsor.stream.read import ReadDetectPublish
+    from watsor.stream.share import FrameBuffer, RateLimiter
+    from watsor.stream.sync import CountDownLatch
+    from watsor.stream.work import WorkPublish
+    from watsor_amd.coco import COCO_CLASSES
+
+    class Source(ReadDetectPublish):                    # the role of the reference's `Artist`
+        def __init__(self, name, stop_event, log_queue, frame_queue, frame_buffer):
+            super().__init__(name, stop_event, log_queue, frame_queue, frame_buffer, args=(stop_event,))
+            self.count = 0
+
+        def _new_frame(self, frame, *args, **kwargs):
+            frame.clear()
+            img = frame_fn(self.name, self.count, frame.header.width, frame.header.height)
+            np.copyto(np.frombuffer(frame.image.get_obj(), np.uint8), img.reshape(-1))
+            frame.header.epoch = time.time()
+            self.count += 1
+            time.sleep(0.005)
+            return True
+
+    class Sink(WorkPublish):                            # the role of `ShapeCounter`
+        def __init__(self, name, stop_event, log_queue, frame_queue, frame_buffer, latch, seen):
+            super().__init__(Thread, name, stop_event, log_queue, frame_queue, frame_buffer, args=(latch, seen))
+
+        def _new_frame(self, frame, payload, stop_event, frame_buffer, latch, seen, *args, **kwargs):
+            try:
+                d = frame.header.detections[0]
+                if d.label > 0:
+                    seen.append((d.label, d.confidence, d.bounding_box.x_min, int(np.frombuffer(
+                        frame.image.get_obj(), np.uint8)[0])))
+                    latch.count_down()
+            finally:
+                frame.latch.next()
+
+    stop = Event()
+    log_queue = Queue()
+    getLogger().addHandler(QueueHandler(log_queue))
+    frame_queue = Queue(n_cameras)
+    latch = CountDownLatch(want)
+    seen = []
+    procs = [LogHandler(Thread, "logger", stop, log_queue, filename=None)]
+    buffers = {}
+    all_conf = {'detect': [{name: {'confidence': 5}} for name in COCO_CLASSES[1:]]}
+    for c in range(n_cameras):
+        name = "cam%d" % c
+        fb = FrameBuffer(10, width, height)
+        buffers[name] = fb
+        sieve_q, sink_q = Queue(1), Queue(1)
+        src = Source(name, stop, log_queue, frame_queue, fb)
+        sieve = DetectionSieve(name + "-sieve", stop, log_queue, sieve_q, fb,
+                               [TrackFilter([ConfidenceFilter(all_conf)], 1, 1)], RateLimiter())
+        sink = Sink(name + "-sink", stop, log_queue, sink_q, fb, latch, seen)
+        src.subscribe(sieve_q)
+        sieve.subscribe(sink_q)
+        procs += [src, sieve, sink]
+    procs += detector_factory(stop, log_queue, frame_queue, buffers)
+    return stop, latch, seen, procs
+
+
+def run(stop, latch, procs, timeout):
+    for p in procs:
+        p.start()
+    try:
+        return latch.wait(timeout)
+    finally:
+        stop.set()
+        for p in procs:
+            p.join(30)
+
+
+def test_oracle_detector_under_unmodified_reference_worker(reference_on_path, synth_weights, tmp_path):
+    """Config 1: the CPU restatement of the TF detector plugged into watsor's own ObjectDetector."""
+    from watsor.detection.detector import ObjectDetector
+    from oracle.detect import OracleObjectDetector
+    from watsor_amd.synth import synthetic_frame
+    np.savez(tmp_path / "oracle.npz", **synth_weights)
+    frames = {}
+
+    def frame_fn(cam, i, w, h):
+        f = synthetic_frame(w, h, 77 + i % 3)
+        frames[i % 3] = f
+        return f
+
+    def factory(stop, log_queue, frame_queue, buffers):
+        return [ObjectDetector(Thread, "detector1", stop, log_queue, frame_queue, buffers,
+                               kwargs={'detector_class': OracleObjectDetector, 'detector_args': (str(tmp_path),)})]
+
+    stop, latch, seen, procs = build_pipeline(reference_on_path, factory, 1, frame_fn, 160, 120, want=3)
+    assert run(stop, latch, procs, 120) and len(seen) >= 3
+    det = procs[-1]
+    assert det.device_name == b"CPU"
+    # rows that reached the sink are rows the plugin computed for that very frame
+    oracle = OracleObjectDetector(weights=synth_weights)
+    from watsor_amd.share import DetectionArray
+    for label, conf, x_min, px0 in seen[:2]:
+        src = next(f for f in frames.values() if int(f.reshape(-1)[0]) == px0)
+        rows = DetectionArray()
+        oracle.detect(src.shape, src, rows)
+        # the sieve's TrackFilter regroups rows by label, so look the survivor up among the plugin's rows
+        assert any(r.label == label and abs(r.confidence - conf) < 1e-12 for r in rows), (label, conf)
+
+
+def test_batched_worker_one_latch_step_per_payload(reference_on_path, tmp_path):
+    """`BatchedObjectDetector`: several cameras on one queue, one detect_batch per drain, every frame released."""
+    from watsor_amd.detection.detector import BatchedObjectDetector
+    FakeBatchDetector.calls = []
+
+    def frame_fn(cam, i, w, h):
+        return np.full((h, w, 3), (int(cam[3:]) * 50 + i) % 256, np.uint8)
+
+    def factory(stop, log_queue, frame_queue, buffers):
+        return [BatchedObjectDetector(Thread, "detector1", stop, log_queue, frame_queue, buffers,
+                                      kwargs={'detector_class': FakeBatchDetector,
+                                              'detector_args': (str(tmp_path), 0)})]
+
+    stop, latch, seen, procs = build_pipeline(reference_on_path, factory, 3, frame_fn)
+    assert run(stop, latch, procs, 60)
+    assert len(seen) >= 12
+    for label, conf, x_min, px0 in seen:
+        assert label == 1 and x_min == px0            # the row belongs to the frame it sits behind
+    assert max(FakeBatchDetector.calls) > 1           # frames of several cameras really were batched
+    assert max(FakeBatchDetector.calls) <= FakeBatchDetector.max_batch
+    det = procs[-1]
+    assert det.fps() > 0 and det.inference_time() > 0
+
+
+def test_factory_defers_to_reference_when_no_engine_file(reference_on_path, tmp_path):
+    from multiprocessing import Event, Queue
+    from watsor_amd.detection import detector as d
+    with pytest.raises(AssertionError, match="Failed to create an object detector"):
+        d.create_object_detectors(Thread, Event(), Queue(), Queue(), {}, str(tmp_path))   # no TF here either
