@@ -127,6 +127,9 @@ int wz_stage_name(wz_engine_t* e, int stage, char* name, int namelen);
 int wz_profile_device(wz_engine_t* e, int n, const uint8_t* const* d_rgb, const int* w, const int* h,
                       int reps, float* stage_ms);
 
+/* diagnostics: 16 words per frame written by the NMS kernel of lane 0 (phase timestamps at 100 MHz, counts) */
+int wz_debug_nms(wz_engine_t* e, int n, uint64_t* out);
+
 /* ---- device memory helpers so callers need no other GPU runtime binding */
 int wz_dev_alloc(wz_engine_t* e, uint64_t bytes, void** d_ptr);
 int wz_dev_free(wz_engine_t* e, void* d_ptr);

@@ -285,12 +285,14 @@ __device__ int wz_nms_band(NmsShared* S, const WzPostBuffers& b, const WzPostCon
             }
         }
     }
+    if (tid == 0) b.dbg[(size_t)f * 16 + 5] = wall_clock64();
     for (int i = tid; i < cnt; i += NMS_THREADS) {
         const uint32_t tie = 0xFFFFFFFFu - (uint32_t)(sorted[i] & 0xFFFFFFFFull);
         const int a = (int)(tie % (uint32_t)A);
         S->sbox[i] = *reinterpret_cast<const float4_t*>(b.boxes + ((size_t)f * A + a) * 4);
     }
     __syncthreads();
+    if (tid == 0) b.dbg[(size_t)f * 16 + 6] = wall_clock64();
     if (wave == 0) {
         // The kept list lives in registers during the walk (lane j holds entries j and j+64);
         // candidates are pre-loaded 64 at a time, one per lane, and broadcast with v_readlane:
@@ -340,6 +342,7 @@ __device__ int wz_nms_band(NmsShared* S, const WzPostBuffers& b, const WzPostCon
         if (lane < kept) { S->kbox[lane] = kb0; S->kcls[lane] = kc0; S->kscore[lane] = ks0; }
         if (lane + 64 < kept) { S->kbox[lane + 64] = kb1; S->kcls[lane + 64] = kc1; S->kscore[lane + 64] = ks1; }
         if (lane == 0) S->kept = kept;
+        if (lane == 0) b.dbg[(size_t)f * 16 + 7] = wall_clock64();
     }
     __syncthreads();
     return S->kept;
@@ -396,8 +399,11 @@ __global__ __launch_bounds__(NMS_THREADS) void wz_k_nms(WzPostBuffers b, WzPostC
     // Bands of the score histogram, highest first.  Band 0 = bins [thr, 1024) was compacted by
     // wz_k_compact; further bands (needed only when NMS suppresses so much that band 0 runs dry
     // before max_total rows are kept) are collected here by one scan over the frame's candidates.
+#define NMS_STAMP(i) do { if (tid == 0) b.dbg[(size_t)f * 16 + (i)] = wall_clock64(); } while (0)
+    NMS_STAMP(0);
     uint32_t total = 0;
     int lo_bin = wz_threshold_bin(b.hist + (size_t)f * WZ_HIST_BINS, S->hist, WZ_CAND_TARGET, &total);
+    NMS_STAMP(1);
     int hi_bin = WZ_HIST_BINS;
     uint32_t processed = 0;
     int kept = 0;
@@ -430,12 +436,14 @@ __global__ __launch_bounds__(NMS_THREADS) void wz_k_nms(WzPostBuffers b, WzPostC
             cnt_raw = S->ncand;
         }
         __syncthreads();
+        if (first) NMS_STAMP(2);
         if (cnt_raw > WZ_CAND_CAP)
             kept = wz_nms_band_serial(S, b, k, f, kept, (unsigned long long)((uint32_t)lo_bin << 20) << 32,
                                       (unsigned long long)((uint32_t)hi_bin << 20) << 32);
         else if (cnt_raw > 0)
             kept = wz_nms_band(S, b, k, f, (int)cnt_raw, kept);
         processed += cnt_raw;
+        if (first) { NMS_STAMP(3); if (tid == 0) { b.dbg[(size_t)f * 16 + 8] = cnt_raw; b.dbg[(size_t)f * 16 + 9] = kept; } }
         if (kept >= k.max_total || processed >= total || lo_bin == 0) break;
         hi_bin = lo_bin;
         lo_bin = wz_threshold_bin(b.hist + (size_t)f * WZ_HIST_BINS, S->hist, WZ_CAND_TARGET, nullptr, hi_bin);
@@ -452,6 +460,8 @@ __global__ __launch_bounds__(NMS_THREADS) void wz_k_nms(WzPostBuffers b, WzPostC
         b.det_classes[(size_t)f * k.max_total + i] = (on ? S->kcls[i] : 0) + 1;
     }
     if (tid == 0) b.det_num[f] = kept;
+    NMS_STAMP(4);
+    if (tid == 0) b.dbg[(size_t)f * 16 + 10] = processed;
 }
 
 // ---------------------------------------------------------------------------------------------

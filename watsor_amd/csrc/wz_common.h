@@ -84,6 +84,7 @@ struct WzPostBuffers {
     float* det_scores;        // [n][100]
     int32_t* det_classes;     // [n][100] 1-based
     int32_t* det_num;         // [n]
+    unsigned long long* dbg;  // [n][16] phase timestamps of wz_k_nms (wall_clock64, 100 MHz), diagnostics only
 };
 void wz_launch_decode(const WzPostBuffers& b, const WzPostConsts& c, int n, hipStream_t s);
 void wz_launch_hist(const WzPostBuffers& b, const WzPostConsts& c, int n, hipStream_t s);

@@ -397,6 +397,8 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
         CK(hipMalloc((void**)&pb.det_scores, (size_t)max_batch * h.max_total * 4));
         CK(hipMalloc((void**)&pb.det_classes, (size_t)max_batch * h.max_total * 4));
         CK(hipMalloc((void**)&pb.det_num, (size_t)max_batch * 4));
+        CK(hipMalloc((void**)&pb.dbg, (size_t)max_batch * 16 * 8));
+        CK(hipMemset(pb.dbg, 0, (size_t)max_batch * 16 * 8));
         CK(hipHostMalloc((void**)&L.h_desc, sizeof(WzFrameDesc) * max_batch, hipHostMallocDefault));
         CK(hipMalloc((void**)&L.d_desc, sizeof(WzFrameDesc) * max_batch));
         CK(hipMalloc((void**)&L.d_rows, sizeof(wz_detection_t) * WZ_MAX_DETECTIONS * max_batch));
@@ -452,7 +454,7 @@ extern "C" void wz_destroy(wz_engine_t* e) {
         for (auto& kv : L.graphs) (void)hipGraphExecDestroy(kv.second);
         for (void* p : L.bufs) (void)hipFree(p);
         void* lp[] = {L.d_box_enc, L.d_logits, L.d_ws, L.post.boxes, L.post.valid, L.d_post_scratch, L.post.cand,
-                      L.post.det_boxes, L.post.det_scores, L.post.det_classes, L.post.det_num, L.d_desc, L.d_rows,
+                      L.post.det_boxes, L.post.det_scores, L.post.det_classes, L.post.det_num, L.post.dbg, L.d_desc, L.d_rows,
                       L.d_pass};
         for (void* p : lp)
             if (p) (void)hipFree(p);
@@ -656,6 +658,14 @@ extern "C" int wz_op_info(wz_engine_t* e, int idx, char* name, int namelen, int*
         const int v[12] = {o.kind, o.cin, o.cout, o.ksize, o.stride, o.hin, o.win, o.hout, o.wout, o.n_pad, o.kc, 0};
         memcpy(dims, v, sizeof(v));
     }
+    return WZ_OK;
+}
+
+extern "C" int wz_debug_nms(wz_engine_t* e, int n, uint64_t* out) {
+    if (!e || !out || n < 1 || n > e->max_batch) return wz_fail(WZ_EINVAL, "wz_debug_nms: bad argument");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(out, e->lanes[0].post.dbg, (size_t)n * 16 * 8, hipMemcpyDeviceToHost));
     return WZ_OK;
 }
 
