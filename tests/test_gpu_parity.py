@@ -229,3 +229,21 @@ def test_limits_and_errors(model_dir):
     with pytest.raises(FileNotFoundError):
         from watsor_amd.detection.hip_gpu import HipObjectDetector
         HipObjectDetector(os.path.join(model_dir, "nope"), 0)
+
+
+def test_postprocess_with_binding_per_class_cap(synth_weights, tmp_path, head_outputs):
+    """max_detections_per_class < max_total_detections: the per-class cap decides which rows survive."""
+    from watsor_amd import engine
+    engine.save_engine(engine.build_engine(synth_weights, post=dict(max_per_class=3)), str(tmp_path / "mi355x.bin"))
+    e = make_engine(str(tmp_path), max_batch=2)
+    try:
+        _, rbe, rlg, _ = head_outputs
+        B, S, C, N = e.stage_postprocess(rbe, rlg)
+        rB, rS, rC, rN = pu.oracle_postprocess(rbe, rlg, max_per_class=3)
+        np.testing.assert_array_equal(N, rN)
+        np.testing.assert_array_equal(C, rC)
+        np.testing.assert_allclose(S, rS, rtol=0, atol=1e-6)
+        np.testing.assert_allclose(B, rB, rtol=0, atol=2e-6)
+        assert np.bincount(C[0][:N[0]]).max() == 3
+    finally:
+        e.close()

@@ -129,7 +129,12 @@ __global__ __launch_bounds__(256) void wz_k_compact(WzPostBuffers b, WzPostConst
     __shared__ uint32_t s_cnt, s_base;
     const int f = blockIdx.y, total = k.num_anchors * k.num_classes;
     if (threadIdx.x == 0) s_cnt = 0;
-    const uint32_t thr = (uint32_t)wz_threshold_bin(b.hist + (size_t)f * WZ_HIST_BINS, sh, WZ_CAND_TARGET, nullptr);
+    uint32_t all = 0;
+    const uint32_t thr = (uint32_t)wz_threshold_bin(b.hist + (size_t)f * WZ_HIST_BINS, sh, WZ_CAND_TARGET, &all);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {   // every block computes the same band; one publishes it for wz_k_nms
+        b.band[2 * f] = thr;
+        b.band[2 * f + 1] = all;
+    }
     const int base = blockIdx.x * 256 * POST_ITEMS;
     uint32_t keys[POST_ITEMS], ties[POST_ITEMS], pos[POST_ITEMS];
     uint32_t mask = 0;
@@ -208,6 +213,7 @@ __device__ __forceinline__ float4_t wz_norm_box(const float4_t b, float& area) {
 
 #define NMS_THREADS 1024
 #define NMS_KEEP_MAX 128   // >= max_total (100)
+#define NMS_CHUNK 256     // candidates per parallel suppression pass (4 per lane of the scanning wave)
 #define NMS_RANK_MAX 1536  // up to here an O(n^2/threads) rank sort beats the barrier-bound bitonic network
 
 struct NmsShared {   // carved from dynamic LDS, every member 16-byte aligned
@@ -218,6 +224,15 @@ struct NmsShared {   // carved from dynamic LDS, every member 16-byte aligned
     float kscore[NMS_KEEP_MAX];
     int32_t kcls[NMS_KEEP_MAX];
     unsigned long long red[NMS_THREADS / 64];
+    // chunk state of the parallel suppression pass (NMS_CHUNK sorted candidates at a time)
+    unsigned long long supp[NMS_CHUNK][NMS_CHUNK / 64];   // supp[j] = mask of earlier chunk members i < j that suppress j
+    float4_t cnorm[NMS_CHUNK];                            // candidate boxes normalised to (ymin,xmin,ymax,xmax)
+    float4_t knorm[NMS_KEEP_MAX];                         // the same for the kept list
+    float carea[NMS_CHUNK];
+    float karea[NMS_KEEP_MAX];
+    int32_t ccls[NMS_CHUNK];
+    uint32_t cdead[NMS_CHUNK];                            // 1 = suppressed by a box kept in an earlier chunk / band
+    int32_t kidx[NMS_KEEP_MAX];                           // kept -> index into the sorted band
     uint32_t hist[64];
     int32_t kept;
     uint32_t ncand;
@@ -241,7 +256,10 @@ __device__ __forceinline__ int wz_try_keep(NmsShared* S, int kept, const float4_
     for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
     if (!any_sup && tot < k.max_per_class) {
         if (lane == 0) {
+            float ar;
             S->kbox[kept] = box;
+            S->knorm[kept] = wz_norm_box(box, ar);
+            S->karea[kept] = ar;
             S->kcls[kept] = cls;
             S->kscore[kept] = score;
         }
@@ -258,11 +276,20 @@ __device__ int wz_nms_band(NmsShared* S, const WzPostBuffers& b, const WzPostCon
     unsigned long long* sorted = S->keys;
     if (cnt <= NMS_RANK_MAX) {
         // rank sort: keys are unique (the tie index is), so rank = #larger keys is a permutation.
-        // Every thread streams the whole list from LDS (same address per step = broadcast).
+        // Every thread streams the whole list from LDS, 8 keys per step (same address = broadcast).
+        const int cnt8 = (cnt + 7) & ~7;
+        for (int i = cnt + tid; i < cnt8; i += NMS_THREADS) S->keys[i] = 0ull;   // 0 is never "larger"
+        __syncthreads();
         for (int i = tid; i < cnt; i += NMS_THREADS) {
             const unsigned long long mine = S->keys[i];
             int r = 0;
-            for (int j = 0; j < cnt; ++j) r += (S->keys[j] > mine) ? 1 : 0;
+            for (int j = 0; j < cnt8; j += 8) {
+                unsigned long long kk[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) kk[u] = S->keys[j + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) r += (kk[u] > mine) ? 1 : 0;
+            }
             S->keys2[r] = mine;
         }
         __syncthreads();
@@ -293,59 +320,98 @@ __device__ int wz_nms_band(NmsShared* S, const WzPostBuffers& b, const WzPostCon
     }
     __syncthreads();
     if (tid == 0) b.dbg[(size_t)f * 16 + 6] = wall_clock64();
-    if (wave == 0) {
-        // The kept list lives in registers during the walk (lane j holds entries j and j+64);
-        // candidates are pre-loaded 64 at a time, one per lane, and broadcast with v_readlane:
-        // no LDS round trips on the serial chain.
-        const float4_t z4 = {0.f, 0.f, 0.f, 0.f};
-        const WzIouThr ithr = wz_iou_thr(k.iou_thr);
-        float4_t kb0 = lane < kept ? S->kbox[lane] : z4, kb1 = lane + 64 < kept ? S->kbox[lane + 64] : z4;
-        float ka0, ka1;                                   // normalised corners + areas of the kept boxes
-        float4_t kn0 = wz_norm_box(kb0, ka0), kn1 = wz_norm_box(kb1, ka1);
-        int kc0 = lane < kept ? S->kcls[lane] : -1, kc1 = lane + 64 < kept ? S->kcls[lane + 64] : -1;
-        float ks0 = lane < kept ? S->kscore[lane] : 0.f, ks1 = lane + 64 < kept ? S->kscore[lane + 64] : 0.f;
-        const bool count_classes = k.max_per_class < k.max_total;
-        for (int base = 0; base < cnt && kept < k.max_total; base += 64) {
-            const int i = base + lane;
-            const unsigned long long comp = (i < cnt) ? sorted[i] : 0ull;
-            const float4_t cb = (i < cnt) ? S->sbox[i] : z4;
-            const int lim = min(64, cnt - base);
-            for (int tq = 0; tq < lim && kept < k.max_total; ++tq) {
-                const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(comp >> 32), tq);
-                const uint32_t tie = 0xFFFFFFFFu - (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)comp, tq);
-                float4_t box;
-                box[0] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb[0]), tq));
-                box[1] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb[1]), tq));
-                box[2] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb[2]), tq));
-                box[3] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cb[3]), tq));
-                const int cls = (int)(tie / (uint32_t)A);
-                float barea;
-                const float4_t bn = wz_norm_box(box, barea);
-                bool sup = kc0 == cls && wz_iou_exceeds(bn, barea, kn0, ka0, ithr);
-                if (kept > 64) sup = sup || (kc1 == cls && wz_iou_exceeds(bn, barea, kn1, ka1, ithr));
-                bool ok = !__any(sup);
-                if (ok && count_classes) {
-                    int same = (kc0 == cls ? 1 : 0) + (kc1 == cls ? 1 : 0);
+
+    // Greedy NMS over the sorted band, NMS_CHUNK candidates at a time:
+    //  (1) in parallel: which chunk members are suppressed by boxes kept earlier, and the pairwise
+    //      "i suppresses j" relation inside the chunk (same class and IoU > thr), as bit masks;
+    //  (2) one wavefront resolves the sequential part with register-only steps: lane l owns candidates
+    //      l, l+64, l+128, l+192; candidate i is kept iff its dead bit is clear, and keeping it ORs
+    //      bit i of every later candidate's suppressor mask into that candidate's dead bit.
+    const WzIouThr ithr = wz_iou_thr(k.iou_thr);
+    const bool count_classes = k.max_per_class < k.max_total;   // per-class cap can bind: counted in the scan
+    for (int base = 0; base < cnt && kept < k.max_total; base += NMS_CHUNK) {
+        const int m = min(NMS_CHUNK, cnt - base);
+        for (int i = tid; i < NMS_CHUNK; i += NMS_THREADS) {
+            S->cdead[i] = 0u;
 #pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) same += __shfl_xor(same, o);
-                    ok = same < k.max_per_class;
-                }
-                if (ok) {
-                    if (lane == (kept & 63)) {
-                        if (kept < 64) { kb0 = box; kn0 = bn; ka0 = barea; kc0 = cls; ks0 = __uint_as_float(key); }
-                        else { kb1 = box; kn1 = bn; ka1 = barea; kc1 = cls; ks1 = __uint_as_float(key); }
-                    }
-                    ++kept;
-                }
+            for (int w = 0; w < NMS_CHUNK / 64; ++w) S->supp[i][w] = 0ull;
+            if (i < m) {
+                const uint32_t tie = 0xFFFFFFFFu - (uint32_t)(sorted[base + i] & 0xFFFFFFFFull);
+                S->ccls[i] = (int)(tie / (uint32_t)A);
+                float ar;
+                S->cnorm[i] = wz_norm_box(S->sbox[base + i], ar);
+                S->carea[i] = ar;
+            } else {
+                S->ccls[i] = -1;
             }
         }
-        if (lane < kept) { S->kbox[lane] = kb0; S->kcls[lane] = kc0; S->kscore[lane] = ks0; }
-        if (lane + 64 < kept) { S->kbox[lane + 64] = kb1; S->kcls[lane + 64] = kc1; S->kscore[lane + 64] = ks1; }
-        if (lane == 0) S->kept = kept;
-        if (lane == 0) b.dbg[(size_t)f * 16 + 7] = wall_clock64();
+        __syncthreads();
+        for (int p = tid; p < m * kept; p += NMS_THREADS) {          // vs boxes kept before this chunk
+            const int i = p / kept, j = p - i * kept;
+            if (S->kcls[j] == S->ccls[i] && wz_iou_exceeds(S->cnorm[i], S->carea[i], S->knorm[j], S->karea[j], ithr))
+                S->cdead[i] = 1u;                                    // benign race: every writer stores 1
+        }
+        for (int p = tid; p < m * m; p += NMS_THREADS) {             // inside the chunk, i before j
+            const int i = p / m, j = p - i * m;
+            if (i < j && S->ccls[i] == S->ccls[j] &&
+                wz_iou_exceeds(S->cnorm[j], S->carea[j], S->cnorm[i], S->carea[i], ithr))
+                atomicOr(&S->supp[j][i >> 6], 1ull << (i & 63));
+        }
+        __syncthreads();
+        if (wave == 0) {
+            unsigned long long sp[NMS_CHUNK / 64][NMS_CHUNK / 64];   // [slot q][word w] of candidate lane + 64 q
+            uint32_t dead = 0;                                       // bit q = candidate lane + 64 q is suppressed
+            int mycls[NMS_CHUNK / 64];
+#pragma unroll
+            for (int q = 0; q < NMS_CHUNK / 64; ++q) {
+                const int j = lane + 64 * q;
+                mycls[q] = S->ccls[j];
+                if (S->cdead[j] || j >= m) dead |= 1u << q;
+#pragma unroll
+                for (int w = 0; w < NMS_CHUNK / 64; ++w) sp[q][w] = S->supp[j][w];
+            }
+            const int kept0 = kept;
+#pragma unroll
+            for (int w = 0; w < NMS_CHUNK / 64; ++w) {
+                for (int bb = 0; bb < 64; ++bb) {
+                    const int i = w * 64 + bb;
+                    if (i >= m || kept >= k.max_total) break;
+                    const uint32_t dbits = (uint32_t)__builtin_amdgcn_readlane((int)dead, bb);
+                    if ((dbits >> w) & 1u) continue;
+                    if (count_classes) {                             // kept boxes of this class so far
+                        const int cls = __builtin_amdgcn_readlane(mycls[w], bb);
+                        int same = 0;
+                        for (int j = lane; j < kept; j += 64)
+                            same += (j < kept0 ? S->kcls[j] : S->ccls[S->kidx[j] - base]) == cls ? 1 : 0;
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) same += __shfl_xor(same, o);
+                        if (same >= k.max_per_class) continue;
+                    }
+                    if (lane == 0) S->kidx[kept] = base + i;
+                    ++kept;
+#pragma unroll
+                    for (int q = 0; q < NMS_CHUNK / 64; ++q)
+                        dead |= (uint32_t)((sp[q][w] >> bb) & 1ull) << q;
+                }
+            }
+            if (lane == 0) S->kept = kept;
+        }
+        __syncthreads();
+        const int kept_new = S->kept;
+        for (int j = kept + tid; j < kept_new; j += NMS_THREADS) {   // materialise the newly kept rows
+            const int si = S->kidx[j];
+            const unsigned long long comp = sorted[si];
+            S->kbox[j] = S->sbox[si];
+            S->knorm[j] = S->cnorm[si - base];
+            S->karea[j] = S->carea[si - base];
+            S->kcls[j] = S->ccls[si - base];
+            S->kscore[j] = __uint_as_float((uint32_t)(comp >> 32));
+        }
+        __syncthreads();
+        kept = kept_new;
     }
-    __syncthreads();
-    return S->kept;
+    if (tid == 0) b.dbg[(size_t)f * 16 + 7] = wall_clock64();
+    return kept;
 }
 
 // A band too crowded for the LDS list (massive score ties): exact one-candidate-per-scan walk over
@@ -401,8 +467,8 @@ __global__ __launch_bounds__(NMS_THREADS) void wz_k_nms(WzPostBuffers b, WzPostC
     // before max_total rows are kept) are collected here by one scan over the frame's candidates.
 #define NMS_STAMP(i) do { if (tid == 0) b.dbg[(size_t)f * 16 + (i)] = wall_clock64(); } while (0)
     NMS_STAMP(0);
-    uint32_t total = 0;
-    int lo_bin = wz_threshold_bin(b.hist + (size_t)f * WZ_HIST_BINS, S->hist, WZ_CAND_TARGET, &total);
+    const uint32_t total = b.band[2 * f + 1];
+    int lo_bin = (int)b.band[2 * f];
     NMS_STAMP(1);
     int hi_bin = WZ_HIST_BINS;
     uint32_t processed = 0;

@@ -79,6 +79,7 @@ struct WzPostBuffers {
     uint8_t* valid;           // [n][A]   clipped area > 0
     uint32_t* hist;           // [n][WZ_HIST_BINS]
     uint32_t* count;          // [n]  (directly behind hist so one memset clears both)
+    uint32_t* band;           // [n][2] threshold bin of band 0 and the frame's candidate total (written by wz_k_compact)
     uint2* cand;              // [n][WZ_CAND_CAP] (score bits, tie index c*A + a)
     float* det_boxes;         // [n][100][4]
     float* det_scores;        // [n][100]

@@ -344,7 +344,7 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     e->pc.score_thr = h.score_threshold;
     e->pc.iou_thr = h.iou_threshold;
     e->pc.scale_y = h.scale_y; e->pc.scale_x = h.scale_x; e->pc.scale_h = h.scale_h; e->pc.scale_w = h.scale_w;
-    e->post_scratch_bytes = (size_t)max_batch * (WZ_HIST_BINS + 1) * 4;
+    e->post_scratch_bytes = (size_t)max_batch * (WZ_HIST_BINS + 3) * 4;
 
     for (uint32_t i = 0; i < h.n_tensors; ++i)
         if (e->tensors[i].slot < 0 || e->tensors[i].slot >= (int)h.n_slots) {
@@ -392,6 +392,7 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
         CK(hipMalloc(&L.d_post_scratch, e->post_scratch_bytes));
         pb.hist = (uint32_t*)L.d_post_scratch;
         pb.count = pb.hist + (size_t)max_batch * WZ_HIST_BINS;
+        pb.band = pb.count + max_batch;
         CK(hipMalloc((void**)&pb.cand, (size_t)max_batch * WZ_CAND_CAP * sizeof(uint2)));
         CK(hipMalloc((void**)&pb.det_boxes, (size_t)max_batch * h.max_total * 16));
         CK(hipMalloc((void**)&pb.det_scores, (size_t)max_batch * h.max_total * 4));
