@@ -358,6 +358,7 @@ __device__ int wz_nms_band(NmsShared* S, const WzPostBuffers& b, const WzPostCon
                 atomicOr(&S->supp[j][i >> 6], 1ull << (i & 63));
         }
         __syncthreads();
+        const int kept_before = kept;   // wave 0 advances its private copy of `kept` in the scan below
         if (wave == 0) {
             unsigned long long sp[NMS_CHUNK / 64][NMS_CHUNK / 64];   // [slot q][word w] of candidate lane + 64 q
             uint32_t dead = 0;                                       // bit q = candidate lane + 64 q is suppressed
@@ -398,7 +399,7 @@ __device__ int wz_nms_band(NmsShared* S, const WzPostBuffers& b, const WzPostCon
         }
         __syncthreads();
         const int kept_new = S->kept;
-        for (int j = kept + tid; j < kept_new; j += NMS_THREADS) {   // materialise the newly kept rows
+        for (int j = kept_before + tid; j < kept_new; j += NMS_THREADS) {   // materialise the newly kept rows
             const int si = S->kidx[j];
             const unsigned long long comp = sorted[si];
             S->kbox[j] = S->sbox[si];
