@@ -40,13 +40,28 @@ def kernel_class(op):
         return "wz_k_stem"
     if op["kind"] == arch.OP_DW:
         return "wz_k_dw"
+    if op["kind"] == arch.OP_MBCONV:
+        return "wz_k_mbconv"
     return "wz_k_conv<%d>" % op["ksize"]
 
 
 def algorithmic_cost(op, n):
-    """(flops, bytes) of one launch per the per-layer rule of SURVEY.md 8(d): every tensor once."""
+    """(flops, bytes) of one launch per the per-layer rule of SURVEY.md 8(d): every tensor once.
+    A fused inverted-residual block is priced as the layers it computes (expand, depthwise, project), i.e.
+    the bytes a layer-by-layer execution moves; `fused_min_bytes` below is what the fused launch has to move."""
     from watsor_amd import arch
     M = n * op["hout"] * op["wout"]
+    if op["kind"] == arch.OP_MBCONV:
+        Min, cin, cmid, cout = n * op["hin"] * op["win"], op["cin"], op["cmid"], op["cout"]
+        fl, by = 0.0, 0.0
+        if cin != cmid:                                              # 1x1 expand
+            fl += 2.0 * Min * cin * cmid
+            by += 2.0 * (Min * cin + cin * cmid + Min * cmid)
+        fl += 2.0 * M * cmid * 9                                     # depthwise 3x3
+        by += 2.0 * (Min * cmid + 9 * cmid + M * cmid)
+        fl += 2.0 * M * cmid * cout                                  # 1x1 project
+        by += 2.0 * (M * cmid + cmid * cout + M * cout)
+        return fl, by
     if op["kind"] == arch.OP_DW:
         c = op["cin"]
         return 2.0 * M * c * 9, 2.0 * (n * op["hin"] * op["win"] * c + 9 * c + M * c)
@@ -60,6 +75,7 @@ def algorithmic_cost(op, n):
 
 def roofline_from_stages(stages, ops, n, frame_bytes, size):
     """Aggregate event-bracketed stage times by kernel; return (roofline dict of the dominant kernel, table)."""
+    from watsor_amd import arch
     by_name = {o["name"]: o for o in ops}
     # A hipEventRecord pair with nothing in between reads ~5 us on this stack (the record itself is a
     # barrier packet).  Brackets of unused split-K slots are exactly that: calibrate on them and
@@ -83,8 +99,15 @@ def roofline_from_stages(stages, ops, n, frame_bytes, size):
             k, fl, by = "wz_k_" + name.split("/")[1], 0.0, 0.0
         else:
             continue
-        a = agg.setdefault(k, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+        a = agg.setdefault(k, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, min_bytes=0.0))
         a["ms"] += ms; a["flops"] += fl; a["bytes"] += by; a["launches"] += 1
+        if name in by_name and by_name[name]["kind"] == arch.OP_MBCONV:   # block input + weights + output, once each
+            o = by_name[name]
+            cin, cmid, cout = o["cin"], o["cmid"], o["cout"]
+            a["min_bytes"] += 2.0 * (n * o["hin"] * o["win"] * cin + (cin * cmid if cin != cmid else 0) + 9 * cmid +
+                                     cmid * cout + n * o["hout"] * o["wout"] * cout)
+        else:
+            a["min_bytes"] += by
     table = []
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
         t = a["ms"] * 1e-3
@@ -94,7 +117,9 @@ def roofline_from_stages(stages, ops, n, frame_bytes, size):
                           gbs=a["bytes"] / t / 1e9 if t > 0 else 0.0, tflops=a["flops"] / t / 1e12 if t > 0 else 0.0,
                           t_roof_frac=max(t_hbm, t_mfma) / t if t > 0 else 0.0,
                           bound="mfma" if t_mfma > t_hbm else "hbm",
-                          bytes_per_launch=a["bytes"] / a["launches"], flops_per_launch=a["flops"] / a["launches"]))
+                          bytes_per_launch=a["bytes"] / a["launches"], flops_per_launch=a["flops"] / a["launches"],
+                          min_bytes_per_launch=a["min_bytes"] / a["launches"],
+                          min_gbs=a["min_bytes"] / t / 1e9 if t > 0 else 0.0))
     dom = table[0]
     if dom["bound"] == "hbm":
         ach, peak, unit = dom["gbs"], HBM_PEAK_GBS, "GB/s"
@@ -103,7 +128,10 @@ def roofline_from_stages(stages, ops, n, frame_bytes, size):
     roof = dict(kernel=dom["kernel"], event_overhead_us=round(overhead * 1e3, 3), bound=dom["bound"], achieved=round(ach, 3), peak=peak, unit=unit,
                 frac=round(ach / peak, 5), traffic=None, avg_launch_us=round(dom["avg_us"], 3),
                 launches_per_step=dom["launches"], time_frac_of_roofline=round(dom["t_roof_frac"], 5),
-                algorithmic_bytes_per_launch=dom["bytes_per_launch"], algorithmic_flops_per_launch=dom["flops_per_launch"])
+                algorithmic_bytes_per_launch=dom["bytes_per_launch"], algorithmic_flops_per_launch=dom["flops_per_launch"],
+                # what the launch has to move when intermediate tensors stay on chip (= algorithmic for unfused kernels)
+                fused_min_bytes_per_launch=dom["min_bytes_per_launch"],
+                frac_of_peak_on_fused_min_bytes=round(dom["min_gbs"] / HBM_PEAK_GBS, 5))
     return roof, table
 
 

@@ -52,6 +52,15 @@ def model_dir(synth_weights, tmp_path_factory):
 
 
 @pytest.fixture(scope="session")
+def model_dir_unfused(synth_weights, tmp_path_factory):
+    """The same model with one op per layer (no fused inverted-residual blocks): every activation tensor exists."""
+    from watsor_amd import engine
+    d = tmp_path_factory.mktemp("model_unfused")
+    engine.save_engine(engine.build_engine(synth_weights, fuse=False), str(d / "mi355x.bin"))
+    return str(d)
+
+
+@pytest.fixture(scope="session")
 def oracle_net(synth_weights):
     from oracle.ssd_mobilenet_v2 import OracleNet
     return OracleNet(synth_weights)

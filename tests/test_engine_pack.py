@@ -9,6 +9,13 @@ from watsor_amd import arch, engine
 
 @pytest.fixture(scope="module")
 def blob(synth_weights):
+    """one op per layer"""
+    return engine.build_engine(synth_weights, fuse=False)
+
+
+@pytest.fixture(scope="module")
+def fused_blob(synth_weights):
+    """the default program: one op per inverted-residual block"""
     return engine.build_engine(synth_weights)
 
 
@@ -26,9 +33,11 @@ def parse(blob):
     keys = ("kind src dst res cin cout ksize stride hin win hout wout pad_t pad_l act out_mode anchor_off "
             "anchors_per_loc n_pad kc").split()
     for i in range(hdr["n_ops"]):
-        o = struct.unpack_from("<20i2q8i64s", blob, hdr["ops_off"] + 192 * i)
+        o = struct.unpack_from("<20i2q8i8q64s", blob, hdr["ops_off"] + engine.OP_RECORD_BYTES * i)
         d = dict(zip(keys, o[:20]))
-        d.update(w_off=o[20], b_off=o[21], n_box=o[22], name=o[30].split(b"\0")[0].decode())
+        d.update(w_off=o[20], b_off=o[21], n_box=o[22], cmid=o[23], cin0=o[24], kc0=o[25], cmid_pad=o[26],
+                 nmid_pad=o[27], we_off=o[30], be_off=o[31], wd_off=o[32], bd_off=o[33],
+                 name=o[38].split(b"\0")[0].decode())
         ops.append(d)
     return hdr, tensors, ops
 
@@ -60,8 +69,9 @@ def test_shapes_follow_tf_same_padding(blob):
     assert [o["anchor_off"] for o in heads] == [0, 1083, 1683, 1833, 1887, 1911]
 
 
-def test_slots_never_alias_live_tensors(blob):
-    hdr, tensors, ops = parse(blob)
+@pytest.mark.parametrize("which", ["blob", "fused_blob"])
+def test_slots_never_alias_live_tensors(which, request):
+    hdr, tensors, ops = parse(request.getfixturevalue(which))
     last = {}
     for i, o in enumerate(ops):
         last[o["src"]] = i
@@ -76,7 +86,7 @@ def test_slots_never_alias_live_tensors(blob):
             if a < b and tensors[a]["slot"] == tensors[b]["slot"]:
                 # lifetimes [born, last] must be disjoint; an op's dst may not reuse its own inputs
                 assert last[a] < born[b] or last[b] < born[a], (tensors[a]["name"], tensors[b]["name"])
-    assert hdr["n_slots"] < len(tensors) // 4       # sharing actually happens
+    assert hdr["n_slots"] <= len(tensors) // 4      # sharing actually happens
 
 
 def unpack_conv(blob, hdr, o):
@@ -90,7 +100,7 @@ def unpack_conv(blob, hdr, o):
 
 def test_weight_fragments_round_trip(blob, synth_weights):
     hdr, tensors, ops = parse(blob)
-    prog = arch.build()
+    prog = arch.build(fuse=False)
     for o, op in zip(ops, prog.ops):
         wf, bf = engine.fold_batch_norm(synth_weights, op)
         bias_n = o["n_pad"] if o["kind"] == arch.OP_CONV else op.cout
@@ -106,10 +116,48 @@ def test_weight_fragments_round_trip(blob, synth_weights):
             np.testing.assert_array_equal(w, wf.reshape(9, op.cin).astype(np.float16))
 
 
+def test_fused_blocks_pack_the_same_weights(blob, fused_blob, synth_weights):
+    """OP_MBCONV records carry exactly the folded weights of the three layers they replace."""
+    hdr, tensors, ops = parse(blob)
+    fhdr, ftensors, fops = parse(fused_blob)
+    assert fhdr["n_ops"] == 34 and sum(1 for o in fops if o["kind"] == arch.OP_MBCONV) == 17
+    by_name = {o["name"]: o for o in ops}
+    fprog = arch.build(fuse=True)
+    names = {t["name"] for t in ftensors}
+    assert "expanded_conv_13/expand" in names and "expanded_conv_12/expand" not in names   # SSD tap stays in HBM
+    for o, op in zip(fops, fprog.ops):
+        if o["kind"] != arch.OP_MBCONV:
+            assert o["w_off"] >= 0
+            continue
+        pj = by_name[o["name"] + "/project"]
+        dw = by_name[o["name"] + "/depthwise"]
+        assert (o["cin"], o["cout"], o["n_pad"], o["kc"], o["stride"]) == (pj["cin"], pj["cout"], pj["n_pad"], pj["kc"], dw["stride"])
+        assert (o["hin"], o["hout"], o["pad_t"], o["pad_l"]) == (dw["hin"], dw["hout"], dw["pad_t"], dw["pad_l"])
+        assert o["cmid"] == dw["cin"] and o["cmid_pad"] == (o["cmid"] + 31) // 32 * 32 and o["kc"] == o["cmid_pad"] // 32
+        np.testing.assert_array_equal(unpack_conv(fused_blob, fhdr, dict(o, ksize=1)), unpack_conv(blob, hdr, pj))
+        wd = np.frombuffer(fused_blob, np.float16, 9 * o["cmid_pad"], fhdr["weights_off"] + o["wd_off"]).reshape(9, -1)
+        ref = np.frombuffer(blob, np.float16, 9 * dw["cin"], hdr["weights_off"] + dw["w_off"]).reshape(9, -1)
+        np.testing.assert_array_equal(wd[:, :o["cmid"]], ref)
+        assert not wd[:, o["cmid"]:].any()
+        bd = np.frombuffer(fused_blob, np.float32, o["cmid_pad"], fhdr["weights_off"] + o["bd_off"])
+        np.testing.assert_array_equal(bd[:o["cmid"]], np.frombuffer(blob, np.float32, dw["cin"], hdr["weights_off"] + dw["b_off"]))
+        if o["cin0"]:
+            ex = by_name[o["name"] + "/expand"]
+            assert (o["cin0"], o["kc0"], o["nmid_pad"]) == (ex["cin"], ex["kc"], ex["n_pad"]) and ex["cout"] == o["cmid"]
+            np.testing.assert_array_equal(
+                unpack_conv(fused_blob, fhdr, dict(ksize=1, n_pad=o["nmid_pad"], kc=o["kc0"], w_off=o["we_off"])),
+                unpack_conv(blob, hdr, ex))
+            np.testing.assert_array_equal(
+                np.frombuffer(fused_blob, np.float32, o["nmid_pad"], fhdr["weights_off"] + o["be_off"]),
+                np.frombuffer(blob, np.float32, ex["n_pad"], hdr["weights_off"] + ex["b_off"]))
+        else:
+            assert o["name"].endswith(("expanded_conv", "expanded_conv_13"))
+
+
 def test_fold_matches_oracle_fold(synth_weights):
     """Product-side BN folding / head fusion vs the oracle's independent description of the graph."""
     from oracle import ssd_mobilenet_v2 as net
-    prog = arch.build()
+    prog = arch.build(fuse=False)
     spec = {s.name: s for s in net.graph_spec()}
     assert len(spec) == 72 and len(prog.ops) == 66
     for op in prog.ops:

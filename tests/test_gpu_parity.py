@@ -36,14 +36,28 @@ def eng(model_dir):
     e.close()
 
 
-@pytest.fixture(scope="module")
-def eng_keep(model_dir):
-    """Engine whose activation tensors do not share buffers (every layer readable after a forward)."""
-    os.environ["WZ_NO_BUFFER_REUSE"] = "1"
+def _keep_engine(path, **env):
+    env = dict(env, WZ_NO_BUFFER_REUSE="1")
+    os.environ.update(env)
     try:
-        e = make_engine(model_dir, max_batch=2)
+        return make_engine(path, max_batch=2)
     finally:
-        os.environ.pop("WZ_NO_BUFFER_REUSE")
+        for k in env:
+            os.environ.pop(k)
+
+
+@pytest.fixture(scope="module")
+def eng_keep(model_dir_unfused):
+    """One op per layer, activation tensors do not share buffers: every layer is readable after a forward."""
+    e = _keep_engine(model_dir_unfused)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def eng_keep_fused(model_dir):
+    """The default program (fused inverted-residual blocks), tensors not sharing buffers."""
+    e = _keep_engine(model_dir)
     yield e
     e.close()
 
@@ -82,6 +96,81 @@ def test_every_layer_close_to_oracle(eng_keep, head_outputs):
     assert np.abs(lg - rlg).max() <= LOGIT_TOL
 
 
+def _compare_programs(e_unf, e_fused, x_half, rel):
+    a = e_unf.stage_forward(x_half)
+    b = e_fused.stage_forward(x_half)
+    unf = {t[0]: i for i, t in enumerate(e_unf.tensors())}
+    fused = e_fused.tensors()
+    assert len(fused) < len(unf) and any(k == 4 for k in [o["kind"] for o in e_fused.ops()])
+    bad = []
+    for idx, (name, h, w, c) in enumerate(fused):
+        if name == "input":
+            continue
+        for f in range(2):
+            x = e_fused.stage_read_tensor(idx, f).astype(np.float32)
+            y = e_unf.stage_read_tensor(unf[name], f).astype(np.float32)
+            d = np.abs(x - y)
+            if d.max() > rel * np.abs(y).max():
+                bad.append("%s[%d]: %d of %d differ, max %.4g (max|ref| %.3g) at %s" % (
+                    name, f, int((d > 0).sum()), d.size, d.max(), np.abs(y).max(), np.unravel_index(d.argmax(), d.shape)))
+    assert not bad, "\n".join(bad[:12])
+    return a, b
+
+
+def test_fused_blocks_equal_unfused_layers(model_dir, model_dir_unfused, head_outputs):
+    """One launch per inverted-residual block (k_mbconv.hip) rounds at the same points and, when the
+    expanded channels are not spread over workgroups (WZ_SPLITK=0), accumulates in the same order as the
+    per-layer kernels: every tensor both programs hold is bit-identical."""
+    e_unf = _keep_engine(model_dir_unfused, WZ_SPLITK="0")
+    e_fus = _keep_engine(model_dir, WZ_SPLITK="0")
+    try:
+        a, b = _compare_programs(e_unf, e_fus, head_outputs[0], 0.0)
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+    finally:
+        e_unf.close()
+        e_fus.close()
+
+
+def test_fused_blocks_with_channel_groups_close_to_unfused(eng_keep, eng_keep_fused, head_outputs):
+    """Default program: late blocks sum fp32 partials of channel groups in a fixed order -- same values up to
+    the fp32 summation order, i.e. an fp16 ulp here and there, never more than 1 % of a tensor's range."""
+    a, b = _compare_programs(eng_keep, eng_keep_fused, head_outputs[0], 0.01)
+    assert np.abs(a[1] - b[1]).max() <= 0.02 and np.abs(a[0] - b[0]).max() <= 0.02
+
+
+@pytest.fixture(scope="module")
+def nosplit_outputs(model_dir, head_outputs):
+    os.environ["WZ_SPLITK"] = "0"
+    try:
+        e = make_engine(model_dir, max_batch=2)
+    finally:
+        os.environ.pop("WZ_SPLITK")
+    try:
+        return e.stage_forward(head_outputs[0])
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("tile", [(4, 4), (5, 7), (8, 16), (16, 8), (3, 19)])
+def test_fused_blocks_any_tile_shape(model_dir, nosplit_outputs, head_outputs, tile):
+    """The workgroup tile is a tuning knob: results may not depend on it (channel groups off, so that the
+    fp32 summation order is the same)."""
+    env = dict(WZ_MB_TH=str(tile[0]), WZ_MB_TW=str(tile[1]), WZ_SPLITK="0")
+    os.environ.update(env)
+    try:
+        e = make_engine(model_dir, max_batch=2)
+        try:
+            got = e.stage_forward(head_outputs[0])
+        finally:
+            e.close()
+    finally:
+        for k in env:
+            os.environ.pop(k)
+    np.testing.assert_array_equal(got[0], nosplit_outputs[0])
+    np.testing.assert_array_equal(got[1], nosplit_outputs[1])
+
+
 def test_scores_within_tolerance(eng, head_outputs):
     from oracle.postprocess import sigmoid
     x_half, rbe, rlg, _ = head_outputs
@@ -89,10 +178,10 @@ def test_scores_within_tolerance(eng, head_outputs):
     assert np.abs(sigmoid(lg) - sigmoid(rlg)).max() <= SCORE_TOL
 
 
-def test_buffer_sharing_changes_nothing(eng, eng_keep, head_outputs):
+def test_buffer_sharing_changes_nothing(eng, eng_keep_fused, head_outputs):
     x_half = head_outputs[0]
     a = eng.stage_forward(x_half)
-    b = eng_keep.stage_forward(x_half)
+    b = eng_keep_fused.stage_forward(x_half)
     np.testing.assert_array_equal(a[0], b[0])
     np.testing.assert_array_equal(a[1], b[1])
 

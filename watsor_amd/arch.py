@@ -20,7 +20,7 @@ NUM_CLASSES = 91                      # class-head columns per anchor (column 0 
 FE = "FeatureExtractor/MobilenetV2/"
 
 # op kinds understood by the runtime (keep in sync with csrc/wz_program.h)
-OP_STEM, OP_DW, OP_CONV = 1, 2, 3
+OP_STEM, OP_DW, OP_CONV, OP_MBCONV = 1, 2, 3, 4   # OP_MBCONV: fused inverted-residual block (csrc/k_mbconv.hip)
 # output modes of OP_CONV
 OUT_ACT, OUT_BOX, OUT_CLS, OUT_HEAD = 0, 1, 2, 3   # OUT_HEAD: box columns then class columns, one launch
 ACT_NONE, ACT_RELU6 = 0, 1
@@ -72,6 +72,11 @@ class Op:
     pad_l: int = 0
     anchor_offset: int = 0     # first anchor index of this head's feature map
     n_box: int = 0             # OUT_HEAD: leading output columns that are box encodings (anchors_per_loc * 4)
+    # OP_MBCONV: [1x1 expand ->] depthwise 3x3 -> 1x1 project (+ res) in one launch; cin/cout above describe
+    # the PROJECT conv (cin = cmid); `parts` are the unfused ops it replaces (weights are folded per part)
+    cmid: int = 0              # depthwise (= expanded) channels
+    cin0: int = 0              # block input channels feeding the expand conv; 0 = no expand stage
+    parts: Optional[list] = None
 
 
 @dataclass
@@ -85,7 +90,10 @@ class Program:
     def variable_shapes(self) -> Dict[str, Tuple[int, ...]]:
         """TF variable name -> shape, for every variable the program consumes."""
         out: Dict[str, Tuple[int, ...]] = {}
+        flat: List[Op] = []
         for op in self.ops:
+            flat.extend(op.parts if op.kind == OP_MBCONV else [op])
+        for op in flat:
             if op.out_mode == OUT_HEAD:
                 for sub, cols in (("BoxEncodingPredictor", op.n_box), ("ClassPredictor", op.cout - op.n_box)):
                     out["%s/%s/weights" % (op.scope, sub)] = (op.k, op.k, op.cin, cols)
@@ -107,7 +115,10 @@ def _blk(i: int) -> str:
     return "expanded_conv" if i == 0 else "expanded_conv_%d" % i
 
 
-def build(size: int = INPUT_SIZE) -> Program:
+def build(size: int = INPUT_SIZE, fuse: bool = True) -> Program:
+    """fuse=True: every inverted-residual block is ONE op (OP_MBCONV); block 13 keeps its expand conv as
+    a separate op because its output is the first SSD feature map.  fuse=False: one op per layer (the
+    program the per-layer parity tests walk); both programs compute bit-identical tensors."""
     p = Program(size=size)
     ops: List[Op] = []
     ops.append(Op(OP_STEM, FE + "Conv", "input", "Conv", 3, 32, 3, 2, ACT_RELU6, True))
@@ -118,16 +129,26 @@ def build(size: int = INPUT_SIZE) -> Program:
             stride = s if j == 0 else 1
             name = _blk(idx)
             x_in, mid = cur, cin * t
+            block: List[Op] = []
             if t != 1:
-                ops.append(Op(OP_CONV, FE + name + "/expand", cur, name + "/expand", cin, mid, 1, 1, ACT_RELU6, True))
+                block.append(Op(OP_CONV, FE + name + "/expand", cur, name + "/expand", cin, mid, 1, 1, ACT_RELU6, True))
                 cur = name + "/expand"
                 if idx == 13:
                     tap0 = cur
-            ops.append(Op(OP_DW, FE + name + "/depthwise", cur, name + "/depthwise", mid, mid, 3, stride,
-                          ACT_RELU6, True))
+            block.append(Op(OP_DW, FE + name + "/depthwise", cur, name + "/depthwise", mid, mid, 3, stride,
+                            ACT_RELU6, True))
             res = x_in if (stride == 1 and cin == c) else None
-            ops.append(Op(OP_CONV, FE + name + "/project", name + "/depthwise", name + "/output", mid, c, 1, 1,
-                          ACT_NONE, True, res=res))
+            block.append(Op(OP_CONV, FE + name + "/project", name + "/depthwise", name + "/output", mid, c, 1, 1,
+                            ACT_NONE, True, res=res))
+            if fuse:
+                keep_expand = t != 1 and idx == 13          # its output is an SSD feature map
+                if keep_expand:
+                    ops.append(block.pop(0))
+                has_expand = t != 1 and not keep_expand
+                ops.append(Op(OP_MBCONV, FE + name, block[0].src, name + "/output", mid, c, 3, stride, ACT_NONE, True,
+                              res=res, cmid=mid, cin0=cin if has_expand else 0, parts=block))
+            else:
+                ops.extend(block)
             cur, cin = name + "/output", c
             idx += 1
     ops.append(Op(OP_CONV, FE + "Conv_1", cur, "Conv_1", cin, 1280, 1, 1, ACT_RELU6, True))

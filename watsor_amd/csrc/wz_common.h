@@ -41,6 +41,28 @@ struct WzConvArgs {
     int32_t n_box;              // WZ_OUT_HEAD: columns [0, n_box) are box encodings, the rest class logits
 };
 
+// One fused inverted-residual block (k_mbconv.hip).  cin/kc/n_pad/cout describe the project conv.
+struct WzMbArgs {
+    const half_t* in;      // block input, NHWC fp16: cin0 channels (expand) or cmid channels (no expand)
+    const half_t* we;      // expand weights, MFMA A fragments [nmid_pad/16][kc0][64][8]
+    const float* be;       // [nmid_pad]
+    const half_t* wd;      // depthwise weights [9][cmid_pad]
+    const float* bd;       // [cmid_pad]
+    const half_t* wp;      // project weights, MFMA A fragments [n_pad/16][kc][64][8]
+    const float* bp;       // [n_pad]
+    const half_t* res;     // residual (shape of out) or nullptr
+    half_t* out;           // NHWC fp16, cout channels
+    int32_t hin, win, hout, wout;
+    int32_t cin0, kc0, nmid_pad;   // expand: input channels (0 = no expand stage), K chunks, packed columns
+    int32_t cmid, cmid_pad, kc;    // depthwise channels, padded row, K chunks of the project conv
+    int32_t cout, n_pad;
+    int32_t stride, pad_t, pad_l;
+    float* ws;             // fp32 workspace for channel-group partial sums (nullptr: never split)
+    uint64_t ws_bytes;
+    int32_t M;             // n * hout * wout
+    int32_t th, tw, tiles_y, tiles_x, nsplit, cpg;   // filled in by the launcher
+};
+
 // Per-camera filter state resident in HBM (see wz_set_camera_filter).
 struct WzCamFilter {
     int32_t enabled, width, height, n_zones;
@@ -67,6 +89,7 @@ void wz_launch_dw(const half_t* in, const half_t* w, const float* bias, half_t* 
 void wz_launch_conv(const WzConvArgs& a, hipStream_t s);
 void wz_launch_splitk_reduce(const WzConvArgs& a, const float* ws, hipStream_t s);
 int wz_choose_splitk(int M, int n_pad, int kchunks);
+int wz_launch_mbconv(const WzMbArgs& a, int n, hipStream_t s, bool prepare);   // -1: no kernel; else #channel groups
 
 #define WZ_HIST_BINS 1024
 #define WZ_CAND_CAP 4096

@@ -108,6 +108,27 @@ typedef wz_engine::Lane Lane;
 // ------------------------------------------------------------------------------------------------
 // pipeline
 // ------------------------------------------------------------------------------------------------
+static WzMbArgs mb_args(wz_engine* e, const Lane& L, const WzOpDesc& op) {
+    const uint8_t* wbase = e->d_weights;
+    WzMbArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = L.tptr.empty() ? nullptr : L.tptr[op.src];
+    a.we = op.cin0 > 0 ? (const half_t*)(wbase + op.we_off) : nullptr;
+    a.be = op.cin0 > 0 ? (const float*)(wbase + op.be_off) : nullptr;
+    a.wd = (const half_t*)(wbase + op.wd_off);
+    a.bd = (const float*)(wbase + op.bd_off);
+    a.wp = (const half_t*)(wbase + op.w_off);
+    a.bp = (const float*)(wbase + op.b_off);
+    a.res = (op.res >= 0 && !L.tptr.empty()) ? L.tptr[op.res] : nullptr;
+    a.out = L.tptr.empty() ? nullptr : L.tptr[op.dst];
+    a.hin = op.hin; a.win = op.win; a.hout = op.hout; a.wout = op.wout;
+    a.cin0 = op.cin0; a.kc0 = op.kc0; a.nmid_pad = op.nmid_pad;
+    a.cmid = op.cmid; a.cmid_pad = op.cmid_pad; a.kc = op.kc;
+    a.cout = op.cout; a.n_pad = op.n_pad;
+    a.stride = op.stride; a.pad_t = op.pad_t; a.pad_l = op.pad_l;
+    return a;
+}
+
 static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t) {
     hipStream_t s = L.stream;
     for (uint32_t i = 0; i < e->hdr.n_ops; ++i) {
@@ -120,6 +141,21 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t) {
             wz_launch_dw(L.tptr[op.src], (const half_t*)(wbase + op.w_off), (const float*)(wbase + op.b_off),
                          L.tptr[op.dst], n, op.hin, op.win, op.cin, op.hout, op.wout, op.stride, op.pad_t,
                          op.pad_l, op.act, s);
+        } else if (op.kind == WZ_OP_MBCONV) {
+            WzMbArgs a = mb_args(e, L, op);
+            a.M = n * op.hout * op.wout;
+            a.ws = e->use_splitk ? L.d_ws : nullptr;
+            a.ws_bytes = WZ_WS_BYTES;
+            const int groups = wz_launch_mbconv(a, n, s, false);
+            if (t) t->mark();
+            if (groups > 1) {   // sum the channel groups' partials in a fixed order, + bias, + residual, -> fp16
+                WzConvArgs r;
+                memset(&r, 0, sizeof(r));
+                r.bias = a.bp; r.res = a.res; r.out = a.out;
+                r.M = a.M; r.hout = op.hout; r.wout = op.wout; r.cout = op.cout; r.n_pad = op.n_pad;
+                r.act = WZ_ACT_NONE; r.out_mode = WZ_OUT_ACT; r.splitk = groups;
+                wz_launch_splitk_reduce(r, L.d_ws, s);
+            }
         } else {
             WzConvArgs a;
             memset(&a, 0, sizeof(a));
@@ -281,8 +317,21 @@ static int load_blob(wz_engine* e, const char* path) {
                                        (op.out_mode == WZ_OUT_ACT && op.cout % 8 != 0) ||
                                        (op.ksize != 1 && op.ksize != 3) ||
                                        (op.out_mode == WZ_OUT_HEAD && (op.n_box % 4 != 0 || op.n_box <= 0 || op.n_box >= op.cout)))) ||
-            (op.kind == WZ_OP_DW && op.cin % 8 != 0))
+            (op.kind == WZ_OP_DW && op.cin % 8 != 0) ||
+            (op.kind == WZ_OP_MBCONV &&
+             (op.dst < 0 || op.cmid < 8 || op.cmid % 8 != 0 || op.cmid_pad != (op.cmid + 31) / 32 * 32 ||
+              op.kc != op.cmid_pad / 32 || op.n_pad % 32 != 0 || op.n_pad < op.cout || op.cout % 8 != 0 ||
+              op.wd_off < 0 || (uint64_t)op.wd_off >= h.weights_bytes || op.bd_off < 0 ||
+              (uint64_t)op.bd_off >= h.weights_bytes || op.stride < 1 || op.stride > 2 ||
+              (op.cin0 != 0 && (op.cin0 % 8 != 0 || op.kc0 != (op.cin0 + 31) / 32 || op.nmid_pad % 16 != 0 ||
+                                op.nmid_pad < op.cmid || op.we_off < 0 || (uint64_t)op.we_off >= h.weights_bytes ||
+                                op.be_off < 0 || (uint64_t)op.be_off >= h.weights_bytes)))))
             return wz_fail(WZ_EFORMAT, "%s: op %u (%s) is malformed", path, i, op.name);
+        if (op.kind == WZ_OP_MBCONV) {
+            wz_engine::Lane none;
+            if (wz_launch_mbconv(mb_args(e, none, op), 1, nullptr, true) != 0)
+                return wz_fail(WZ_EFORMAT, "%s: op %u (%s): no fused-block kernel for this shape", path, i, op.name);
+        }
     }
     return WZ_OK;
 }
@@ -328,6 +377,11 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     wz_device_name_of(device, nm, sizeof(nm));
     e->name = nm;
     wz_post_init();
+    for (uint32_t i = 0; i < e->hdr.n_ops; ++i)   // kernel attributes of the fused-block kernels, on THIS device
+        if (e->ops[i].kind == WZ_OP_MBCONV) {
+            wz_engine::Lane none;
+            (void)wz_launch_mbconv(mb_args(e, none, e->ops[i]), max_batch, nullptr, true);
+        }
 
     const WzBlobHeader& h = e->hdr;
     CK(hipMalloc((void**)&e->d_weights, h.weights_bytes));
@@ -422,7 +476,8 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     e->stage_names.push_back("preprocess");
     for (uint32_t i = 0; i < h.n_ops; ++i) {
         e->stage_names.push_back(e->ops[i].name);
-        if (e->ops[i].kind == WZ_OP_CONV) e->stage_names.push_back(std::string(e->ops[i].name) + "#splitk_reduce");
+        if (e->ops[i].kind == WZ_OP_CONV || e->ops[i].kind == WZ_OP_MBCONV)
+            e->stage_names.push_back(std::string(e->ops[i].name) + "#splitk_reduce");
     }
     e->stage_names.push_back("post/decode");
     e->stage_names.push_back("post/hist");
@@ -656,7 +711,9 @@ extern "C" int wz_op_info(wz_engine_t* e, int idx, char* name, int namelen, int*
     const WzOpDesc& o = e->ops[idx];
     if (name && namelen > 0) snprintf(name, namelen, "%s", o.name);
     if (dims) {
-        const int v[12] = {o.kind, o.cin, o.cout, o.ksize, o.stride, o.hin, o.win, o.hout, o.wout, o.n_pad, o.kc, 0};
+        // WZ_OP_MBCONV: cin = block input channels, slot 11 = depthwise (expanded) channels
+        const int v[12] = {o.kind, o.kind == WZ_OP_MBCONV ? (o.cin0 ? o.cin0 : o.cmid) : o.cin, o.cout, o.ksize, o.stride,
+                           o.hin, o.win, o.hout, o.wout, o.n_pad, o.kc, o.kind == WZ_OP_MBCONV ? o.cmid : 0};
         memcpy(dims, v, sizeof(v));
     }
     return WZ_OK;

@@ -8,9 +8,9 @@
 #include <stdint.h>
 
 #define WZ_MAGIC 0x35335A57u /* "WZ35" */
-#define WZ_FORMAT_VERSION 4u
+#define WZ_FORMAT_VERSION 5u
 
-enum WzOpKind { WZ_OP_STEM = 1, WZ_OP_DW = 2, WZ_OP_CONV = 3 };
+enum WzOpKind { WZ_OP_STEM = 1, WZ_OP_DW = 2, WZ_OP_CONV = 3, WZ_OP_MBCONV = 4 };
 enum WzOutMode { WZ_OUT_ACT = 0, WZ_OUT_BOX = 1, WZ_OUT_CLS = 2, WZ_OUT_HEAD = 3 };
 enum WzAct { WZ_ACT_NONE = 0, WZ_ACT_RELU6 = 1 };
 
@@ -34,7 +34,7 @@ struct WzTensorDesc {  // 64 bytes
     char name[48];
 };
 
-struct WzOpDesc {  // 192 bytes
+struct WzOpDesc {  // 256 bytes
     int32_t kind, src, dst, res;            // tensor indices, res = -1 when absent
     int32_t cin, cout, ksize, stride;
     int32_t hin, win, hout, wout;
@@ -44,7 +44,17 @@ struct WzOpDesc {  // 192 bytes
     int32_t kc;                             // 32-channel K chunks per filter tap (ceil(cin/32))
     int64_t w_off, b_off;                   // byte offsets from weights_off
     int32_t n_box;                          // WZ_OUT_HEAD: leading columns that go to the box-encoding buffer
-    int32_t reserved[7];
+    // WZ_OP_MBCONV (one inverted-residual block = [1x1 expand ->] depthwise 3x3 -> 1x1 project [+ residual]):
+    // cin/cout/n_pad/kc/w_off/b_off describe the PROJECT conv (cin = cmid); the fields below the rest.
+    int32_t cmid;                           // depthwise channels (= expanded channels)
+    int32_t cin0;                           // block input channels (expand K); 0 = no expand stage
+    int32_t kc0;                            // 32-channel K chunks of the expand conv
+    int32_t cmid_pad;                       // cmid rounded up to 32 (row length of the packed depthwise weights)
+    int32_t nmid_pad;                       // packed output columns of the expand conv
+    int32_t reserved[2];
+    int64_t we_off, be_off;                 // expand weights (WZ_OP_CONV layout, 1 tap) / float bias[nmid_pad]
+    int64_t wd_off, bd_off;                 // depthwise: half w[9][cmid_pad] / float bias[cmid_pad]
+    int64_t reserved2[4];
     char name[64];
 };
 #pragma pack(pop)
@@ -55,3 +65,4 @@ struct WzOpDesc {  // 192 bytes
 //  WZ_OP_CONV : half   w[n_pad/16][taps][kc][64 lanes][8]  where lane l of N-tile t holds
 //               W[k = chunk*32 + (l>>4)*8 + j][n = t*16 + (l&15)], zero beyond cin / cout
 //               (exactly the A-operand fragment of v_mfma_f32_16x16x32_f16), float bias[n_pad]
+//  WZ_OP_MBCONV: expand + project in the WZ_OP_CONV layout, depthwise as WZ_OP_DW with rows padded to cmid_pad

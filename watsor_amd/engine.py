@@ -24,7 +24,7 @@ from . import arch
 from .anchors import ssd_anchor_table
 
 MAGIC = 0x35335A57
-FORMAT_VERSION = 4
+FORMAT_VERSION = 5
 BN_EPSILON = 1e-3          # watsor/test/model/prepare.py:48
 
 DEFAULT_POST = dict(max_total=100, max_per_class=100, score_threshold=1e-8, iou_threshold=0.6,
@@ -69,6 +69,25 @@ def pack_conv_weights(w: np.ndarray, n_pad: int, kc: int) -> np.ndarray:
     return np.ascontiguousarray(wp).astype(np.float16).reshape(-1)
 
 
+OP_RECORD_BYTES = 256
+
+
+def _op_record(op, tindex, n_pad, kc, w_off, b_off, mb) -> bytes:
+    """struct WzOpDesc of csrc/wz_program.h."""
+    return struct.pack(
+        "<20i2q8i8q64s",
+        op.kind, tindex[op.src], tindex.get(op.dst, -1) if op.out_mode == arch.OUT_ACT else -1,
+        tindex[op.res] if op.res else -1,
+        op.cin, op.cout, op.k, op.stride,
+        op.hin, op.win, op.hout, op.wout,
+        op.pad_t, op.pad_l, op.act, op.out_mode,
+        op.anchor_offset, op.anchors_per_loc, n_pad, kc,
+        w_off, b_off,
+        op.n_box, mb["cmid"], mb["cin0"], mb["kc0"], mb["cmid_pad"], mb["nmid_pad"], 0, 0,
+        mb["we_off"], mb["be_off"], mb["wd_off"], mb["bd_off"], 0, 0, 0, 0,
+        op.scope.encode()[:63])
+
+
 def assign_slots(prog: "arch.Program", tensor_names: List[str]) -> List[int]:
     """Liveness-based buffer sharing: tensors whose lifetimes do not overlap reuse one HBM buffer."""
     index = {n: i for i, n in enumerate(tensor_names)}
@@ -106,15 +125,16 @@ def assign_slots(prog: "arch.Program", tensor_names: List[str]) -> List[int]:
 
 
 def build_engine(weights: Dict[str, np.ndarray], precision: int = 16, model_width: int = 300,
-                 model_height: int = 300, post: Optional[dict] = None) -> bytes:
-    """Returns the engine image.  Mirrors `build_engine` of watsor/engine.py:17-51."""
+                 model_height: int = 300, post: Optional[dict] = None, fuse: bool = True) -> bytes:
+    """Returns the engine image.  Mirrors `build_engine` of watsor/engine.py:17-51.
+    fuse=False keeps one op per layer (used by the per-layer parity tests; same results, slower)."""
     if precision != 16:
         raise ValueError("only -p 16 (fp16 storage, fp32 accumulate) is implemented on MI355X")
     if model_width != model_height:
         raise ValueError("square model input expected")
     cfg = dict(DEFAULT_POST)
     cfg.update(post or {})
-    prog = arch.build(model_width)
+    prog = arch.build(model_width, fuse=fuse)
     missing = [n for n in prog.variable_shapes() if n not in weights]
     if missing:
         raise KeyError("model is missing %d variables, e.g. %s" % (len(missing), missing[0]))
@@ -134,10 +154,36 @@ def build_engine(weights: Dict[str, np.ndarray], precision: int = 16, model_widt
         wblob.extend(arr.tobytes())
         return off
 
+    def put_conv(op):
+        w, b = fold_batch_norm(weights, op)
+        n_pad = _align(op.cout, 64 if op.cout >= 256 else 32)   # 64-wide wave tiles for the wide layers
+        kc = (op.cin + 31) // 32
+        w_off = put(pack_conv_weights(w.astype(np.float32), n_pad, kc))
+        bp = np.zeros(n_pad, np.float32)
+        bp[:op.cout] = b
+        return w_off, put(bp), n_pad, kc
+
     op_recs = []
     for op in prog.ops:
-        w, b = fold_batch_norm(weights, op)
         n_pad, kc = 0, 0
+        mb = dict(cmid=0, cin0=0, kc0=0, cmid_pad=0, nmid_pad=0, we_off=0, be_off=0, wd_off=0, bd_off=0)
+        if op.kind == arch.OP_MBCONV:
+            parts = list(op.parts)
+            if op.cin0:
+                ex = parts.pop(0)
+                mb["we_off"], mb["be_off"], mb["nmid_pad"], mb["kc0"] = put_conv(ex)
+            dw, pj = parts
+            wd, bd = fold_batch_norm(weights, dw)
+            cmid_pad = _align(op.cmid, 32)
+            wdp = np.zeros((9, cmid_pad), np.float16)
+            wdp[:, :op.cmid] = wd.reshape(9, op.cmid).astype(np.float16)
+            bdp = np.zeros(cmid_pad, np.float32)
+            bdp[:op.cmid] = bd
+            mb.update(cmid=op.cmid, cin0=op.cin0, cmid_pad=cmid_pad, wd_off=put(wdp), bd_off=put(bdp))
+            w_off, b_off, n_pad, kc = put_conv(pj)
+            op_recs.append(_op_record(op, tindex, n_pad, kc, w_off, b_off, mb))
+            continue
+        w, b = fold_batch_norm(weights, op)
         if op.kind == arch.OP_STEM:
             w_off = put(w.reshape(27, 32).astype(np.float32))
             b_off = put(b.astype(np.float32))
@@ -151,16 +197,8 @@ def build_engine(weights: Dict[str, np.ndarray], precision: int = 16, model_widt
             bp = np.zeros(n_pad, np.float32)
             bp[:op.cout] = b
             b_off = put(bp)
-        op_recs.append(struct.pack(
-            "<20i2q8i64s",
-            op.kind, tindex[op.src], tindex.get(op.dst, -1) if op.out_mode == arch.OUT_ACT else -1,
-            tindex[op.res] if op.res else -1,
-            op.cin, op.cout, op.k, op.stride,
-            op.hin, op.win, op.hout, op.wout,
-            op.pad_t, op.pad_l, op.act, op.out_mode,
-            op.anchor_offset, op.anchors_per_loc, n_pad, kc,
-            w_off, b_off, op.n_box, *([0] * 7), op.scope.encode()[:63]))
-    assert all(len(r) == 192 for r in op_recs)
+        op_recs.append(_op_record(op, tindex, n_pad, kc, w_off, b_off, mb))
+    assert all(len(r) == OP_RECORD_BYTES for r in op_recs)
 
     tensor_recs = []
     for n, s in zip(tensor_names, slots):
@@ -173,7 +211,7 @@ def build_engine(weights: Dict[str, np.ndarray], precision: int = 16, model_widt
     header_size = 160
     tensors_off = _align(header_size)
     ops_off = _align(tensors_off + 64 * len(tensor_recs))
-    anchors_off = _align(ops_off + 192 * len(op_recs))
+    anchors_off = _align(ops_off + OP_RECORD_BYTES * len(op_recs))
     weights_off = _align(anchors_off + anchors.nbytes)
     total = weights_off + len(wblob)
     sy, sx, sh, sw = cfg["scales"]
@@ -189,7 +227,7 @@ def build_engine(weights: Dict[str, np.ndarray], precision: int = 16, model_widt
     out = bytearray(total)
     out[:header_size] = header
     out[tensors_off:tensors_off + 64 * len(tensor_recs)] = b"".join(tensor_recs)
-    out[ops_off:ops_off + 192 * len(op_recs)] = b"".join(op_recs)
+    out[ops_off:ops_off + OP_RECORD_BYTES * len(op_recs)] = b"".join(op_recs)
     out[anchors_off:anchors_off + anchors.nbytes] = anchors.tobytes()
     out[weights_off:] = wblob
     return bytes(out)

@@ -183,7 +183,7 @@ class HipEngine:
         out = []
         name = C.create_string_buffer(80)
         dims = (C.c_int32 * 12)()
-        keys = ("kind", "cin", "cout", "ksize", "stride", "hin", "win", "hout", "wout", "n_pad", "kc", "splitk")
+        keys = ("kind", "cin", "cout", "ksize", "stride", "hin", "win", "hout", "wout", "n_pad", "kc", "cmid")
         for i in range(self._lib.wz_num_ops(self._h)):
             _lib.check(self._lib.wz_op_info(self._h, i, name, 80, dims))
             d = dict(zip(keys, list(dims)))

@@ -17,7 +17,7 @@ from . import arch
 
 
 def synthetic_weights(seed: int = 1234, program: "arch.Program | None" = None) -> Dict[str, np.ndarray]:
-    prog = program or arch.build()
+    prog = program or arch.build(fuse=False)   # one op per layer: the draw order of the RNG is part of the seed
     rng = np.random.Generator(np.random.PCG64(seed))
     W: Dict[str, np.ndarray] = {}
 
