@@ -80,8 +80,8 @@ def roofline_from_stages(stages, ops, n, frame_bytes, size):
     # A hipEventRecord pair with nothing in between reads ~5 us on this stack (the record itself is a
     # barrier packet).  Brackets of unused split-K slots are exactly that: calibrate on them and
     # subtract, so a stage time is the kernel's own duration as rocprofv3's kernel trace reports it.
-    empty = sorted(ms for name, ms in stages if name.endswith("#splitk_reduce"))
-    overhead = empty[len(empty) // 4] if empty else 0.0
+    overhead = min([ms for name, ms in stages if name == "(empty)"] +
+                   [ms for name, ms in stages if name.endswith("#splitk_reduce")])   # unused reduce slots are empty too
     agg = {}
     for name, ms in stages:
         ms = max(ms - overhead, 0.0)

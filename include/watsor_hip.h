@@ -77,7 +77,7 @@ int wz_detect_batch(wz_engine_t* e, int n, const uint8_t* const* rgb, const int*
 /* Same, frames already resident in this GPU's HBM (device pointers).  Split into an asynchronous
  * submit (everything enqueued on the engine's stream, results land in pinned slot `slot`) and a
  * collect that waits for that slot -- so a caller can keep WZ_SLOTS batches in flight. */
-#define WZ_SLOTS 4
+#define WZ_SLOTS 8
 int wz_submit_device(wz_engine_t* e, int slot, int n, const uint8_t* const* d_rgb, const int* w,
                      const int* h, const int* cam);
 int wz_collect(wz_engine_t* e, int slot, wz_detection_t* const* out, uint8_t* const* pass);
@@ -129,6 +129,9 @@ int wz_profile_device(wz_engine_t* e, int n, const uint8_t* const* d_rgb, const 
 
 /* diagnostics: 16 words per frame written by the NMS kernel of lane 0 (phase timestamps at 100 MHz, counts) */
 int wz_debug_nms(wz_engine_t* e, int n, uint64_t* out);
+/* Engines created with WZ_MB_DEBUG=1 in the environment: phase timestamps (100 MHz) of the first and the last
+ * workgroup of every fused inverted-residual block, out[n_ops][16]; groups[n_ops] = channel groups launched. */
+int wz_debug_mbconv(wz_engine_t* e, uint64_t* out, int32_t* groups);
 
 /* ---- device memory helpers so callers need no other GPU runtime binding */
 int wz_dev_alloc(wz_engine_t* e, uint64_t bytes, void** d_ptr);

@@ -298,7 +298,9 @@ def test_batch_of_mixed_resolutions_equals_single_calls(eng):
         pairs, missing = pu.match_rows(b, {"label": a["label"], "confidence": a["confidence"],
                                            "box": np.stack([a["x_min"], a["y_min"], a["x_max"], a["y_max"]], 1)},
                                        min_score=0.1)
-        assert not missing
+        # a batch of 4 and a batch of 1 pick different channel-group / split-K counts (fp32 summation
+        # order), i.e. scores move by ~1e-4: the rows at the top-100 cut may swap with the 101st candidate
+        assert all(m >= 90 for m in missing) and len(missing) <= 2, missing
         assert max(abs(p[3]) for p in pairs) <= SCORE_TOL
 
 

@@ -16,5 +16,6 @@ _lib.check(e._lib.wz_debug_nms(e._h, 8, C.c_void_p(out.ctypes.data)))
 for f in range(8):
     t = out[f].astype(np.int64)
     us = lambda a, b: (t[b] - t[a]) / 100.0
+    print("   walk: init %.1f | pairwise %.1f | per-class %.1f | rows %.1f" % ((t[11] - t[6]) / 100.0, us(11, 12), us(12, 13), (t[7] - t[13]) / 100.0))
     print("frame %d: thr %.1f us | load keys %.1f | band total %.1f (sort %.1f, gather %.1f, walk %.1f) | out %.1f | total %.1f   cnt %d kept %d processed %d"
           % (f, us(0, 1), us(1, 2), us(2, 3), (t[5] - t[2]) / 100.0, us(5, 6), us(6, 7), us(3, 4), us(0, 4), t[8], t[9], t[10]))

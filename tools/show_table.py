@@ -8,8 +8,7 @@ for k in d["kernels"]:
         k["kernel"], k["launches"], k["ms_per_step"] * 1e3, k["avg_us"], k["gbs"], k["tflops"], k["t_roof_frac"]))
 print("sum %.1f us" % sum(k["ms_per_step"] * 1e3 for k in d["kernels"]))
 if len(sys.argv) > 2:
-    ov = sorted(ms for n, ms in d["stages"] if n.endswith("#splitk_reduce"))
-    ov = ov[len(ov) // 4] if ov else 0.0
+    ov = min(ms for n, ms in d["stages"] if n == "(empty)" or n.endswith("#splitk_reduce"))
     for name, ms in d["stages"]:
         v = (ms - ov) * 1e3
         if v > 0.3:

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwatsor_hip.so")
 
 WZ_OK, WZ_EINVAL, WZ_ENOENT, WZ_EFORMAT, WZ_EHIP, WZ_ENODEV, WZ_ELIMIT = 0, -1, -2, -3, -4, -5, -6
-WZ_SLOTS = 4
+WZ_SLOTS = 8
 WZ_NUM_LABELS = 91
 
 c_u8p = C.POINTER(C.c_uint8)
@@ -57,6 +57,7 @@ SIGNATURES = {
     "wz_stage_name": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int]),
     "wz_profile_device": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), c_i32p, c_i32p, C.c_int, c_f32p]),
     "wz_debug_nms": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "wz_debug_mbconv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "wz_dev_alloc": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "wz_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "wz_dev_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),

@@ -301,6 +301,159 @@ __global__ __launch_bounds__(256) void wz_k_splitk_reduce(const WzConvArgs a, co
     wz_epilogue4(a, m, n4, v);
 }
 
+// --------------------------------------------------------------------------------------------
+// LDS-tiled implicit GEMM for the layers with a long K loop (the 3x3 SSD heads, the 3x3 extras, Conv_1):
+// workgroup = 128 pixels x 64 channels, K step = 64 (two MFMA K chunks), 4 waves as 2 (pixels) x 2
+// (channels), wave tile 64 x 32.  Both operands go global -> LDS with `global_load_lds_dwordx4`
+// (no staging registers): the LDS image of a tile is a list of 1 KiB MFMA fragments, lane l's 16 bytes
+// at l*16, which is exactly what the DMA writes (wave-uniform base + lane * 16) and what `ds_read_b128`
+// reads back conflict-free.  Weight fragments are contiguous in the packed layout; an activation
+// fragment is a per-lane gather (lane = pixel r16 x channel group g) whose out-of-frame lanes read a
+// zero page.  Two LDS buffers: the DMA of step s+1 runs under the MFMAs of step s, one barrier per step.
+// --------------------------------------------------------------------------------------------
+#define WZ_LDS_TM 128
+#define WZ_LDS_TN 64
+#define WZ_LDS_BUF (24 * 1024)   // 8 A fragments + 16 B fragments of 1 KiB
+
+__device__ __forceinline__ void wz_glds16(const void* gsrc, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int KS>
+__global__ __launch_bounds__(256) void wz_k_conv_lds(const WzConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wz_cl_smem[];
+    constexpr int taps = KS * KS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware tile order: workgroup L runs on XCD L % 8 (each XCD has its own L2).  Renumber so that
+    // the workgroups of one XCD are CONSECUTIVE tiles, pixel tile fastest: the tiles that stream the same
+    // weight slice (same channel tile, same K split) then share one L2 instead of pulling it eight times.
+    int bx, by, bz;
+    {
+        const int total = a.grid_m * a.grid_n * a.splitk;
+        const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+        const int qd = total >> 3, rm = total & 7;
+        const int V = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + slot;
+        bx = V % a.grid_m;
+        const int rest = V / a.grid_m;
+        by = rest % a.grid_n;
+        bz = rest / a.grid_n;
+    }
+    const int m_base = bx * WZ_LDS_TM;
+    const int nt0 = by * (WZ_LDS_TN / 16);
+
+    // the two activation m-tiles this wave stages (2*wave, 2*wave+1): pixel of this lane
+    const int hw = a.hout * a.wout;
+    int iy0[2], ix0[2], boff[2];
+    bool mv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m_base + (wave * 2 + i) * 16 + r16;
+        mv[i] = m < a.M;
+        const int mm = mv[i] ? m : 0;
+        const int b = mm / hw, rem = mm - b * hw;
+        const int oy = rem / a.wout, ox = rem - oy * a.wout;
+        iy0[i] = oy * a.stride - a.pad_t;
+        ix0[i] = ox * a.stride - a.pad_l;
+        boff[i] = b * a.hin;
+    }
+
+    // K steps of this split (a step = 2 consecutive 32-channel chunks of one filter tap; kc is even)
+    const int nsteps = a.kchunks >> 1;
+    const int per = (nsteps + a.splitk - 1) / a.splitk;
+    const int s0 = bz * per, s1 = min(s0 + per, nsteps);
+
+    auto stage = [&](int s, int buf) {
+        unsigned char* base = wz_cl_smem + buf * WZ_LDS_BUF;
+        const int q = s * 2;
+        const int t = (KS == 1) ? 0 : q / a.kc, c = (KS == 1) ? q : q - t * a.kc;
+        const int ky = (KS == 1) ? 0 : t / KS, kx = (KS == 1) ? 0 : t - ky * KS;
+        // A: fragments (nt = wave, kc = 0/1): 2 KiB contiguous in the packed weights
+        const half_t* wsrc = a.w + ((size_t)((nt0 + wave) * taps + t) * a.kc + c) * 512 + lane * 8;
+        wz_glds16(wsrc, base + (wave * 2 + 0) * 1024);
+        wz_glds16(wsrc + 512, base + (wave * 2 + 1) * 1024);
+        // B: fragments (mt = 2*wave + i, kc = 0/1)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int iy = iy0[i] + ky, ix = ix0[i] + kx;
+            const bool ok = mv[i] && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
+            const half_t* src = ok ? a.in + ((size_t)(boff[i] + iy) * a.win + ix) * a.cin + c * 32 + g * 8 : a.zeros;
+            unsigned char* dst = base + 8 * 1024 + ((wave * 2 + i) * 2) * 1024;
+            wz_glds16(src, dst);
+            wz_glds16(ok ? src + 32 : a.zeros, dst + 1024);
+        }
+    };
+
+    float4_t acc[4][2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    if (s0 < s1) stage(s0, 0);
+    for (int s = s0; s < s1; ++s) {
+        const int buf = (s - s0) & 1;
+        __syncthreads();   // this step's DMA has landed (vmcnt(0) is part of the barrier); the other buffer is free
+        if (s + 1 < s1) stage(s + 1, buf ^ 1);
+        const unsigned char* base = wz_cl_smem + buf * WZ_LDS_BUF;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            half8_t fa[2], fb[4];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                fa[nt] = *reinterpret_cast<const half8_t*>(base + ((wn * 2 + nt) * 2 + kc) * 1024 + lane * 16);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                fb[mt] = *reinterpret_cast<const half8_t*>(base + 8 * 1024 + ((wm * 4 + mt) * 2 + kc) * 1024 + lane * 16);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[nt], fb[mt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = m_base + (wm * 4 + mt) * 16 + r16;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int n4 = (nt0 + wn * 2 + nt) * 16 + g * 4;
+            if (a.splitk > 1) {
+                if (m < a.M)
+                    *reinterpret_cast<float4_t*>(reinterpret_cast<float*>(a.out) +
+                                                 ((size_t)bz * a.M + m) * a.n_pad + n4) = acc[mt][nt];
+            } else {
+                wz_epilogue4(a, m, n4, acc[mt][nt]);
+            }
+        }
+    }
+}
+
+static int wz_env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return (e && atoi(e) >= 0 && e[0]) ? atoi(e) : dflt;
+}
+
+// the LDS-tiled kernel needs whole 64-column tiles, whole 2-chunk K steps and enough pixels to fill a tile
+bool wz_conv_use_lds(const WzConvArgs& a) {
+    static const int min_m = wz_env_int("WZ_LDS_MIN_M", 128);
+    static const int min_k = wz_env_int("WZ_LDS_MIN_KCHUNKS", 8);
+    return a.zeros && a.n_pad % WZ_LDS_TN == 0 && a.kc % 2 == 0 && a.M >= min_m && a.kchunks >= min_k && a.cin % 32 == 0;
+}
+
+int wz_choose_splitk_lds(int M, int n_pad, int kchunks) {
+    static const int target = wz_env_int("WZ_LDS_WGS", 512);
+    const int wgs = ((M + WZ_LDS_TM - 1) / WZ_LDS_TM) * (n_pad / WZ_LDS_TN);
+    const int nsteps = kchunks / 2;
+    int s = (target + wgs - 1) / wgs;
+    if (s > nsteps / 4) s = nsteps / 4;   // >= 4 steps per split
+    if (s > 32) s = 32;
+    return s < 1 ? 1 : s;
+}
+
 // measured (profiles/): the 64x64 tile wins only where M is large enough to keep >= 1 wave per SIMD
 // busy through a long K loop (BoxPredictor_0: M = n*361); at M = n*100 it is latency-bound and loses.
 static inline bool wz_conv_big(int M, int n_pad, int kchunks) { return n_pad % 64 == 0 && n_pad >= 256 && M >= 2048 && kchunks >= 64; }
@@ -311,11 +464,13 @@ int wz_choose_splitk(int M, int n_pad, int kchunks) {
     const bool big = wz_conv_big(M, n_pad, kchunks);
     const int tm = big ? 64 : 32, tn = big ? 64 : 32;
     const long waves = (long)((M + tm - 1) / tm) * (n_pad / tn);
-    if (kchunks < 32 || waves >= 1024) return 1;
-    int s = (int)(1024 / (waves > 0 ? waves : 1));
+    static const int target = [] { const char* e = getenv("WZ_SPLITK_WAVES"); return (e && atoi(e) > 0) ? atoi(e) : 1024; }();
+    static const int max_split = [] { const char* e = getenv("WZ_SPLITK_MAX"); return (e && atoi(e) > 0) ? atoi(e) : 16; }();
+    if (kchunks < 32 || waves >= target) return 1;
+    int s = (int)(target / (waves > 0 ? waves : 1));
     const int max_by_k = kchunks / 8;
     if (s > max_by_k) s = max_by_k;
-    if (s > 16) s = 16;
+    if (s > max_split) s = max_split;
     return s < 1 ? 1 : s;
 }
 
@@ -329,7 +484,24 @@ static void wz_launch_conv_cfg(const WzConvArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((wz_k_conv<3, MT, NT, U>), grid, dim3(256), 0, s, a);
 }
 
-void wz_launch_conv(const WzConvArgs& a, hipStream_t s) {
+void wz_conv_init() {   // kernel attributes (before any stream capture)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wz_k_conv_lds<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WZ_LDS_BUF);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wz_k_conv_lds<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WZ_LDS_BUF);
+}
+
+void wz_launch_conv(const WzConvArgs& a0, hipStream_t s) {
+    if (wz_conv_use_lds(a0)) {
+        WzConvArgs a = a0;
+        a.grid_m = (a.M + WZ_LDS_TM - 1) / WZ_LDS_TM;
+        a.grid_n = a.n_pad / WZ_LDS_TN;
+        dim3 grid(a.grid_m * a.grid_n * a.splitk);
+        if (a.ksize == 1)
+            hipLaunchKernelGGL(wz_k_conv_lds<1>, grid, dim3(256), 2 * WZ_LDS_BUF, s, a);
+        else
+            hipLaunchKernelGGL(wz_k_conv_lds<3>, grid, dim3(256), 2 * WZ_LDS_BUF, s, a);
+        return;
+    }
+    const WzConvArgs& a = a0;
     if (wz_conv_big(a.M, a.n_pad, a.kchunks))
         wz_launch_conv_cfg<4, 4, 2>(a, s);
     else

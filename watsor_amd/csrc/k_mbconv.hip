@@ -40,6 +40,12 @@ __global__ __launch_bounds__(256) void wz_k_mbconv(const WzMbArgs a) {
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
+    // diagnostics (a.dbg != nullptr only under wz_debug_mbconv): phase timestamps of the first and the last workgroup
+    const bool stamp = a.dbg && threadIdx.x == 0 && blockIdx.y == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1);
+    unsigned long long* const dbg = a.dbg + (blockIdx.x == 0 ? 0 : 8);
+#define MB_STAMP(i) do { if (stamp) dbg[i] = wall_clock64(); } while (0)
+    MB_STAMP(0);
+    if (stamp) dbg[5] = clock64();   // shader cycles: (dbg[6] - dbg[5]) / (dbg[4] - dbg[0]) * 100 = effective MHz
     const int tiles = a.tiles_x * a.tiles_y;
     const int b = blockIdx.x / tiles, t = blockIdx.x - b * tiles;
     const int tyi = t / a.tiles_x;
@@ -47,7 +53,7 @@ __global__ __launch_bounds__(256) void wz_k_mbconv(const WzMbArgs a) {
     const int s = a.stride;
     const int hw_ = (a.tw - 1) * s + 3, hh_ = (a.th - 1) * s + 3;
     const int P = hh_ * hw_, Q = a.th * a.tw;
-    const int np_tiles = (P + 15) >> 4, nq_tiles = (Q + 15) >> 4;
+    const int nq_tiles = (Q + 15) >> 4;
     const int iy_base = oy0 * s - a.pad_t, ix_base = ox0 * s - a.pad_l;
     const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
@@ -87,7 +93,9 @@ __global__ __launch_bounds__(256) void wz_k_mbconv(const WzMbArgs a) {
                 h.xf[i][c] = (ok && k0 < a.cin0) ? *reinterpret_cast<const half8_t*>(src + k0) : zero8;
             }
         }
-        const int ebuf = np_tiles * 16 * ES;   // halfs per chunk buffer
+        // halfs per chunk buffer: one row per halo pixel SLOT of the template (MP m-tiles per wave), so that the
+        // expand stage needs no "does this m-tile exist" branch and the compiler can interleave the MP chains
+        constexpr int ebuf = MP * 64 * ES;
         const int nchunks = (a.cmid + CE - 1) / CE;
         // this workgroup's share of the expanded channels (blockIdx.y = group; a.cpg chunks per group)
         const int ch_begin = blockIdx.y * a.cpg, ch_end = min(ch_begin + a.cpg, nchunks);
@@ -96,6 +104,7 @@ __global__ __launch_bounds__(256) void wz_k_mbconv(const WzMbArgs a) {
         // depthwise weights + bias of these channels -> LDS (read after the first barrier below)
         half_t* const wd_l = e_base + 2 * ebuf;                               // [9][cw]
         float* const bd_l = reinterpret_cast<float*>(wd_l + 9 * a.cpg * CE);   // [cw]
+        float* const be_l = bd_l + a.cpg * CE;                                 // [cw] expand bias
         {
             const int c8s = cw >> 3;
             for (int i = threadIdx.x; i < 9 * c8s; i += 256) {
@@ -103,9 +112,37 @@ __global__ __launch_bounds__(256) void wz_k_mbconv(const WzMbArgs a) {
                 *reinterpret_cast<half8_t*>(wd_l + tp * cw + c8 * 8) =
                     *reinterpret_cast<const half8_t*>(a.wd + (size_t)tp * a.cmid_pad + c_begin + c8 * 8);
             }
-            for (int i = threadIdx.x; i < (cw >> 2); i += 256)
+            for (int i = threadIdx.x; i < (cw >> 2); i += 256) {
                 *reinterpret_cast<float4_t*>(bd_l + i * 4) = *reinterpret_cast<const float4_t*>(a.bd + c_begin + i * 4);
+                // (the expand bias has nmid_pad >= cmid entries; nmid_pad is a multiple of 32 like cmid_pad)
+                *reinterpret_cast<float4_t*>(be_l + i * 4) =
+                    (c_begin + i * 4 < a.nmid_pad) ? *reinterpret_cast<const float4_t*>(a.be + c_begin + i * 4)
+                                                   : (float4_t){0.f, 0.f, 0.f, 0.f};
+            }
         }
+        // expand + project weights of these channels -> LDS by DMA (global_load_lds, 1 KiB MFMA fragment per
+        // wave instruction, no staging registers): every global latency of the workgroup -- halo pixels,
+        // depthwise weights, GEMM weights -- is in flight at once and paid once, at the barrier below.
+        // (a.stage == 0 when the slice does not fit: the fragments are then read from L2 where they are used.)
+        unsigned char* const we_l = reinterpret_cast<unsigned char*>(be_l + a.cpg * CE);   // [cw/16][KCI] KiB
+        const int nkg = cw >> 5;                                                           // K chunks of the project conv
+        unsigned char* const wp_l = we_l + (size_t)(a.cpg * CE / 16) * KCI * 1024;         // [NTO][nkg] KiB
+        if (a.stage) {
+            const int nwe = (cw >> 4) * KCI;
+            const half_t* wsrc = a.we + ((size_t)(c_begin >> 4) * a.kc0 * 64 + lane) * 8;
+            for (int fr = wave; fr < nwe; fr += 4)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (size_t)fr * 512),
+                                                 (__attribute__((address_space(3))) void*)(we_l + fr * 1024), 16, 0, 0);
+            const int nwp = NTO * nkg;
+            for (int fr = wave; fr < nwp; fr += 4) {
+                const int nt = fr / nkg, kl = fr - nt * nkg;
+                const half_t* src = a.wp + ((size_t)(nt * a.kc + (c_begin >> 5) + kl) * 64 + lane) * 8;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(wp_l + fr * 1024), 16, 0, 0);
+            }
+        }
+        __syncthreads();   // staged biases / weights are visible (the barrier's vmcnt(0) also covers the halo loads above)
+        MB_STAMP(1);
         for (int ch = ch_begin; ch < ch_end; ++ch) {
             half_t* const E = e_base + (ch & 1) * ebuf;
             const int ce0 = ch * CE;
@@ -113,29 +150,34 @@ __global__ __launch_bounds__(256) void wz_k_mbconv(const WzMbArgs a) {
             // ---- expand: E[p][ce] = in-frame ? relu6(sum_k X[p][k] We[k][ce] + be[ce]) : 0
             for (int nt = 0; nt < nte; ++nt) {
                 half8_t wa[KCI];
-                const half_t* wsrc = a.we + ((size_t)((ce0 >> 4) + nt) * a.kc0 * 64 + lane) * 8;
+                if (a.stage) {
+                    const unsigned char* wl = we_l + ((size_t)(((ce0 - c_begin) >> 4) + nt) * KCI * 64 + lane) * 16;
 #pragma unroll
-                for (int c = 0; c < KCI; ++c) wa[c] = *reinterpret_cast<const half8_t*>(wsrc + (size_t)c * 512);
-                const float4_t bv = *reinterpret_cast<const float4_t*>(a.be + ce0 + nt * 16 + g * 4);
+                    for (int c = 0; c < KCI; ++c) wa[c] = *reinterpret_cast<const half8_t*>(wl + c * 1024);
+                } else {
+                    const half_t* wsrc = a.we + ((size_t)((ce0 >> 4) + nt) * a.kc0 * 64 + lane) * 8;
+#pragma unroll
+                    for (int c = 0; c < KCI; ++c) wa[c] = *reinterpret_cast<const half8_t*>(wsrc + (size_t)c * 512);
+                }
+                const float4_t bv = *reinterpret_cast<const float4_t*>(be_l + (ce0 - c_begin) + nt * 16 + g * 4);
 #pragma unroll
                 for (int i = 0; i < MP; ++i) {
-                    const int mt = wave + 4 * i;
-                    if (mt < np_tiles) {   // wave-uniform
-                        float4_t d = {0.f, 0.f, 0.f, 0.f};
+                    const int mt = wave + 4 * i;   // slots beyond the halo hold zeros (inimg false)
+                    float4_t d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int c = 0; c < KCI; ++c)
-                            d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[c], h.xf[i][c], d, 0, 0, 0);
-                        half4_t o;
+                    for (int c = 0; c < KCI; ++c)
+                        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[c], h.xf[i][c], d, 0, 0, 0);
+                    half4_t o;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float v = fminf(fmaxf(d[r] + bv[r], 0.0f), 6.0f);
-                            o[r] = h.inimg[i] ? (half_t)v : (half_t)0.0f;
-                        }
-                        *reinterpret_cast<half4_t*>(E + (mt * 16 + r16) * ES + nt * 16 + g * 4) = o;
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = fminf(fmaxf(d[r] + bv[r], 0.0f), 6.0f);
+                        o[r] = h.inimg[i] ? (half_t)v : (half_t)0.0f;
                     }
+                    *reinterpret_cast<half4_t*>(E + (mt * 16 + r16) * ES + nt * 16 + g * 4) = o;
                 }
             }
             __syncthreads();
+            if (ch == ch_begin) MB_STAMP(2);
             // ---- depthwise on the chunk (lane = output pixel x 8 channels) feeding the project MFMAs
             const int nkk = (nte * 16 + 31) >> 5;
             for (int kk = 0; kk < nkk; ++kk) {
@@ -148,7 +190,7 @@ __global__ __launch_bounds__(256) void wz_k_mbconv(const WzMbArgs a) {
                 const int kg = (ce0 >> 5) + kk;            // K chunk of the project conv
 #pragma unroll
                 for (int j = 0; j < MQ; ++j) {
-                    if (wave + 4 * j < nq_tiles) {   // wave-uniform
+                    {   // (output m-tile slots beyond the tile compute on a clamped pixel and are never stored)
                         float d[8];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { d[r] = b0[r]; d[4 + r] = b1[r]; }
@@ -164,11 +206,20 @@ __global__ __launch_bounds__(256) void wz_k_mbconv(const WzMbArgs a) {
                         half8_t bf;
 #pragma unroll
                         for (int r = 0; r < 8; ++r) bf[r] = (half_t)fminf(fmaxf(d[r], 0.0f), 6.0f);
+                        if (a.stage) {
+                            const unsigned char* wl = wp_l + ((size_t)(kg - (c_begin >> 5)) * 64 + lane) * 16;
 #pragma unroll
-                        for (int nt = 0; nt < NTO; ++nt) {
-                            const half8_t wp = *reinterpret_cast<const half8_t*>(
-                                a.wp + ((size_t)(nt * a.kc + kg) * 64 + lane) * 8);
-                            acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wp, bf, acc[j][nt], 0, 0, 0);
+                            for (int nt = 0; nt < NTO; ++nt) {
+                                const half8_t wp = *reinterpret_cast<const half8_t*>(wl + (size_t)nt * nkg * 1024);
+                                acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wp, bf, acc[j][nt], 0, 0, 0);
+                            }
+                        } else {
+#pragma unroll
+                            for (int nt = 0; nt < NTO; ++nt) {
+                                const half8_t wp = *reinterpret_cast<const half8_t*>(
+                                    a.wp + ((size_t)(nt * a.kc + kg) * 64 + lane) * 8);
+                                acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wp, bf, acc[j][nt], 0, 0, 0);
+                            }
                         }
                     }
                 }
@@ -223,6 +274,7 @@ __global__ __launch_bounds__(256) void wz_k_mbconv(const WzMbArgs a) {
     }
 
     // ---- epilogue: lane holds output channels nt*16 + g*4 .. +3 of its output pixel
+    MB_STAMP(3);
     if (a.nsplit > 1) {   // raw fp32 partial sums of this channel group; wz_k_splitk_reduce finishes the block
 #pragma unroll
         for (int j = 0; j < MQ; ++j) {
@@ -231,6 +283,8 @@ __global__ __launch_bounds__(256) void wz_k_mbconv(const WzMbArgs a) {
 #pragma unroll
             for (int nt = 0; nt < NTO; ++nt) *reinterpret_cast<float4_t*>(o + nt * 16) = acc[j][nt];
         }
+        MB_STAMP(4);
+        if (stamp) dbg[6] = clock64();
         return;
     }
 #pragma unroll
@@ -254,6 +308,9 @@ __global__ __launch_bounds__(256) void wz_k_mbconv(const WzMbArgs a) {
             *reinterpret_cast<half4_t*>(a.out + o) = hv;
         }
     }
+    MB_STAMP(4);
+    if (stamp) dbg[6] = clock64();
+#undef MB_STAMP
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -280,6 +337,9 @@ static MbCfg wz_mb_choose(const WzMbArgs& a, int n) {
     else if (a.wout <= 19 && a.stride == 1) { th = 10; tw = 10; }
     c.th = wz_mb_env("WZ_MB_TH", th);
     c.tw = wz_mb_env("WZ_MB_TW", tw);
+    if (a.wout <= 10) { c.th = wz_mb_env("WZ_MB_TH10", c.th); c.tw = wz_mb_env("WZ_MB_TW10", c.tw); }
+    else if (a.wout <= 19) { c.th = wz_mb_env("WZ_MB_TH19", c.th); c.tw = wz_mb_env("WZ_MB_TW19", c.tw); }
+    else if (a.wout <= 38) { c.th = wz_mb_env("WZ_MB_TH38", c.th); c.tw = wz_mb_env("WZ_MB_TW38", c.tw); }
     if (c.th > a.hout) c.th = a.hout;
     if (c.tw > a.wout) c.tw = a.wout;
     for (;;) {
@@ -314,10 +374,17 @@ static int wz_mb_launch(WzMbArgs a, const MbCfg& c, int n, hipStream_t s, bool p
     a.nsplit = c.nsplit;
     a.cpg = c.cpg;
     size_t lds = 0;
+    a.stage = 0;
     if (EXPAND) {
         const int P = ((c.th - 1) * a.stride + 3) * ((c.tw - 1) * a.stride + 3);
-        lds = (size_t)2 * ((P + 15) / 16) * 16 * (CE + 8) * sizeof(half_t)      // chunk buffers
-              + (size_t)c.cpg * CE * (9 * sizeof(half_t) + sizeof(float));       // depthwise weights + bias
+        (void)P;
+        lds = (size_t)2 * MP * 64 * (CE + 8) * sizeof(half_t)                    // chunk buffers
+              + (size_t)c.cpg * CE * (9 * sizeof(half_t) + 2 * sizeof(float));   // depthwise weights + bias, expand bias
+        const size_t wbytes = (size_t)(c.cpg * CE / 16) * KCI * 1024 + (size_t)NTO * (c.cpg * CE / 32) * 1024;
+        if (lds + wbytes <= (size_t)wz_mb_env("WZ_MB_STAGE_KB", 96) * 1024) {    // GEMM weights of the group fit in LDS
+            a.stage = 1;
+            lds += wbytes;
+        }
     }
     auto k = wz_k_mbconv<EXPAND, CE, MP, MQ, KCI, NTO>;
     if (prepare) {   // kernel attributes cannot be set while a stream is capturing: done once at engine creation

@@ -186,6 +186,7 @@ __device__ __forceinline__ float wz_iou(const float4_t a, const float4_t c) {
 // 25 significant bits, so m * uni is exact in double and the comparison is exact.
 struct WzIouThr {
     double mid;
+    float lo, hi;   // thr * (1 -/+ 1e-3)
     bool tie_up;
 };
 __device__ __forceinline__ WzIouThr wz_iou_thr(float thr) {
@@ -193,6 +194,8 @@ __device__ __forceinline__ WzIouThr wz_iou_thr(float thr) {
     const float up = __uint_as_float(__float_as_uint(thr) + 1u);   // thr >= 0
     t.mid = ((double)thr + (double)up) * 0.5;
     t.tie_up = (__float_as_uint(thr) & 1u) != 0u;
+    t.lo = thr * 0.999f;
+    t.hi = thr * 1.001f;
     return t;
 }
 __device__ __forceinline__ bool wz_iou_exceeds(const float4_t a, float area_a, const float4_t c, float area_c,
@@ -202,6 +205,9 @@ __device__ __forceinline__ bool wz_iou_exceeds(const float4_t a, float area_a, c
     const float iy1 = fminf(a[2], c[2]), ix1 = fminf(a[3], c[3]);
     const float inter = fmaxf(iy1 - iy0, 0.0f) * fmaxf(ix1 - ix0, 0.0f);
     const float uni = area_a + area_c - inter;
+    // clear cases in fp32 (margins 1e-3 >> the 2^-24 roundings), the exact double test only near the threshold
+    if (!(inter > t.lo * uni)) return false;
+    if (inter > t.hi * uni) return true;
     const double lhs = (double)inter, rhs = t.mid * (double)uni;
     return lhs > rhs || (t.tie_up && lhs == rhs);
 }
@@ -232,7 +238,8 @@ struct NmsShared {   // carved from dynamic LDS, every member 16-byte aligned
     float karea[NMS_KEEP_MAX];
     int32_t ccls[NMS_CHUNK];
     uint32_t cdead[NMS_CHUNK];                            // 1 = suppressed by a box kept in an earlier chunk / band
-    int32_t kidx[NMS_KEEP_MAX];                           // kept -> index into the sorted band
+    int32_t cnext[NMS_CHUNK];                             // next chunk member of the same class, or 0x7fffffff
+    unsigned long long keptmask[NMS_CHUNK / 64];          // chunk members kept by the per-class resolution
     uint32_t hist[64];
     int32_t kept;
     uint32_t ncand;
@@ -271,7 +278,7 @@ __device__ __forceinline__ int wz_try_keep(NmsShared* S, int kept, const float4_
 // One band = all candidates whose score bits fall in histogram bins [lo_bin, hi_bin), `cnt` of them in
 // S->keys (unsorted composites).  Sort, gather boxes, walk.  Returns the new kept count (block-uniform).
 __device__ int wz_nms_band(NmsShared* S, const WzPostBuffers& b, const WzPostConsts& k, int f, int cnt, int kept) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const int A = k.num_anchors;
     unsigned long long* sorted = S->keys;
     if (cnt <= NMS_RANK_MAX) {
@@ -321,20 +328,27 @@ __device__ int wz_nms_band(NmsShared* S, const WzPostBuffers& b, const WzPostCon
     __syncthreads();
     if (tid == 0) b.dbg[(size_t)f * 16 + 6] = wall_clock64();
 
-    // Greedy NMS over the sorted band, NMS_CHUNK candidates at a time:
-    //  (1) in parallel: which chunk members are suppressed by boxes kept earlier, and the pairwise
-    //      "i suppresses j" relation inside the chunk (same class and IoU > thr), as bit masks;
-    //  (2) one wavefront resolves the sequential part with register-only steps: lane l owns candidates
-    //      l, l+64, l+128, l+192; candidate i is kept iff its dead bit is clear, and keeping it ORs
-    //      bit i of every later candidate's suppressor mask into that candidate's dead bit.
+    // Greedy NMS over the sorted band, NMS_CHUNK candidates at a time, with no serial pass over the band:
+    //  (1) in parallel: which chunk members are suppressed by boxes kept earlier (cdead) and the pairwise
+    //      "i suppresses j" relation inside the chunk (same class, i before j, IoU > thr) as bit masks
+    //      supp[j], each 64-bit word built in one thread's register;
+    //  (2) "j is kept iff it is alive and no KEPT earlier member is in supp[j]" is a recurrence in band
+    //      order with a unique solution; one wavefront iterates it to its fixed point with ballots (round
+    //      r finalises the first r members; real detections need a handful of rounds).  When the per-class
+    //      cap can bind (max_per_class < max_total) one thread per class walks its chain instead;
+    //  (3) the kept bits, read in band order, are the rows; the first max_total of them are exactly what a
+    //      one-by-one walk keeps (a candidate's fate depends only on higher-scored boxes of its own class,
+    //      so the members behind the cut cannot change the rows before it).
     const WzIouThr ithr = wz_iou_thr(k.iou_thr);
-    const bool count_classes = k.max_per_class < k.max_total;   // per-class cap can bind: counted in the scan
+    const bool count_classes = k.max_per_class < k.max_total;   // per-class cap can bind
+    const int ncls = k.num_classes - 1;
+    // the sort buffer that does not hold the sorted band is free: per-class tables live there
+    int32_t* const first = reinterpret_cast<int32_t*>(sorted == S->keys2 ? S->keys : S->keys2);   // [ncls]
+    int32_t* const ccount = first + 4096;                                                          // [ncls]
     for (int base = 0; base < cnt && kept < k.max_total; base += NMS_CHUNK) {
         const int m = min(NMS_CHUNK, cnt - base);
         for (int i = tid; i < NMS_CHUNK; i += NMS_THREADS) {
             S->cdead[i] = 0u;
-#pragma unroll
-            for (int w = 0; w < NMS_CHUNK / 64; ++w) S->supp[i][w] = 0ull;
             if (i < m) {
                 const uint32_t tie = 0xFFFFFFFFu - (uint32_t)(sorted[base + i] & 0xFFFFFFFFull);
                 S->ccls[i] = (int)(tie / (uint32_t)A);
@@ -345,71 +359,126 @@ __device__ int wz_nms_band(NmsShared* S, const WzPostBuffers& b, const WzPostCon
                 S->ccls[i] = -1;
             }
         }
+        for (int c = tid; c < ncls; c += NMS_THREADS) {
+            first[c] = 0x7fffffff;
+            ccount[c] = 0;
+        }
+        if (tid < NMS_CHUNK / 64) S->keptmask[tid] = 0ull;
         __syncthreads();
+        if (tid == 0 && base == 0) b.dbg[(size_t)f * 16 + 11] = wall_clock64();
         for (int p = tid; p < m * kept; p += NMS_THREADS) {          // vs boxes kept before this chunk
             const int i = p / kept, j = p - i * kept;
             if (S->kcls[j] == S->ccls[i] && wz_iou_exceeds(S->cnorm[i], S->carea[i], S->knorm[j], S->karea[j], ithr))
                 S->cdead[i] = 1u;                                    // benign race: every writer stores 1
         }
-        for (int p = tid; p < m * m; p += NMS_THREADS) {             // inside the chunk, i before j
-            const int i = p / m, j = p - i * m;
-            if (i < j && S->ccls[i] == S->ccls[j] &&
-                wz_iou_exceeds(S->cnorm[j], S->carea[j], S->cnorm[i], S->carea[i], ithr))
-                atomicOr(&S->supp[j][i >> 6], 1ull << (i & 63));
+        {   // supp[j][w]: thread = (chunk member j, word w of earlier members 64w .. 64w+63), built in a register
+            const int j = tid & (NMS_CHUNK - 1), w = tid >> 8;
+            unsigned long long bits = 0ull;
+            if (j < m) {
+                const float4_t bj = S->cnorm[j];
+                const float aj = S->carea[j];
+                const int cj = S->ccls[j];
+                const int i_end = min(w * 64 + 64, j);               // i before j
+                for (int i = w * 64; i < i_end; ++i)                  // i is wave-uniform: LDS broadcasts
+                    if (S->ccls[i] == cj && wz_iou_exceeds(bj, aj, S->cnorm[i], S->carea[i], ithr))
+                        bits |= 1ull << (i & 63);
+            }
+            S->supp[j][w] = bits;
+        }
+        if (count_classes) {   // per-class chains in band order (only needed when the per-class cap can bind)
+            for (int j = tid; j < kept; j += NMS_THREADS) atomicAdd(&ccount[S->kcls[j]], 1);
+            for (int i = tid; i < m; i += NMS_THREADS) {
+                atomicMin(&first[S->ccls[i]], i);
+                int nx = 0x7fffffff;
+                for (int j = i + 1; j < m; ++j)
+                    if (S->ccls[j] == S->ccls[i]) { nx = j; break; }
+                S->cnext[i] = nx;
+            }
         }
         __syncthreads();
-        const int kept_before = kept;   // wave 0 advances its private copy of `kept` in the scan below
-        if (wave == 0) {
-            unsigned long long sp[NMS_CHUNK / 64][NMS_CHUNK / 64];   // [slot q][word w] of candidate lane + 64 q
-            uint32_t dead = 0;                                       // bit q = candidate lane + 64 q is suppressed
-            int mycls[NMS_CHUNK / 64];
+        if (tid == 0 && base == 0) b.dbg[(size_t)f * 16 + 12] = wall_clock64();
+        if (!count_classes) {
+            // Member j is kept iff it is not dead and no KEPT earlier member is in supp[j].  That is a
+            // recurrence in band order with a unique solution; iterate "kept = alive & no kept suppressor"
+            // from "everything alive is kept": after r rounds the first r members are final, and the
+            // typical dependency depth is a handful.  One wavefront, 4 members per lane, ballots only.
+            if (tid < 64) {
+                unsigned long long row[NMS_CHUNK / 64][NMS_CHUNK / 64];
+                bool alive[NMS_CHUNK / 64];
+                unsigned long long km[NMS_CHUNK / 64];
 #pragma unroll
-            for (int q = 0; q < NMS_CHUNK / 64; ++q) {
-                const int j = lane + 64 * q;
-                mycls[q] = S->ccls[j];
-                if (S->cdead[j] || j >= m) dead |= 1u << q;
+                for (int q = 0; q < NMS_CHUNK / 64; ++q) {
+                    const int j = tid + 64 * q;
 #pragma unroll
-                for (int w = 0; w < NMS_CHUNK / 64; ++w) sp[q][w] = S->supp[j][w];
-            }
-            const int kept0 = kept;
+                    for (int w = 0; w < NMS_CHUNK / 64; ++w) row[q][w] = S->supp[j][w];
+                    alive[q] = j < m && !S->cdead[j];
+                    km[q] = __ballot(alive[q]);
+                }
+                for (int round = 0; round <= NMS_CHUNK; ++round) {
+                    unsigned long long nk[NMS_CHUNK / 64];
+                    bool same = true;
 #pragma unroll
-            for (int w = 0; w < NMS_CHUNK / 64; ++w) {
-                for (int bb = 0; bb < 64; ++bb) {
-                    const int i = w * 64 + bb;
-                    if (i >= m || kept >= k.max_total) break;
-                    const uint32_t dbits = (uint32_t)__builtin_amdgcn_readlane((int)dead, bb);
-                    if ((dbits >> w) & 1u) continue;
-                    if (count_classes) {                             // kept boxes of this class so far
-                        const int cls = __builtin_amdgcn_readlane(mycls[w], bb);
-                        int same = 0;
-                        for (int j = lane; j < kept; j += 64)
-                            same += (j < kept0 ? S->kcls[j] : S->ccls[S->kidx[j] - base]) == cls ? 1 : 0;
+                    for (int q = 0; q < NMS_CHUNK / 64; ++q) {
+                        unsigned long long hit = 0ull;
 #pragma unroll
-                        for (int o = 32; o > 0; o >>= 1) same += __shfl_xor(same, o);
-                        if (same >= k.max_per_class) continue;
+                        for (int w = 0; w < NMS_CHUNK / 64; ++w) hit |= row[q][w] & km[w];
+                        nk[q] = __ballot(alive[q] && hit == 0ull);
+                        same = same && nk[q] == km[q];
                     }
-                    if (lane == 0) S->kidx[kept] = base + i;
-                    ++kept;
+#pragma unroll
+                    for (int q = 0; q < NMS_CHUNK / 64; ++q) km[q] = nk[q];
+                    if (same) break;
+                }
+                if (tid < NMS_CHUNK / 64) {
 #pragma unroll
                     for (int q = 0; q < NMS_CHUNK / 64; ++q)
-                        dead |= (uint32_t)((sp[q][w] >> bb) & 1ull) << q;
+                        if (tid == q) S->keptmask[q] = km[q];
                 }
             }
-            if (lane == 0) S->kept = kept;
+        } else
+        for (int c = tid; c < ncls; c += NMS_THREADS) {              // one thread per class walks its chain
+            int j = first[c];
+            if (j == 0x7fffffff) continue;
+            unsigned long long km[NMS_CHUNK / 64];
+#pragma unroll
+            for (int w = 0; w < NMS_CHUNK / 64; ++w) km[w] = 0ull;
+            int have = ccount[c];
+            while (j != 0x7fffffff) {
+                unsigned long long hit = 0ull;
+#pragma unroll
+                for (int w = 0; w < NMS_CHUNK / 64; ++w) hit |= S->supp[j][w] & km[w];
+                if (!S->cdead[j] && hit == 0ull && have < k.max_per_class) {
+#pragma unroll
+                    for (int w = 0; w < NMS_CHUNK / 64; ++w)
+                        if (w == (j >> 6)) km[w] |= 1ull << (j & 63);
+                    ++have;
+                }
+                j = S->cnext[j];
+            }
+#pragma unroll
+            for (int w = 0; w < NMS_CHUNK / 64; ++w)
+                if (km[w]) atomicOr(&S->keptmask[w], km[w]);
         }
         __syncthreads();
-        const int kept_new = S->kept;
-        for (int j = kept_before + tid; j < kept_new; j += NMS_THREADS) {   // materialise the newly kept rows
-            const int si = S->kidx[j];
-            const unsigned long long comp = sorted[si];
-            S->kbox[j] = S->sbox[si];
-            S->knorm[j] = S->cnorm[si - base];
-            S->karea[j] = S->carea[si - base];
-            S->kcls[j] = S->ccls[si - base];
+        if (tid == 0 && base == 0) b.dbg[(size_t)f * 16 + 13] = wall_clock64();
+        int total_new = 0;
+#pragma unroll
+        for (int w = 0; w < NMS_CHUNK / 64; ++w) total_new += __popcll(S->keptmask[w]);
+        for (int i = tid; i < m; i += NMS_THREADS) {                 // materialise the newly kept rows, band order
+            if (!((S->keptmask[i >> 6] >> (i & 63)) & 1ull)) continue;
+            int before = __popcll(S->keptmask[i >> 6] & ((1ull << (i & 63)) - 1ull));
+            for (int w = 0; w < (i >> 6); ++w) before += __popcll(S->keptmask[w]);
+            const int j = kept + before;
+            if (j >= k.max_total) continue;
+            const unsigned long long comp = sorted[base + i];
+            S->kbox[j] = S->sbox[base + i];
+            S->knorm[j] = S->cnorm[i];
+            S->karea[j] = S->carea[i];
+            S->kcls[j] = S->ccls[i];
             S->kscore[j] = __uint_as_float((uint32_t)(comp >> 32));
         }
         __syncthreads();
-        kept = kept_new;
+        kept = min(kept + total_new, k.max_total);
     }
     if (tid == 0) b.dbg[(size_t)f * 16 + 7] = wall_clock64();
     return kept;

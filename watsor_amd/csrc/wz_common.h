@@ -39,6 +39,8 @@ struct WzConvArgs {
     float* out2;                // WZ_OUT_HEAD: class-logit buffer (out = box-encoding buffer)
     int64_t out2_batch_stride, out2_off;
     int32_t n_box;              // WZ_OUT_HEAD: columns [0, n_box) are box encodings, the rest class logits
+    const half_t* zeros;        // >= 64 zero halfs in HBM: source of out-of-frame lanes in the LDS-tiled kernel
+    int32_t grid_m, grid_n;     // LDS-tiled kernel: pixel tiles x channel tiles (filled in by the launcher)
 };
 
 // One fused inverted-residual block (k_mbconv.hip).  cin/kc/n_pad/cout describe the project conv.
@@ -60,7 +62,8 @@ struct WzMbArgs {
     float* ws;             // fp32 workspace for channel-group partial sums (nullptr: never split)
     uint64_t ws_bytes;
     int32_t M;             // n * hout * wout
-    int32_t th, tw, tiles_y, tiles_x, nsplit, cpg;   // filled in by the launcher
+    unsigned long long* dbg;   // diagnostics: 16 timestamps (first / last workgroup), or nullptr
+    int32_t th, tw, tiles_y, tiles_x, nsplit, cpg, stage;   // filled in by the launcher
 };
 
 // Per-camera filter state resident in HBM (see wz_set_camera_filter).
@@ -89,6 +92,9 @@ void wz_launch_dw(const half_t* in, const half_t* w, const float* bias, half_t* 
 void wz_launch_conv(const WzConvArgs& a, hipStream_t s);
 void wz_launch_splitk_reduce(const WzConvArgs& a, const float* ws, hipStream_t s);
 int wz_choose_splitk(int M, int n_pad, int kchunks);
+bool wz_conv_use_lds(const WzConvArgs& a);               // the LDS-tiled kernel will serve this conv
+int wz_choose_splitk_lds(int M, int n_pad, int kchunks);
+void wz_conv_init();
 int wz_launch_mbconv(const WzMbArgs& a, int n, hipStream_t s, bool prepare);   // -1: no kernel; else #channel groups
 
 #define WZ_HIST_BINS 1024
