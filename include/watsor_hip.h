@@ -117,6 +117,7 @@ int wz_num_anchors(wz_engine_t* e);
 int wz_num_classes(wz_engine_t* e);
 int wz_num_tensors(wz_engine_t* e);
 int wz_tensor_info(wz_engine_t* e, int idx, char* name, int namelen, int* h, int* w, int* c);
+int wz_precision(wz_engine_t* e);   /* 16: fp16 storage / fp16 MFMA; 32: fp32 storage / exact-fp32 MFMA (engine built with -p 32) */
 int wz_num_ops(wz_engine_t* e);
 /* dims[12] = kind,cin,cout,ksize,stride,hin,win,hout,wout,n_pad,kc,splitk */
 int wz_op_info(wz_engine_t* e, int idx, char* name, int namelen, int* dims);

@@ -61,6 +61,15 @@ def model_dir_unfused(synth_weights, tmp_path_factory):
 
 
 @pytest.fixture(scope="session")
+def model_dir_fp32(synth_weights, tmp_path_factory):
+    """The `-p 32` engine: fp32 storage, exact-fp32 matrix cores."""
+    from watsor_amd import engine
+    d = tmp_path_factory.mktemp("model_fp32")
+    engine.save_engine(engine.build_engine(synth_weights, precision=32), str(d / "mi355x.bin"))
+    return str(d)
+
+
+@pytest.fixture(scope="session")
 def oracle_net(synth_weights):
     from oracle.ssd_mobilenet_v2 import OracleNet
     return OracleNet(synth_weights)

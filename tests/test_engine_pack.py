@@ -197,4 +197,26 @@ def test_cli_and_errors(tmp_path, synth_weights):
     with pytest.raises(KeyError):
         engine.build_engine(bad)
     with pytest.raises(ValueError):
-        engine.build_engine(synth_weights, precision=32)
+        engine.build_engine(synth_weights, precision=8)
+
+
+def test_fp32_engine_packs_unrounded_weights(synth_weights):
+    """-p 32: one op per layer, fp32 weights in the float4-per-lane fragment order of csrc/k_f32.hip."""
+    blob32 = engine.build_engine(synth_weights, precision=32)
+    hdr, tensors, ops = parse(blob32)
+    assert hdr["precision"] == 32 and hdr["n_ops"] == 66 and not any(o["kind"] == arch.OP_MBCONV for o in ops)
+    prog = arch.build(fuse=False)
+    for o, op in zip(ops, prog.ops):
+        wf, bf = engine.fold_batch_norm(synth_weights, op)
+        if o["kind"] == arch.OP_CONV:
+            taps = o["ksize"] ** 2
+            assert o["kc"] == (op.cin + 15) // 16
+            n = (o["n_pad"] // 16) * taps * o["kc"] * 256
+            w = np.frombuffer(blob32, np.float32, n, hdr["weights_off"] + o["w_off"])
+            w = w.reshape(o["n_pad"] // 16, taps, o["kc"], 4, 16, 4)            # [t][tap][c][g][r][j]
+            w = w.transpose(1, 2, 3, 5, 0, 4).reshape(taps, o["kc"] * 16, o["n_pad"])
+            np.testing.assert_array_equal(w[:, :op.cin, :op.cout], wf.reshape(taps, op.cin, op.cout).astype(np.float32))
+            assert not w[:, op.cin:, :].any() and not w[:, :, op.cout:].any()
+        elif o["kind"] == arch.OP_DW:
+            w = np.frombuffer(blob32, np.float32, 9 * op.cin, hdr["weights_off"] + o["w_off"]).reshape(9, op.cin)
+            np.testing.assert_array_equal(w, wf.reshape(9, op.cin).astype(np.float32))

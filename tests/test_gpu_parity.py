@@ -178,6 +178,43 @@ def test_scores_within_tolerance(eng, head_outputs):
     assert np.abs(sigmoid(lg) - sigmoid(rlg)).max() <= SCORE_TOL
 
 
+SCORE_TOL_FP32 = 1e-3   # the north-star's bar ("box scores within 1e-3 of the CPU reference"); measured ~1e-5
+
+
+def test_fp32_engine_meets_the_north_star_tolerance(model_dir_fp32, head_outputs, synth_weights, frames_640):
+    """`-p 32` engine (fp32 storage, v_mfma_f32_16x16x4_f32): every layer, every score and the end-to-end rows."""
+    from oracle.postprocess import sigmoid
+    from watsor_amd.detection.hip_gpu import HipObjectDetector
+    from watsor_amd.share import DetectionArray
+    x_half, rbe, rlg, T = head_outputs
+    e = _keep_engine(model_dir_fp32)
+    try:
+        assert e.precision == 32
+        be, lg = e.stage_forward(x_half)
+        for idx, (name, h, w, c) in enumerate(e.tensors()):
+            if name == "input":
+                continue
+            got = np.stack([e.stage_read_tensor(idx, f) for f in range(2)])
+            assert got.dtype == np.float32
+            err, scale = np.abs(got - T[name]).max(), np.abs(T[name]).max()
+            assert err <= 2e-4 * scale + 1e-5, "%s: max abs err %.3g (max|ref| %.3g)" % (name, err, scale)
+        assert np.abs(sigmoid(lg) - sigmoid(rlg)).max() <= SCORE_TOL_FP32 / 10
+        assert np.abs(be - rbe).max() <= 1e-3
+    finally:
+        e.close()
+    oracle = odet.OracleObjectDetector(weights=synth_weights)
+    with HipObjectDetector(model_dir_fp32, 0) as det:
+        for f in frames_640[:2]:
+            rows = DetectionArray()
+            det.detect(f.shape, f, rows)
+            got = np.frombuffer(rows, dtype=ROW_DTYPE)
+            b, c, s, _, _ = oracle.raw(f)
+            ref = odet.rows_as_array(f.shape, b, c, s)
+            pairs, missing = pu.match_rows(got, ref, min_score=0.0)
+            assert len(missing) <= 1, missing            # (a tie at the top-100 cut may swap one row)
+            assert max(abs(p[3]) for p in pairs) <= SCORE_TOL_FP32
+
+
 def test_buffer_sharing_changes_nothing(eng, eng_keep_fused, head_outputs):
     x_half = head_outputs[0]
     a = eng.stage_forward(x_half)

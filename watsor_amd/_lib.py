@@ -47,6 +47,7 @@ SIGNATURES = {
     "wz_filter_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "wz_zones_from_alpha": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "wz_input_size": (C.c_int, [C.c_void_p]),
+    "wz_precision": (C.c_int, [C.c_void_p]),
     "wz_num_anchors": (C.c_int, [C.c_void_p]),
     "wz_num_classes": (C.c_int, [C.c_void_p]),
     "wz_num_tensors": (C.c_int, [C.c_void_p]),

@@ -41,6 +41,7 @@ struct WzConvArgs {
     int32_t n_box;              // WZ_OUT_HEAD: columns [0, n_box) are box encodings, the rest class logits
     const half_t* zeros;        // >= 64 zero halfs in HBM: source of out-of-frame lanes in the LDS-tiled kernel
     int32_t grid_m, grid_n;     // LDS-tiled kernel: pixel tiles x channel tiles (filled in by the launcher)
+    float* ws;                  // fp32 engine: split-K workspace (the fp16 kernels get it through `out`)
 };
 
 // One fused inverted-residual block (k_mbconv.hip).  cin/kc/n_pad/cout describe the project conv.
@@ -95,6 +96,12 @@ int wz_choose_splitk(int M, int n_pad, int kchunks);
 bool wz_conv_use_lds(const WzConvArgs& a);               // the LDS-tiled kernel will serve this conv
 int wz_choose_splitk_lds(int M, int n_pad, int kchunks);
 void wz_conv_init();
+// `-p 32` engine (k_f32.hip): fp32 activations and weights, exact-fp32 MFMA
+void wz_launch_stem_f32(const half_t* in, const float* w, const float* bias, float* out, int n, int hin, int win,
+                        int hout, int wout, int pad_t, int pad_l, hipStream_t s);
+void wz_launch_dw_f32(const float* in, const float* w, const float* bias, float* out, int n, int hin, int win, int c,
+                      int hout, int wout, int stride, int pad_t, int pad_l, int act, hipStream_t s);
+void wz_launch_conv_f32(const WzConvArgs& a, hipStream_t s);   // + its split-K reduce when a.splitk > 1
 int wz_launch_mbconv(const WzMbArgs& a, int n, hipStream_t s, bool prepare);   // -1: no kernel; else #channel groups
 
 #define WZ_HIST_BINS 1024

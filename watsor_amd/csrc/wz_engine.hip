@@ -139,10 +139,18 @@ static WzMbArgs mb_args(wz_engine* e, const Lane& L, const WzOpDesc& op) {
 
 static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t) {
     hipStream_t s = L.stream;
+    const bool f32 = e->hdr.precision == 32;
     for (uint32_t i = 0; i < e->hdr.n_ops; ++i) {
         const WzOpDesc& op = e->ops[i];
         const uint8_t* wbase = e->d_weights;
-        if (op.kind == WZ_OP_STEM) {
+        if (f32 && op.kind == WZ_OP_STEM) {
+            wz_launch_stem_f32(L.tptr[op.src], (const float*)(wbase + op.w_off), (const float*)(wbase + op.b_off),
+                               (float*)L.tptr[op.dst], n, op.hin, op.win, op.hout, op.wout, op.pad_t, op.pad_l, s);
+        } else if (f32 && op.kind == WZ_OP_DW) {
+            wz_launch_dw_f32((const float*)L.tptr[op.src], (const float*)(wbase + op.w_off), (const float*)(wbase + op.b_off),
+                             (float*)L.tptr[op.dst], n, op.hin, op.win, op.cin, op.hout, op.wout, op.stride, op.pad_t,
+                             op.pad_l, op.act, s);
+        } else if (op.kind == WZ_OP_STEM) {
             wz_launch_stem(L.tptr[op.src], (const float*)(wbase + op.w_off), (const float*)(wbase + op.b_off),
                            L.tptr[op.dst], n, op.hin, op.win, op.hout, op.wout, op.pad_t, op.pad_l, s);
         } else if (op.kind == WZ_OP_DW) {
@@ -200,6 +208,16 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t) {
                 a.n_box = op.n_box;
             }
             a.zeros = e->d_zeros;
+            if (f32) {   // a.kc / a.kchunks count 16-channel chunks here
+                int sk = e->use_splitk ? wz_choose_splitk(a.M, a.n_pad, a.kchunks / 2) : 1;
+                while (sk > 1 && (size_t)sk * a.M * a.n_pad * 4 > WZ_WS_BYTES) --sk;
+                a.splitk = sk;
+                a.ws = L.d_ws;
+                a.out = final_out;
+                wz_launch_conv_f32(a, s);
+                if (t) { t->mark(); t->mark(); }
+                continue;
+            }
             int sk = 1;
             if (e->use_splitk)
                 sk = wz_conv_use_lds(a) ? wz_choose_splitk_lds(a.M, a.n_pad, a.kchunks) : wz_choose_splitk(a.M, a.n_pad, a.kchunks);
@@ -315,7 +333,7 @@ static int load_blob(wz_engine* e, const char* path) {
     if (h.version != WZ_FORMAT_VERSION)
         return wz_fail(WZ_EFORMAT, "%s: engine format %u, runtime expects %u -- rebuild it with watsor_amd.engine",
                        path, h.version, WZ_FORMAT_VERSION);
-    if (h.total_bytes != (uint64_t)sz || h.precision != 16 || h.max_total > WZ_MAX_DETECTIONS || h.max_total < 1 ||
+    if (h.total_bytes != (uint64_t)sz || (h.precision != 16 && h.precision != 32) || h.max_total > WZ_MAX_DETECTIONS || h.max_total < 1 ||
         h.num_classes > 4096 || h.n_ops == 0 || h.weights_off + h.weights_bytes > (uint64_t)sz ||
         h.tensors_off + (uint64_t)h.n_tensors * sizeof(WzTensorDesc) > (uint64_t)sz ||
         h.ops_off + (uint64_t)h.n_ops * sizeof(WzOpDesc) > (uint64_t)sz ||
@@ -340,6 +358,10 @@ static int load_blob(wz_engine* e, const char* path) {
               (op.cin0 != 0 && (op.cin0 % 8 != 0 || op.kc0 != (op.cin0 + 31) / 32 || op.nmid_pad % 16 != 0 ||
                                 op.nmid_pad < op.cmid || op.we_off < 0 || (uint64_t)op.we_off >= h.weights_bytes ||
                                 op.be_off < 0 || (uint64_t)op.be_off >= h.weights_bytes)))))
+            return wz_fail(WZ_EFORMAT, "%s: op %u (%s) is malformed", path, i, op.name);
+        if (op.kind == WZ_OP_MBCONV && h.precision != 16)
+            return wz_fail(WZ_EFORMAT, "%s: fused blocks exist for the fp16 engine only", path);
+        if (h.precision == 32 && ((op.kind == WZ_OP_CONV && op.cin % 4 != 0) || (op.kind == WZ_OP_DW && op.cin % 4 != 0)))
             return wz_fail(WZ_EFORMAT, "%s: op %u (%s) is malformed", path, i, op.name);
         if (op.kind == WZ_OP_MBCONV) {
             wz_engine::Lane none;
@@ -438,7 +460,7 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
             for (uint32_t i = 0; i < h.n_tensors; ++i) {
                 const WzTensorDesc& t = e->tensors[i];
                 void* p = nullptr;
-                CK(hipMalloc(&p, (size_t)max_batch * t.h * t.w * t.c * 2 + 256));
+                CK(hipMalloc(&p, (size_t)max_batch * t.h * t.w * t.c * (h.precision / 8) + 256));
                 L.bufs.push_back(p);
                 L.tptr[i] = (half_t*)p;
             }
@@ -446,7 +468,7 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
             std::vector<size_t> slot_bytes(h.n_slots, 0);
             for (uint32_t i = 0; i < h.n_tensors; ++i) {
                 const WzTensorDesc& t = e->tensors[i];
-                const size_t b = (size_t)max_batch * t.h * t.w * t.c * 2 + 256;
+                const size_t b = (size_t)max_batch * t.h * t.w * t.c * (h.precision / 8) + 256;
                 if (b > slot_bytes[t.slot]) slot_bytes[t.slot] = b;
             }
             for (uint32_t sidx = 0; sidx < h.n_slots; ++sidx) {
@@ -714,6 +736,7 @@ extern "C" int wz_filter_rows(wz_engine_t* e, int cam, wz_detection_t* rows, uin
 // introspection / profiling
 // ------------------------------------------------------------------------------------------------
 extern "C" int wz_input_size(wz_engine_t* e) { return e ? (int)e->hdr.input_size : 0; }
+extern "C" int wz_precision(wz_engine_t* e) { return e ? (int)e->hdr.precision : 0; }
 extern "C" int wz_num_anchors(wz_engine_t* e) { return e ? (int)e->hdr.num_anchors : 0; }
 extern "C" int wz_num_classes(wz_engine_t* e) { return e ? (int)e->hdr.num_classes : 0; }
 extern "C" int wz_num_tensors(wz_engine_t* e) { return e ? (int)e->hdr.n_tensors : 0; }
@@ -865,8 +888,9 @@ extern "C" int wz_stage_read_tensor(wz_engine_t* e, int idx, int frame, uint16_t
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
     const WzTensorDesc& t = e->tensors[idx];
-    const size_t per = (size_t)t.h * t.w * t.c;
-    HIPCHK(hipMemcpy(out_half, e->lanes[0].tptr[idx] + per * frame, per * 2, hipMemcpyDeviceToHost));
+    const size_t es = idx == input_tensor_index(e) ? 2 : e->hdr.precision / 8;   // the input tensor is fp16 in both engines
+    const size_t per = (size_t)t.h * t.w * t.c * es;
+    HIPCHK(hipMemcpy(out_half, (const uint8_t*)e->lanes[0].tptr[idx] + per * frame, per, hipMemcpyDeviceToHost));
     return WZ_OK;
 }
 

@@ -69,6 +69,18 @@ def pack_conv_weights(w: np.ndarray, n_pad: int, kc: int) -> np.ndarray:
     return np.ascontiguousarray(wp).astype(np.float16).reshape(-1)
 
 
+def pack_conv_weights_f32(w: np.ndarray, n_pad: int, kc: int) -> np.ndarray:
+    """[k,k,cin,cout] -> fp32 [n_pad/16][taps][kc][64][4]: lane (r16, g) of N-tile t holds W[k = c*16 + 4g + j][n = t*16 + r16]
+    (the A operands of four v_mfma_f32_16x16x4_f32, one float4 load per lane; csrc/k_f32.hip)."""
+    k, _, cin, cout = w.shape
+    taps = k * k
+    wp = np.zeros((taps, kc * 16, n_pad), np.float32)
+    wp[:, :cin, :cout] = w.reshape(taps, cin, cout)
+    wp = wp.reshape(taps, kc, 4, 4, n_pad // 16, 16)            # [tap][c][g][j][t][r]
+    wp = wp.transpose(4, 0, 1, 2, 5, 3)                         # [t][tap][c][g][r][j]
+    return np.ascontiguousarray(wp).reshape(-1)
+
+
 OP_RECORD_BYTES = 256
 
 
@@ -128,8 +140,10 @@ def build_engine(weights: Dict[str, np.ndarray], precision: int = 16, model_widt
                  model_height: int = 300, post: Optional[dict] = None, fuse: bool = True) -> bytes:
     """Returns the engine image.  Mirrors `build_engine` of watsor/engine.py:17-51.
     fuse=False keeps one op per layer (used by the per-layer parity tests; same results, slower)."""
-    if precision != 16:
-        raise ValueError("only -p 16 (fp16 storage, fp32 accumulate) is implemented on MI355X")
+    if precision not in (16, 32):
+        raise ValueError("precision must be 16 (fp16 storage, fp16 MFMA, fused blocks) or 32 (fp32 storage, fp32 MFMA)")
+    if precision == 32:
+        fuse = False                 # the fp32 engine runs one op per layer (csrc/k_f32.hip)
     if model_width != model_height:
         raise ValueError("square model input expected")
     cfg = dict(DEFAULT_POST)
@@ -157,8 +171,12 @@ def build_engine(weights: Dict[str, np.ndarray], precision: int = 16, model_widt
     def put_conv(op):
         w, b = fold_batch_norm(weights, op)
         n_pad = _align(op.cout, 64 if op.cout >= 256 else 32)   # 64-wide wave tiles for the wide layers
-        kc = (op.cin + 31) // 32
-        w_off = put(pack_conv_weights(w.astype(np.float32), n_pad, kc))
+        if precision == 32:
+            kc = (op.cin + 15) // 16
+            w_off = put(pack_conv_weights_f32(w.astype(np.float32), n_pad, kc))
+        else:
+            kc = (op.cin + 31) // 32
+            w_off = put(pack_conv_weights(w.astype(np.float32), n_pad, kc))
         bp = np.zeros(n_pad, np.float32)
         bp[:op.cout] = b
         return w_off, put(bp), n_pad, kc
@@ -188,15 +206,10 @@ def build_engine(weights: Dict[str, np.ndarray], precision: int = 16, model_widt
             w_off = put(w.reshape(27, 32).astype(np.float32))
             b_off = put(b.astype(np.float32))
         elif op.kind == arch.OP_DW:
-            w_off = put(w.reshape(9, op.cin).astype(np.float16))
+            w_off = put(w.reshape(9, op.cin).astype(np.float32 if precision == 32 else np.float16))
             b_off = put(b.astype(np.float32))
         else:
-            n_pad = _align(op.cout, 64 if op.cout >= 256 else 32)   # 64-wide wave tiles for the wide layers
-            kc = (op.cin + 31) // 32
-            w_off = put(pack_conv_weights(w.astype(np.float32), n_pad, kc))
-            bp = np.zeros(n_pad, np.float32)
-            bp[:op.cout] = b
-            b_off = put(bp)
+            w_off, b_off, n_pad, kc = put_conv(op)
         op_recs.append(_op_record(op, tindex, n_pad, kc, w_off, b_off, mb))
     assert all(len(r) == OP_RECORD_BYTES for r in op_recs)
 

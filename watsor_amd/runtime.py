@@ -38,6 +38,7 @@ class HipEngine:
         rc = self._lib.wz_create(os.fsencode(engine_path), device, max_batch, max_width, max_height, C.byref(self._h))
         _lib.check(rc, "wz_create")
         self.input_size = self._lib.wz_input_size(self._h)
+        self.precision = self._lib.wz_precision(self._h)
         self.num_anchors = self._lib.wz_num_anchors(self._h)
         self.num_classes = self._lib.wz_num_classes(self._h)
         self.num_slots = self._lib.wz_num_slots(self._h)
@@ -228,7 +229,7 @@ class HipEngine:
 
     def stage_read_tensor(self, idx: int, frame: int = 0) -> np.ndarray:
         name, h, w, c = self.tensors()[idx]
-        out = np.empty((h, w, c), np.float16)
+        out = np.empty((h, w, c), np.float16 if (self.precision == 16 or name == "input") else np.float32)
         _lib.check(self._lib.wz_stage_read_tensor(self._h, idx, frame, C.c_void_p(out.ctypes.data)))
         return out
 
