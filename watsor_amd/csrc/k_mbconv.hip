@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void wz_k_mbconv(const WzMbArgs a) {
         const int c_begin = ch_begin * CE;
         const int cw = min(a.cpg * CE, a.cmid_pad - c_begin);   // multiple of 32
         // depthwise weights + bias of these channels -> LDS (read after the first barrier below)
-        half_t* const wd_l = e_base + 2 * ebuf;                               // [9][cw]
+        half_t* const wd_l = e_base + a.ebufs * ebuf;                         // [9][cw]
         float* const bd_l = reinterpret_cast<float*>(wd_l + 9 * a.cpg * CE);   // [cw]
         float* const be_l = bd_l + a.cpg * CE;                                 // [cw] expand bias
         {
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void wz_k_mbconv(const WzMbArgs a) {
         __syncthreads();   // staged biases / weights are visible (the barrier's vmcnt(0) also covers the halo loads above)
         MB_STAMP(1);
         for (int ch = ch_begin; ch < ch_end; ++ch) {
-            half_t* const E = e_base + (ch & 1) * ebuf;
+            half_t* const E = e_base + ((ch - ch_begin) & (a.ebufs - 1)) * ebuf;
             const int ce0 = ch * CE;
             const int nte = min(CE, a.nmid_pad - ce0) >> 4;   // 16-channel tiles of this chunk
             // ---- expand: E[p][ce] = in-frame ? relu6(sum_k X[p][k] We[k][ce] + be[ce]) : 0
@@ -224,9 +224,10 @@ __global__ __launch_bounds__(256) void wz_k_mbconv(const WzMbArgs a) {
                     }
                 }
             }
-            // no barrier here: the next chunk's expand writes the OTHER buffer, and a wave can only reach
-            // the chunk after that (same buffer again) through the barrier above, i.e. after every wave
-            // has finished reading this one
+            // two chunk buffers: no barrier here -- the next chunk's expand writes the OTHER buffer, and a wave
+            // can only reach the chunk after that (same buffer again) through the barrier above, i.e. after
+            // every wave has finished reading this one.  One buffer (less LDS, more workgroups per CU):
+            if (a.ebufs == 1 && ch + 1 < ch_end) __syncthreads();
         }
     } else {
         // ---- no expand stage: depthwise taps gathered from global memory (zero outside the frame)
@@ -333,13 +334,15 @@ static int wz_mb_env(const char* name, int dflt) {
 static MbCfg wz_mb_choose(const WzMbArgs& a, int n) {
     MbCfg c;
     int th = 8, tw = 8;
-    if (a.wout <= 10) { th = 5; tw = 10; }
-    else if (a.wout <= 19 && a.stride == 1) { th = 10; tw = 10; }
+    if (a.wout <= 19 && a.stride == 1) { th = 5; tw = 10; }   // 10x10: 2 tiles, 19x19: 4 x 2 tiles per frame
+    else if (a.wout <= 10) { th = 5; tw = 10; }
     c.th = wz_mb_env("WZ_MB_TH", th);
     c.tw = wz_mb_env("WZ_MB_TW", tw);
     if (a.wout <= 10) { c.th = wz_mb_env("WZ_MB_TH10", c.th); c.tw = wz_mb_env("WZ_MB_TW10", c.tw); }
     else if (a.wout <= 19) { c.th = wz_mb_env("WZ_MB_TH19", c.th); c.tw = wz_mb_env("WZ_MB_TW19", c.tw); }
     else if (a.wout <= 38) { c.th = wz_mb_env("WZ_MB_TH38", c.th); c.tw = wz_mb_env("WZ_MB_TW38", c.tw); }
+    else if (a.wout <= 75) { c.th = wz_mb_env("WZ_MB_TH75", c.th); c.tw = wz_mb_env("WZ_MB_TW75", c.tw); }
+    else { c.th = wz_mb_env("WZ_MB_TH150", c.th); c.tw = wz_mb_env("WZ_MB_TW150", c.tw); }
     if (c.th > a.hout) c.th = a.hout;
     if (c.tw > a.wout) c.tw = a.wout;
     for (;;) {
@@ -378,7 +381,8 @@ static int wz_mb_launch(WzMbArgs a, const MbCfg& c, int n, hipStream_t s, bool p
     if (EXPAND) {
         const int P = ((c.th - 1) * a.stride + 3) * ((c.tw - 1) * a.stride + 3);
         (void)P;
-        lds = (size_t)2 * MP * 64 * (CE + 8) * sizeof(half_t)                    // chunk buffers
+        a.ebufs = (c.cpg > 1 && wz_mb_env("WZ_MB_EBUFS", 1) == 2) ? 2 : 1;
+        lds = (size_t)a.ebufs * MP * 64 * (CE + 8) * sizeof(half_t)              // chunk buffer(s)
               + (size_t)c.cpg * CE * (9 * sizeof(half_t) + 2 * sizeof(float));   // depthwise weights + bias, expand bias
         const size_t wbytes = (size_t)(c.cpg * CE / 16) * KCI * 1024 + (size_t)NTO * (c.cpg * CE / 32) * 1024;
         if (lds + wbytes <= (size_t)wz_mb_env("WZ_MB_STAGE_KB", 96) * 1024) {    // GEMM weights of the group fit in LDS

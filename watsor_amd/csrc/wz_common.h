@@ -64,7 +64,7 @@ struct WzMbArgs {
     uint64_t ws_bytes;
     int32_t M;             // n * hout * wout
     unsigned long long* dbg;   // diagnostics: 16 timestamps (first / last workgroup), or nullptr
-    int32_t th, tw, tiles_y, tiles_x, nsplit, cpg, stage;   // filled in by the launcher
+    int32_t th, tw, tiles_y, tiles_x, nsplit, cpg, stage, ebufs;   // filled in by the launcher
 };
 
 // Per-camera filter state resident in HBM (see wz_set_camera_filter).
