@@ -80,6 +80,14 @@ int wz_detect_batch(wz_engine_t* e, int n, const uint8_t* const* rgb, const int*
 #define WZ_SLOTS 8
 int wz_submit_device(wz_engine_t* e, int slot, int n, const uint8_t* const* d_rgb, const int* w,
                      const int* h, const int* cam);
+/* The same with HOST frame pointers (as wz_detect_batch takes them): each lane has its own staging area, the copies
+ * ride the lane's stream, so the H2D of one batch overlaps the kernels of the batches on the other lanes. */
+int wz_submit_host(wz_engine_t* e, int slot, int n, const uint8_t* const* rgb, const int* w,
+                   const int* h, const int* cam);
+/* Page-lock / release a host range that frames are handed over from (the reference's FrameBuffer arenas,
+ * watsor/stream/share.py:35-41): copies out of it become DMA transfers at PCIe rate. */
+int wz_host_register(wz_engine_t* e, void* ptr, uint64_t bytes);
+int wz_host_unregister(wz_engine_t* e, void* ptr);
 int wz_collect(wz_engine_t* e, int slot, wz_detection_t* const* out, uint8_t* const* pass);
 /* Wait for `slot` without copying rows out (rows stay readable via wz_slot_rows). */
 int wz_wait(wz_engine_t* e, int slot);

@@ -341,6 +341,27 @@ def test_batch_of_mixed_resolutions_equals_single_calls(eng):
         assert max(abs(p[3]) for p in pairs) <= SCORE_TOL
 
 
+def test_submit_host_equals_detect_batch(eng):
+    """Asynchronous host-frame path (per-lane staging, optional page-locking) == the synchronous plugin call."""
+    frames = [synthetic_frame(640, 480, 11 + i) for i in range(4)]
+    ref = [np.zeros(100, ROW_DTYPE) for _ in frames]
+    eng.detect_batch(frames, ref)
+    arena = np.stack(frames)                                   # one contiguous "FrameBuffer arena"
+    eng.host_register(arena)
+    try:
+        views = [arena[i] for i in range(4)]
+        for slot in range(min(3, eng.num_slots)):              # several lanes in flight
+            eng.submit_host(slot, views)
+        for slot in range(min(3, eng.num_slots)):
+            got = [np.zeros(100, ROW_DTYPE) for _ in frames]
+            eng.collect(slot, got)
+            for a, b in zip(ref, got):
+                np.testing.assert_array_equal(a, b)
+    finally:
+        eng.sync()
+        eng.host_unregister(arena)
+
+
 def test_limits_and_errors(model_dir):
     e = make_engine(model_dir, max_batch=2, max_width=640, max_height=480)
     try:

@@ -36,6 +36,9 @@ SIGNATURES = {
     "wz_detect_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), c_i32p, c_i32p, c_i32p,
                                   C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), c_f32p]),
     "wz_submit_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), c_i32p, c_i32p, c_i32p]),
+    "wz_submit_host": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), c_i32p, c_i32p, c_i32p]),
+    "wz_host_register": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "wz_host_unregister": (C.c_int, [C.c_void_p, C.c_void_p]),
     "wz_collect": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "wz_wait": (C.c_int, [C.c_void_p, C.c_int]),
     "wz_slot_rows": (C.c_void_p, [C.c_void_p, C.c_int]),

@@ -86,6 +86,7 @@ struct wz_engine {
         float* d_box_enc = nullptr;
         float* d_logits = nullptr;
         float* d_ws = nullptr;
+        uint8_t* d_frames = nullptr;         // staging for host frames of this lane [max_batch][frame_stride] (lazy)
         WzPostBuffers post;
         void* d_post_scratch = nullptr;      // hist + count (memset per batch)
         WzFrameDesc* h_desc = nullptr;       // pinned
@@ -481,6 +482,7 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
         CK(hipMalloc((void**)&L.d_box_enc, (size_t)max_batch * h.num_anchors * 4 * 4));
         CK(hipMalloc((void**)&L.d_logits, (size_t)max_batch * h.num_anchors * h.num_classes * 4));
         CK(hipMalloc((void**)&L.d_ws, WZ_WS_BYTES));
+        CK(hipMalloc((void**)&L.d_frames, e->frame_stride * max_batch));
         WzPostBuffers& pb = L.post;
         pb.box_enc = L.d_box_enc;
         pb.logits = L.d_logits;
@@ -554,7 +556,7 @@ extern "C" void wz_destroy(wz_engine_t* e) {
         Lane& L = e->lanes[li];
         for (auto& kv : L.graphs) (void)hipGraphExecDestroy(kv.second);
         for (void* p : L.bufs) (void)hipFree(p);
-        void* lp[] = {L.d_box_enc, L.d_logits, L.d_ws, L.post.boxes, L.post.valid, L.d_post_scratch, L.post.cand,
+        void* lp[] = {L.d_frames, L.d_box_enc, L.d_logits, L.d_ws, L.post.boxes, L.post.valid, L.d_post_scratch, L.post.cand,
                       L.post.det_boxes, L.post.det_scores, L.post.det_classes, L.post.det_num, L.post.dbg, L.d_desc, L.d_rows,
                       L.d_pass};
         for (void* p : lp)
@@ -662,6 +664,49 @@ extern "C" int wz_detect_batch(wz_engine_t* e, int n, const uint8_t* const* rgb,
     const float el = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (ms)
         for (int i = 0; i < n; ++i) ms[i] = el;
+    return WZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host frames, asynchronously: H2D of batch k+1 (DMA engine) under the kernels of batch k
+// ------------------------------------------------------------------------------------------------
+extern "C" int wz_submit_host(wz_engine_t* e, int slot, int n, const uint8_t* const* rgb, const int* w, const int* h,
+                              const int* cam) {
+    if (!e || !rgb || !w || !h) return wz_fail(WZ_EINVAL, "wz_submit_host: null argument");
+    if (slot < 0 || slot >= e->n_lanes) return wz_fail(WZ_EINVAL, "slot %d out of range [0,%d)", slot, e->n_lanes);
+    if (n < 1 || n > e->max_batch) return wz_fail(WZ_ELIMIT, "batch %d exceeds max_batch %d", n, e->max_batch);
+    HIPCHK(hipSetDevice(e->device));
+    Lane& L = e->lanes[slot];
+    HIPCHK(hipEventSynchronize(L.done));   // the lane's previous batch (and its reads of the staging area) drained
+    if (!L.d_frames) return wz_fail(WZ_EINVAL, "wz_submit_host: lane %d has no staging area", slot);
+    std::vector<const uint8_t*> dptr(n);
+    for (int i = 0; i < n; ++i) {
+        if (!rgb[i] || w[i] < 1 || h[i] < 1) return wz_fail(WZ_EINVAL, "frame %d: bad pointer or size", i);
+        if (w[i] > e->max_w || h[i] > e->max_h || (size_t)w[i] * h[i] * 3 > e->frame_stride)
+            return wz_fail(WZ_ELIMIT, "frame %d is %dx%d, engine was created for at most %dx%d", i, w[i], h[i],
+                           e->max_w, e->max_h);
+        uint8_t* dst = L.d_frames + e->frame_stride * i;
+        // pageable source: the runtime stages it (slow, synchronous); registered / pinned source: one DMA
+        HIPCHK(hipMemcpyAsync(dst, rgb[i], (size_t)w[i] * h[i] * 3, hipMemcpyHostToDevice, L.stream));
+        dptr[i] = dst;
+    }
+    int rc = fill_desc(e, slot, n, dptr.data(), w, h, cam);
+    if (rc != WZ_OK) return rc;
+    return run_batch(e, slot, n);
+}
+
+// Page-lock a host range (e.g. a FrameBuffer arena, watsor/stream/share.py:35-41) so that frames inside it go to
+// the GPU by DMA at PCIe rate instead of through the runtime's bounce buffer.
+extern "C" int wz_host_register(wz_engine_t* e, void* ptr, uint64_t bytes) {
+    if (!e || !ptr || !bytes) return wz_fail(WZ_EINVAL, "wz_host_register: bad argument");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return WZ_OK;
+}
+extern "C" int wz_host_unregister(wz_engine_t* e, void* ptr) {
+    if (!e || !ptr) return wz_fail(WZ_EINVAL, "wz_host_unregister: bad argument");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipHostUnregister(ptr));
     return WZ_OK;
 }
 

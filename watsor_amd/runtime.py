@@ -116,6 +116,32 @@ class HipEngine:
         camv = (C.c_int32 * n)(*cams) if cams is not None else None
         _lib.check(self._lib.wz_submit_device(self._h, slot, n, ptrs, ws, hs, camv))
 
+    def submit_host(self, slot: int, frames: Sequence[np.ndarray], cams: Optional[Sequence[int]] = None) -> None:
+        """Asynchronous detect of host frames ((H,W,3) uint8, C-contiguous) on lane `slot`; collect with
+        `collect()` / `slot_rows()`.  The arrays must stay alive and unchanged until the slot is collected."""
+        n = len(frames)
+        for i, f in enumerate(frames):
+            if f.dtype != np.uint8 or f.ndim != 3 or f.shape[2] != 3 or not f.flags["C_CONTIGUOUS"]:
+                raise ValueError("frame %d must be a C-contiguous (H,W,3) uint8 array (it is read in place, asynchronously)" % i)
+        ptrs = (C.c_void_p * n)(*[f.ctypes.data for f in frames])
+        ws = (C.c_int32 * n)(*[f.shape[1] for f in frames])
+        hs = (C.c_int32 * n)(*[f.shape[0] for f in frames])
+        camv = (C.c_int32 * n)(*cams) if cams is not None else None
+        _lib.check(self._lib.wz_submit_host(self._h, slot, n, ptrs, ws, hs, camv))
+
+    def host_register(self, arr: np.ndarray) -> None:
+        """Page-lock the memory behind `arr` (frames handed over from it then travel by DMA)."""
+        _lib.check(self._lib.wz_host_register(self._h, C.c_void_p(arr.ctypes.data), arr.nbytes))
+
+    def host_unregister(self, arr: np.ndarray) -> None:
+        _lib.check(self._lib.wz_host_unregister(self._h, C.c_void_p(arr.ctypes.data)))
+
+    def collect(self, slot: int, out_rows: Sequence, out_pass: Optional[Sequence[np.ndarray]] = None) -> None:
+        n = len(out_rows)
+        outs = (C.c_void_p * n)(*[self._addr(r) for r in out_rows])
+        passv = (C.c_void_p * n)(*[p.ctypes.data for p in out_pass]) if out_pass is not None else None
+        _lib.check(self._lib.wz_collect(self._h, slot, outs, passv))
+
     def wait(self, slot: int) -> None:
         _lib.check(self._lib.wz_wait(self._h, slot))
 

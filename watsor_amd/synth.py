@@ -89,4 +89,4 @@ def synthetic_frame(width: int, height: int, seed: int, n_shapes: int = 4) -> np
         else:
             m = ((xx - cx) / float(rw)) ** 2 + ((yy - cy) / float(rh)) ** 2 <= 1.0
         img[m] = color
-    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+    return np.ascontiguousarray(np.clip(np.rint(img), 0, 255).astype(np.uint8))   # packed RGB24, row-major
