@@ -312,18 +312,21 @@ __global__ __launch_bounds__(256) void wz_k_splitk_reduce(const WzConvArgs a, co
 // zero page.  Two LDS buffers: the DMA of step s+1 runs under the MFMAs of step s, one barrier per step.
 // --------------------------------------------------------------------------------------------
 #define WZ_LDS_TM 128
-#define WZ_LDS_TN 64
-#define WZ_LDS_BUF (24 * 1024)   // 8 A fragments + 16 B fragments of 1 KiB
+// NW = 16-channel tiles per wave: 2 -> workgroup tile 128 x 64, 4 -> 128 x 128 (twice the MFMAs per DMA byte)
+#define WZ_LDS_TN(NW) (2 * (NW) * 16)
+#define WZ_LDS_BUF(NW) ((4 * (NW) + 16) * 1024)   // A fragments + 16 B fragments of 1 KiB
 
 __device__ __forceinline__ void wz_glds16(const void* gsrc, unsigned char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int KS>
+template <int KS, int NW>
 __global__ __launch_bounds__(256) void wz_k_conv_lds(const WzConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wz_cl_smem[];
     constexpr int taps = KS * KS;
+    constexpr int ABYTES = 4 * NW * 1024, BUF = WZ_LDS_BUF(NW);
+    const int n_tiles = a.n_pad >> 4;   // packed 16-channel tiles; a partial last workgroup tile stages zeros beyond
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(256) void wz_k_conv_lds(const WzConvArgs a) {
         bz = rest / a.grid_n;
     }
     const int m_base = bx * WZ_LDS_TM;
-    const int nt0 = by * (WZ_LDS_TN / 16);
+    const int nt0 = by * (2 * NW);
 
     // the two activation m-tiles this wave stages (2*wave, 2*wave+1): pixel of this lane
     const int hw = a.hout * a.wout;
@@ -366,51 +369,57 @@ __global__ __launch_bounds__(256) void wz_k_conv_lds(const WzConvArgs a) {
     const int s0 = bz * per, s1 = min(s0 + per, nsteps);
 
     auto stage = [&](int s, int buf) {
-        unsigned char* base = wz_cl_smem + buf * WZ_LDS_BUF;
+        unsigned char* base = wz_cl_smem + buf * BUF;
         const int q = s * 2;
         const int t = (KS == 1) ? 0 : q / a.kc, c = (KS == 1) ? q : q - t * a.kc;
         const int ky = (KS == 1) ? 0 : t / KS, kx = (KS == 1) ? 0 : t - ky * KS;
-        // A: fragments (nt = wave, kc = 0/1): 2 KiB contiguous in the packed weights
-        const half_t* wsrc = a.w + ((size_t)((nt0 + wave) * taps + t) * a.kc + c) * 512 + lane * 8;
-        wz_glds16(wsrc, base + (wave * 2 + 0) * 1024);
-        wz_glds16(wsrc + 512, base + (wave * 2 + 1) * 1024);
+        // A: this wave stages NW/2 channel tiles x (kc = 0/1): each 2 KiB contiguous in the packed weights
+#pragma unroll
+        for (int i = 0; i < NW / 2; ++i) {
+            const int ntl = wave * (NW / 2) + i;
+            const bool have = nt0 + ntl < n_tiles;   // wave-uniform
+            const half_t* wsrc = have ? a.w + ((size_t)((nt0 + ntl) * taps + t) * a.kc + c) * 512 + lane * 8
+                                      : a.zeros + lane * 8;
+            wz_glds16(wsrc, base + (ntl * 2 + 0) * 1024);
+            wz_glds16(have ? wsrc + 512 : wsrc, base + (ntl * 2 + 1) * 1024);
+        }
         // B: fragments (mt = 2*wave + i, kc = 0/1)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int iy = iy0[i] + ky, ix = ix0[i] + kx;
             const bool ok = mv[i] && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
             const half_t* src = ok ? a.in + ((size_t)(boff[i] + iy) * a.win + ix) * a.cin + c * 32 + g * 8 : a.zeros;
-            unsigned char* dst = base + 8 * 1024 + ((wave * 2 + i) * 2) * 1024;
+            unsigned char* dst = base + ABYTES + ((wave * 2 + i) * 2) * 1024;
             wz_glds16(src, dst);
             wz_glds16(ok ? src + 32 : a.zeros, dst + 1024);
         }
     };
 
-    float4_t acc[4][2];
+    float4_t acc[4][NW];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NW; ++nt) acc[mt][nt] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
     if (s0 < s1) stage(s0, 0);
     for (int s = s0; s < s1; ++s) {
         const int buf = (s - s0) & 1;
         __syncthreads();   // this step's DMA has landed (vmcnt(0) is part of the barrier); the other buffer is free
         if (s + 1 < s1) stage(s + 1, buf ^ 1);
-        const unsigned char* base = wz_cl_smem + buf * WZ_LDS_BUF;
+        const unsigned char* base = wz_cl_smem + buf * BUF;
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) {
-            half8_t fa[2], fb[4];
+            half8_t fa[NW], fb[4];
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-                fa[nt] = *reinterpret_cast<const half8_t*>(base + ((wn * 2 + nt) * 2 + kc) * 1024 + lane * 16);
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-                fb[mt] = *reinterpret_cast<const half8_t*>(base + 8 * 1024 + ((wm * 4 + mt) * 2 + kc) * 1024 + lane * 16);
+            for (int nt = 0; nt < NW; ++nt)
+                fa[nt] = *reinterpret_cast<const half8_t*>(base + ((wn * NW + nt) * 2 + kc) * 1024 + lane * 16);
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
+                fb[mt] = *reinterpret_cast<const half8_t*>(base + ABYTES + ((wm * 4 + mt) * 2 + kc) * 1024 + lane * 16);
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NW; ++nt)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[nt], fb[mt], acc[mt][nt], 0, 0, 0);
         }
     }
@@ -419,10 +428,10 @@ __global__ __launch_bounds__(256) void wz_k_conv_lds(const WzConvArgs a) {
     for (int mt = 0; mt < 4; ++mt) {
         const int m = m_base + (wm * 4 + mt) * 16 + r16;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int n4 = (nt0 + wn * 2 + nt) * 16 + g * 4;
+        for (int nt = 0; nt < NW; ++nt) {
+            const int n4 = (nt0 + wn * NW + nt) * 16 + g * 4;
             if (a.splitk > 1) {
-                if (m < a.M)
+                if (m < a.M && n4 < a.n_pad)
                     *reinterpret_cast<float4_t*>(reinterpret_cast<float*>(a.out) +
                                                  ((size_t)bz * a.M + m) * a.n_pad + n4) = acc[mt][nt];
             } else {
@@ -441,12 +450,20 @@ static int wz_env_int(const char* name, int dflt) {
 bool wz_conv_use_lds(const WzConvArgs& a) {
     static const int min_m = wz_env_int("WZ_LDS_MIN_M", 128);
     static const int min_k = wz_env_int("WZ_LDS_MIN_KCHUNKS", 8);
-    return a.zeros && a.n_pad % WZ_LDS_TN == 0 && a.kc % 2 == 0 && a.M >= min_m && a.kchunks >= min_k && a.cin % 32 == 0;
+    return a.zeros && a.n_pad % 64 == 0 && a.kc % 2 == 0 && a.M >= min_m && a.kchunks >= min_k && a.cin % 32 == 0;
+}
+
+// 128 x 128 workgroup tiles where there are enough channels and pixels for them to pay
+static int wz_lds_nw(int M, int n_pad, int kchunks) {
+    static const int force = wz_env_int("WZ_LDS_NW", 0);
+    if (force == 2 || force == 4) return force;
+    return (n_pad >= 256 && M >= 512 && kchunks >= 64) ? 4 : 2;   // measured: the two big heads gain, Conv_1 (K = 320) loses
 }
 
 int wz_choose_splitk_lds(int M, int n_pad, int kchunks) {
-    static const int target = wz_env_int("WZ_LDS_WGS", 512);
-    const int wgs = ((M + WZ_LDS_TM - 1) / WZ_LDS_TM) * (n_pad / WZ_LDS_TN);
+    static const int target = wz_env_int("WZ_LDS_WGS", 256);   // the DMA path saturates near one workgroup per CU
+    const int tn = WZ_LDS_TN(wz_lds_nw(M, n_pad, kchunks));
+    const int wgs = ((M + WZ_LDS_TM - 1) / WZ_LDS_TM) * ((n_pad + tn - 1) / tn);
     const int nsteps = kchunks / 2;
     int s = (target + wgs - 1) / wgs;
     if (s > nsteps / 4) s = nsteps / 4;   // >= 4 steps per split
@@ -485,20 +502,30 @@ static void wz_launch_conv_cfg(const WzConvArgs& a, hipStream_t s) {
 }
 
 void wz_conv_init() {   // kernel attributes (before any stream capture)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wz_k_conv_lds<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WZ_LDS_BUF);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wz_k_conv_lds<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WZ_LDS_BUF);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wz_k_conv_lds<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WZ_LDS_BUF(2));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wz_k_conv_lds<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WZ_LDS_BUF(2));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wz_k_conv_lds<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WZ_LDS_BUF(4));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wz_k_conv_lds<3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WZ_LDS_BUF(4));
 }
 
 void wz_launch_conv(const WzConvArgs& a0, hipStream_t s) {
     if (wz_conv_use_lds(a0)) {
         WzConvArgs a = a0;
         a.grid_m = (a.M + WZ_LDS_TM - 1) / WZ_LDS_TM;
-        a.grid_n = a.n_pad / WZ_LDS_TN;
+        const int nw = wz_lds_nw(a.M, a.n_pad, a.kchunks);
+        a.grid_n = (a.n_pad + WZ_LDS_TN(nw) - 1) / WZ_LDS_TN(nw);
         dim3 grid(a.grid_m * a.grid_n * a.splitk);
-        if (a.ksize == 1)
-            hipLaunchKernelGGL(wz_k_conv_lds<1>, grid, dim3(256), 2 * WZ_LDS_BUF, s, a);
-        else
-            hipLaunchKernelGGL(wz_k_conv_lds<3>, grid, dim3(256), 2 * WZ_LDS_BUF, s, a);
+        if (nw == 4) {
+            if (a.ksize == 1)
+                hipLaunchKernelGGL((wz_k_conv_lds<1, 4>), grid, dim3(256), 2 * WZ_LDS_BUF(4), s, a);
+            else
+                hipLaunchKernelGGL((wz_k_conv_lds<3, 4>), grid, dim3(256), 2 * WZ_LDS_BUF(4), s, a);
+        } else {
+            if (a.ksize == 1)
+                hipLaunchKernelGGL((wz_k_conv_lds<1, 2>), grid, dim3(256), 2 * WZ_LDS_BUF(2), s, a);
+            else
+                hipLaunchKernelGGL((wz_k_conv_lds<3, 2>), grid, dim3(256), 2 * WZ_LDS_BUF(2), s, a);
+        }
         return;
     }
     const WzConvArgs& a = a0;

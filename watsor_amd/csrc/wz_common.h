@@ -39,7 +39,7 @@ struct WzConvArgs {
     float* out2;                // WZ_OUT_HEAD: class-logit buffer (out = box-encoding buffer)
     int64_t out2_batch_stride, out2_off;
     int32_t n_box;              // WZ_OUT_HEAD: columns [0, n_box) are box encodings, the rest class logits
-    const half_t* zeros;        // >= 64 zero halfs in HBM: source of out-of-frame lanes in the LDS-tiled kernel
+    const half_t* zeros;        // 4 KiB of zeros in HBM: source of out-of-frame lanes / absent tiles in the LDS-tiled kernel
     int32_t grid_m, grid_n;     // LDS-tiled kernel: pixel tiles x channel tiles (filled in by the launcher)
     float* ws;                  // fp32 engine: split-K workspace (the fp16 kernels get it through `out`)
 };

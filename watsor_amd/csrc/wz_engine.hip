@@ -66,7 +66,7 @@ struct wz_engine {
     bool no_reuse = false, use_graph = true, use_splitk = true;
 
     uint8_t* d_weights = nullptr;
-    half_t* d_zeros = nullptr;               // 256 zero bytes
+    half_t* d_zeros = nullptr;               // 4 KiB of zeros
     unsigned long long* d_mbdbg = nullptr;   // WZ_MB_DEBUG=1: [n_ops][16] phase timestamps of the fused-block kernels
     std::vector<int> mb_groups;
     float* d_anchors = nullptr;
@@ -429,8 +429,8 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
         CK(hipMemset(e->d_mbdbg, 0, (size_t)h.n_ops * 16 * 8));
         e->mb_groups.assign(h.n_ops, 0);
     }
-    CK(hipMalloc((void**)&e->d_zeros, 256));
-    CK(hipMemset(e->d_zeros, 0, 256));
+    CK(hipMalloc((void**)&e->d_zeros, 4096));
+    CK(hipMemset(e->d_zeros, 0, 4096));
     CK(hipMalloc((void**)&e->d_anchors, (size_t)h.num_anchors * 16));
     CK(hipMemcpy(e->d_anchors, e->blob.data() + h.anchors_off, (size_t)h.num_anchors * 16, hipMemcpyHostToDevice));
     e->frame_stride = ((size_t)max_width * max_height * 3 + 255) & ~(size_t)255;
