@@ -133,17 +133,68 @@ __device__ __forceinline__ void wz_epilogue4_f32(const WzConvArgs& a, int m, int
     }
 }
 
-// wave = 32 pixels x 32 channels (2 x 2 MFMA tiles); a.kc = 16-channel chunks per tap, a.kchunks = taps * kc
+// wave = 32 pixels x 32 channels (2 x 2 MFMA tiles); a.kc = 16-channel chunks per tap, a.kchunks = taps * kc.
+// Register double buffer of U chunks each: the loads of the next U chunks are in flight under the 16 U MFMAs
+// (32 cycles each on a SIMD) of the current ones.
+template <int U>
+struct F32Frags {
+    float4_t xb[U][2], wa[U][2];
+};
+
+template <int KS, int U>
+__device__ __forceinline__ void wz_f32_load(const WzConvArgs& a, F32Frags<U>& f, int& ql, const int q1, int& t, int& c,
+                                            const int (&iy0)[2], const int (&ix0)[2], const int (&boff)[2],
+                                            const bool (&mv)[2], const float* in, const float* wlane, const int nt0,
+                                            const int g) {
+    constexpr int taps = KS * KS;
+    const float4_t zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const bool live = ql < q1;   // wave-uniform
+        const int ky = (KS == 1) ? 0 : t / KS, kx = (KS == 1) ? 0 : t - ky * KS;
+        const bool cin_ok = (c * 16 + g * 4) < a.cin;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int iy = iy0[mt] + ky, ix = ix0[mt] + kx;
+            const bool ok = live && cin_ok && mv[mt] && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
+            f.xb[u][mt] = ok ? *reinterpret_cast<const float4_t*>(in + ((size_t)(boff[mt] + iy) * a.win + ix) * a.cin + c * 16 + g * 4)
+                             : zero;
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+            f.wa[u][nt] = live ? *reinterpret_cast<const float4_t*>(wlane + ((size_t)((nt0 + nt) * taps + t) * a.kc + c) * 256)
+                               : zero;
+        ++ql;
+        if (++c == a.kc) {
+            c = 0;
+            ++t;
+        }
+    }
+}
+
+template <int U>
+__device__ __forceinline__ void wz_f32_mfma(const F32Frags<U>& f, float4_t (&acc)[2][2]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.wa[u][nt][j], f.xb[u][mt][j], acc[mt][nt], 0, 0, 0);
+}
+
 template <int KS>
 __global__ __launch_bounds__(256) void wz_k_conv_f32(const WzConvArgs a) {
-    constexpr int MT = 2, NT = 2, taps = KS * KS;
+    constexpr int MT = 2, NT = 2, U = 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
     const int m_base = (blockIdx.x * 4 + wave) * (MT * 16);
     const int nt0 = blockIdx.y * NT;
     if (m_base >= a.M) return;
     const float* in = reinterpret_cast<const float*>(a.in);
-    const float* wts = reinterpret_cast<const float*>(a.w);
+    const float* wlane = reinterpret_cast<const float*>(a.w) + lane * 4;
 
     const int hw = a.hout * a.wout;
     int iy0[MT], ix0[MT], boff[MT];
@@ -167,33 +218,17 @@ __global__ __launch_bounds__(256) void wz_k_conv_f32(const WzConvArgs a) {
 
     const int per = (a.kchunks + a.splitk - 1) / a.splitk;
     const int q0 = blockIdx.z * per, q1 = min(q0 + per, a.kchunks);
-    int t = (KS == 1) ? 0 : q0 / a.kc, c = (KS == 1) ? q0 : q0 - t * a.kc;
-    const float4_t zero = {0.f, 0.f, 0.f, 0.f};
-    for (int q = q0; q < q1; ++q) {
-        const int ky = (KS == 1) ? 0 : t / KS, kx = (KS == 1) ? 0 : t - ky * KS;
-        const bool cin_ok = (c * 16 + g * 4) < a.cin;
-        float4_t xb[MT], wa[NT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int iy = iy0[mt] + ky, ix = ix0[mt] + kx;
-            const bool ok = cin_ok && mv[mt] && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
-            xb[mt] = ok ? *reinterpret_cast<const float4_t*>(in + ((size_t)(boff[mt] + iy) * a.win + ix) * a.cin + c * 16 + g * 4)
-                        : zero;
-        }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-            wa[nt] = *reinterpret_cast<const float4_t*>(wts + ((size_t)((nt0 + nt) * taps + t) * a.kc + c) * 256 + lane * 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[nt][j], xb[mt][j], acc[mt][nt], 0, 0, 0);
-        if (++c == a.kc) {
-            c = 0;
-            ++t;
-        }
+    int ql = q0, t = (KS == 1) ? 0 : q0 / a.kc, c = (KS == 1) ? q0 : q0 - t * a.kc;
+    F32Frags<U> fa, fb;
+    wz_f32_load<KS, U>(a, fa, ql, q1, t, c, iy0, ix0, boff, mv, in, wlane, nt0, g);
+    for (int q = q0; q < q1;) {
+        wz_f32_load<KS, U>(a, fb, ql, q1, t, c, iy0, ix0, boff, mv, in, wlane, nt0, g);
+        wz_f32_mfma(fa, acc);
+        q += U;
+        if (q >= q1) break;
+        wz_f32_load<KS, U>(a, fa, ql, q1, t, c, iy0, ix0, boff, mv, in, wlane, nt0, g);
+        wz_f32_mfma(fb, acc);
+        q += U;
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
