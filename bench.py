@@ -256,6 +256,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the -p 32 engine leg (profiling runs: one engine's kernels only)")
     ap.add_argument("--table", default=None, help="write the per-kernel roofline table (JSON) here")
     ap.add_argument("--dry-run", action="store_true",
                     help="harness self-test without a GPU: a stub engine that sleeps 2 ms per step (used by the "
@@ -379,6 +380,7 @@ def main():
         }
         if world == 1:
             eng.close()
+        if world == 1 and not args.no_fp32_leg:
             out["fp32_engine"] = fp32_engine_leg(weights, host_frames, rank)
             note("fp32 engine leg done")
         if world == 1 and not args.no_cpu_baseline:
