@@ -7,6 +7,8 @@ import pytest
 
 from conftest import make_engine
 from oracle import filters as of
+from oracle import zones as oz
+from watsor_amd.coco import COCO_CLASSES
 from watsor_amd.filter.hip_filter import HipCameraFilter
 from watsor_amd.runtime import ROW_DTYPE
 from watsor_amd.share import BoundingBox, Detection
@@ -130,3 +132,66 @@ def test_filters_inside_detect_batch(eng):
     with pytest.raises(ValueError):                                  # camera filter was set for 640x480
         eng.detect_batch([synthetic_frame(1280, 720, 1)], rows[:1], cams=[5])
     flt.close()
+
+
+def blob_mask(width, height, seed, n_blobs):
+    """RGBA-style alpha plane in the spirit of BASELINE configs[3]: a few filled blobs (>= 8 px thick, alpha 255)
+    on a translucent background (alpha 204), with an anti-aliased rim (alpha 230) that is NOT part of a zone."""
+    rng = np.random.default_rng(seed)
+    alpha = np.full((height, width), 204, np.uint8)
+    yy, xx = np.mgrid[0:height, 0:width]
+    for _ in range(n_blobs):
+        cx, cy = int(rng.integers(width // 8, 7 * width // 8)), int(rng.integers(height // 8, 7 * height // 8))
+        rx, ry = int(rng.integers(max(8, width // 24), width // 7)), int(rng.integers(max(8, height // 24), height // 7))
+        if rng.random() < 0.5:
+            inner = (np.abs(xx - cx) <= rx) & (np.abs(yy - cy) <= ry)
+            rim = (np.abs(xx - cx) <= rx + 2) & (np.abs(yy - cy) <= ry + 2)
+        else:
+            d = ((xx - cx) / float(rx)) ** 2 + ((yy - cy) / float(ry)) ** 2
+            inner, rim = d <= 1.0, d <= 1.08
+        alpha[rim & (alpha != 255)] = 230
+        alpha[inner] = 255
+    return alpha
+
+
+def test_many_cameras_with_masks_and_thresholds_mixed_resolutions(model_dir):
+    """BASELINE configs[3]/[4] in small: 1920x1080 and 640x480 cameras, each with its own zone mask and the
+    thresholds of the reference's sample config (config/config.yaml:69-79), batched together.  The rows come
+    from the GPU detector; pass bytes and zones[] must equal the oracle's literal filters on those rows."""
+    e = make_engine(model_dir, max_batch=8)
+    try:
+        cams, flts = [], []
+        for cam in range(6):
+            w, h = (1920, 1080) if cam % 2 == 0 else (640, 480)
+            alpha = blob_mask(w, h, 100 + cam, 2 + cam % 5)
+            nz = len(oz.zone_polygons(alpha))                          # zones a config names must exist (mask.py:36-37)
+            cfg = {"width": w, "height": h,
+                   "detect": [{"person": {"area": 20, "confidence": 60, "zones": []}},
+                              {"car": {"area": 10, "confidence": 50, "zones": [z for z in (1, 3, 5) if z <= nz]}},
+                              {"truck": {"area": 10, "confidence": 50, "zones": []}},
+                              {"bench": {"area": 1, "confidence": 30, "zones": [min(2, nz)]}},
+                              # the seeded random-init network mostly reports label 14: let it through on odd cameras
+                              {COCO_CLASSES[14]: {"area": 1, "confidence": 30, "zones": [] if cam % 2 else [1]}}]}
+            flt = HipCameraFilter(e, 20 + cam, cfg, alpha=alpha)
+            assert flt.num_zones >= 1
+            cams.append((20 + cam, w, h, [of.ConfidenceFilter(cfg), of.AreaFilter(cfg), of.MaskFilter(cfg, alpha=alpha)]))
+            flts.append(flt)
+        order = [0, 1, 2, 3, 4, 5, 0, 3]                               # 8 frames, cameras repeated
+        frames = [synthetic_frame(cams[c][1], cams[c][2], 700 + i) for i, c in enumerate(order)]
+        rows = [np.zeros(100, ROW_DTYPE) for _ in frames]
+        passes = [np.full(100, 9, np.uint8) for _ in frames]
+        e.detect_batch(frames, rows, cams=[cams[c][0] for c in order], out_pass=passes)
+        hits = 0
+        for i, c in enumerate(order):
+            plain = rows[i].copy()
+            plain["zones"] = 0
+            want_pass, want_zones = oracle_verdict(cams[c][3], plain)
+            np.testing.assert_array_equal(passes[i], want_pass)
+            np.testing.assert_array_equal(rows[i]["zones"], want_zones)
+            assert (rows[i]["label"] >= 1).all() and (rows[i]["x_max"] < cams[c][1]).all() and (rows[i]["y_max"] < cams[c][2]).all()
+            hits += int(want_pass.sum())
+        assert hits > 0
+        for f in flts:
+            f.close()
+    finally:
+        e.close()
