@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void wz_k_mbconv(const WzMbArgs a) {
     const int s = a.stride;
     const int hw_ = (a.tw - 1) * s + 3, hh_ = (a.th - 1) * s + 3;
     const int P = hh_ * hw_, Q = a.th * a.tw;
-    const int nq_tiles = (Q + 15) >> 4;
+
     const int iy_base = oy0 * s - a.pad_t, ix_base = ox0 * s - a.pad_l;
     const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
@@ -230,46 +230,59 @@ __global__ __launch_bounds__(256) void wz_k_mbconv(const WzMbArgs a) {
             if (a.ebufs == 1 && ch + 1 < ch_end) __syncthreads();
         }
     } else {
-        // ---- no expand stage: depthwise taps gathered from global memory (zero outside the frame)
+        // ---- no expand stage: depthwise taps gathered from global memory (zero outside the frame).
+        // Every load of a K step is issued before its first use and none sits behind a branch (out-of-frame
+        // taps load a clamped address and are zeroed afterwards), so a step costs ONE exposed memory latency.
         const int kk_begin = blockIdx.y * a.cpg, kk_end = min(kk_begin + a.cpg, a.kc);
+        int hy0[MQ], hx0[MQ];
+#pragma unroll
+        for (int j = 0; j < MQ; ++j) {
+            hy0[j] = hp0[j] / hw_;
+            hx0[j] = hp0[j] - hy0[j] * hw_;
+        }
         for (int kk = kk_begin; kk < kk_end; ++kk) {
             const int cbase = kk * 32 + g * 8;
+            const int cload = min(cbase, a.cmid - 8);          // channel groups beyond cmid: clamped load, zeroed below
             const bool cok = cbase < a.cmid;
-            half8_t wt[9];
+            half8_t wt[9], x[MQ][9], wp[NTO];
+            bool okx[MQ][9];
 #pragma unroll
             for (int tp = 0; tp < 9; ++tp)
                 wt[tp] = *reinterpret_cast<const half8_t*>(a.wd + (size_t)tp * a.cmid_pad + cbase);
             const float4_t b0 = *reinterpret_cast<const float4_t*>(a.bd + cbase);
             const float4_t b1 = *reinterpret_cast<const float4_t*>(a.bd + cbase + 4);
 #pragma unroll
-            for (int j = 0; j < MQ; ++j) {
-                if (wave + 4 * j < nq_tiles) {
-                    const int hy0 = hp0[j] / hw_, hx0 = hp0[j] - hy0 * hw_;
-                    float d[8];
+            for (int nt = 0; nt < NTO; ++nt)
+                wp[nt] = *reinterpret_cast<const half8_t*>(a.wp + ((size_t)(nt * a.kc + kk) * 64 + lane) * 8);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { d[r] = b0[r]; d[4 + r] = b1[r]; }
+            for (int j = 0; j < MQ; ++j)
 #pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
+                for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) {
-                            const int iy = iy_base + hy0 + ky, ix = ix_base + hx0 + kx;
-                            const bool ok = cok && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
-                            const half8_t x = ok ? *reinterpret_cast<const half8_t*>(
-                                                       a.in + ((size_t)(b * a.hin + iy) * a.win + ix) * a.cmid + cbase)
-                                                 : zero8;
-#pragma unroll
-                            for (int r = 0; r < 8; ++r) d[r] = fmaf((float)x[r], (float)wt[ky * 3 + kx][r], d[r]);
-                        }
-                    half8_t bf;
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) bf[r] = (half_t)fminf(fmaxf(d[r], 0.0f), 6.0f);
-#pragma unroll
-                    for (int nt = 0; nt < NTO; ++nt) {
-                        const half8_t wp = *reinterpret_cast<const half8_t*>(
-                            a.wp + ((size_t)(nt * a.kc + kk) * 64 + lane) * 8);
-                        acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wp, bf, acc[j][nt], 0, 0, 0);
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int iy = iy_base + hy0[j] + ky, ix = ix_base + hx0[j] + kx;
+                        okx[j][ky * 3 + kx] = cok && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
+                        const int cy = min(max(iy, 0), a.hin - 1), cx = min(max(ix, 0), a.win - 1);
+                        x[j][ky * 3 + kx] = *reinterpret_cast<const half8_t*>(
+                            a.in + ((size_t)(b * a.hin + cy) * a.win + cx) * a.cmid + cload);
                     }
+#pragma unroll
+            for (int j = 0; j < MQ; ++j) {
+                float d[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { d[r] = b0[r]; d[4 + r] = b1[r]; }
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) {
+                    const half8_t xv = okx[j][tp] ? x[j][tp] : zero8;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) d[r] = fmaf((float)xv[r], (float)wt[tp][r], d[r]);
                 }
+                half8_t bf;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) bf[r] = (half_t)fminf(fmaxf(d[r], 0.0f), 6.0f);
+#pragma unroll
+                for (int nt = 0; nt < NTO; ++nt)
+                    acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wp[nt], bf, acc[j][nt], 0, 0, 0);
             }
         }
     }

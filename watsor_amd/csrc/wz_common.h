@@ -64,7 +64,7 @@ struct WzMbArgs {
     uint64_t ws_bytes;
     int32_t M;             // n * hout * wout
     unsigned long long* dbg;   // diagnostics: 16 timestamps (first / last workgroup), or nullptr
-    int32_t th, tw, tiles_y, tiles_x, nsplit, cpg, stage, ebufs;   // filled in by the launcher
+    int32_t th, tw, tiles_y, tiles_x, nsplit, cpg, stage, ebufs, nb;   // filled in by the launcher (nb = frames)
 };
 
 // Per-camera filter state resident in HBM (see wz_set_camera_filter).
@@ -103,6 +103,7 @@ void wz_launch_dw_f32(const float* in, const float* w, const float* bias, float*
                       int hout, int wout, int stride, int pad_t, int pad_l, int act, hipStream_t s);
 void wz_launch_conv_f32(const WzConvArgs& a, hipStream_t s);   // + its split-K reduce when a.splitk > 1
 int wz_launch_mbconv(const WzMbArgs& a, int n, hipStream_t s, bool prepare);   // -1: no kernel; else #channel groups
+int wz_launch_mbconv_wave(const WzMbArgs& a, int n, hipStream_t s, bool prepare);   // wave-per-tile variant; -2: not applicable
 
 #define WZ_HIST_BINS 1024
 #define WZ_CAND_CAP 4096

@@ -164,7 +164,8 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t) {
             a.ws = e->use_splitk ? L.d_ws : nullptr;
             a.ws_bytes = WZ_WS_BYTES;
             a.dbg = e->d_mbdbg ? e->d_mbdbg + (size_t)i * 16 : nullptr;
-            const int groups = wz_launch_mbconv(a, n, s, false);
+            int groups = wz_launch_mbconv_wave(a, n, s, false);   // large maps: one wavefront per pixel tile
+            if (groups == -2) groups = wz_launch_mbconv(a, n, s, false);
             if (e->d_mbdbg) e->mb_groups[i] = groups;
             if (t) t->mark();
             if (groups > 1) {   // sum the channel groups' partials in a fixed order, + bias, + residual, -> fp16
@@ -419,6 +420,7 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
         if (e->ops[i].kind == WZ_OP_MBCONV) {
             wz_engine::Lane none;
             (void)wz_launch_mbconv(mb_args(e, none, e->ops[i]), max_batch, nullptr, true);
+            (void)wz_launch_mbconv_wave(mb_args(e, none, e->ops[i]), max_batch, nullptr, true);
         }
 
     const WzBlobHeader& h = e->hdr;
