@@ -61,14 +61,19 @@ __device__ __forceinline__ bool wz_candidate(const WzPostBuffers& b, const WzPos
     return true;
 }
 
+// Entries per thread of the two scans over the 1917 x 91 class logits (measured: 32 per thread, i.e. 22 fat
+// workgroups per frame, triples both kernels' time -- the scans want every CU).
+#ifndef POST_ITEMS
 #define POST_ITEMS 8
+#endif
+#define POST_LIST 1024   // candidates one workgroup stages in LDS before publishing them (more go straight to HBM)
 __global__ __launch_bounds__(256) void wz_k_hist(WzPostBuffers b, WzPostConsts k) {
     __shared__ uint32_t h[WZ_HIST_BINS];
     for (int i = threadIdx.x; i < WZ_HIST_BINS; i += 256) h[i] = 0;
     __syncthreads();
     const int f = blockIdx.y, total = k.num_anchors * k.num_classes;
     const int base = blockIdx.x * 256 * POST_ITEMS;
-#pragma unroll
+#pragma unroll 4
     for (int it = 0; it < POST_ITEMS; ++it) {
         const int j = base + it * 256 + threadIdx.x;
         uint32_t key, tie;
@@ -136,28 +141,28 @@ __global__ __launch_bounds__(256) void wz_k_compact(WzPostBuffers b, WzPostConst
         b.band[2 * f + 1] = all;
     }
     const int base = blockIdx.x * 256 * POST_ITEMS;
-    uint32_t keys[POST_ITEMS], ties[POST_ITEMS], pos[POST_ITEMS];
-    uint32_t mask = 0;
-#pragma unroll
+    __shared__ uint2 s_list[POST_LIST];
+#pragma unroll 4
     for (int it = 0; it < POST_ITEMS; ++it) {
         const int j = base + it * 256 + threadIdx.x;
-        keys[it] = ties[it] = pos[it] = 0;
-        if (j < total && wz_candidate(b, k, f, j, keys[it], ties[it]) && (keys[it] >> 20) >= thr) {
-            mask |= 1u << it;
-            pos[it] = atomicAdd(&s_cnt, 1u);     // LDS atomic: order is irrelevant, the list gets sorted
+        uint32_t key, tie;
+        if (j < total && wz_candidate(b, k, f, j, key, tie) && (key >> 20) >= thr) {
+            const uint32_t p = atomicAdd(&s_cnt, 1u);     // LDS atomic: order is irrelevant, the list gets sorted
+            if (p < POST_LIST) {
+                s_list[p] = make_uint2(key, tie);
+            } else {                                      // a dense band: publish this one directly
+                const uint32_t q = atomicAdd(&b.count[f], 1u);
+                if (q < WZ_CAND_CAP) b.cand[(size_t)f * WZ_CAND_CAP + q] = make_uint2(key, tie);
+            }
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0 && s_cnt) s_base = atomicAdd(&b.count[f], s_cnt);   // one global atomic per block
+    const uint32_t n_list = min(s_cnt, (uint32_t)POST_LIST);
+    if (threadIdx.x == 0 && n_list) s_base = atomicAdd(&b.count[f], n_list);   // one global atomic per block
     __syncthreads();
-    if (mask) {
-        const uint32_t g0 = s_base;
-#pragma unroll
-        for (int it = 0; it < POST_ITEMS; ++it)
-            if ((mask >> it) & 1u) {
-                const uint32_t p = g0 + pos[it];
-                if (p < WZ_CAND_CAP) b.cand[(size_t)f * WZ_CAND_CAP + p] = make_uint2(keys[it], ties[it]);
-            }
+    for (uint32_t i = threadIdx.x; i < n_list; i += 256) {
+        const uint32_t p = s_base + i;
+        if (p < WZ_CAND_CAP) b.cand[(size_t)f * WZ_CAND_CAP + p] = s_list[i];
     }
 }
 
