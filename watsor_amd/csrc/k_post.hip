@@ -28,6 +28,11 @@ __device__ __forceinline__ float wz_sigmoid(float x) { return 1.0f / (1.0f + exp
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void wz_k_decode(WzPostBuffers b, WzPostConsts k, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    // first kernel of the post-processing chain: it also clears the per-frame histogram, candidate count and band
+    // record (num_anchors > WZ_HIST_BINS threads per frame exist) -- one launch less than a memset node
+    if (i < n * WZ_HIST_BINS) b.hist[i] = 0u;
+    if (i < n) b.count[i] = 0u;
+    if (i < 2 * n) b.band[i] = 0u;
     if (i >= n * k.num_anchors) return;
     const int a = i % k.num_anchors;
     const float4_t e = *reinterpret_cast<const float4_t*>(b.box_enc + (size_t)i * 4);

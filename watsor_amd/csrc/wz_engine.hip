@@ -93,8 +93,10 @@ struct wz_engine {
         WzFrameDesc* d_desc = nullptr;
         wz_detection_t* d_rows = nullptr;
         uint8_t* d_pass = nullptr;
-        wz_detection_t* h_rows = nullptr;    // pinned
+        wz_detection_t* h_rows = nullptr;    // pinned, device-mapped: wz_k_rows writes it directly
         uint8_t* h_pass = nullptr;
+        wz_detection_t* m_rows = nullptr;    // device addresses of h_rows / h_pass
+        uint8_t* m_pass = nullptr;
         hipEvent_t done = nullptr;
         int n = 0;
         std::map<int, hipGraphExec_t> graphs;    // key = batch size
@@ -243,8 +245,7 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t) {
 
 static void enqueue_post(wz_engine* e, Lane& L, bool rows, int n, StageTimer* t) {
     hipStream_t s = L.stream;
-    (void)hipMemsetAsync(L.d_post_scratch, 0, e->post_scratch_bytes, s);
-    wz_launch_decode(L.post, e->pc, n, s);
+    wz_launch_decode(L.post, e->pc, n, s);   // (also clears hist / count / band)
     if (t) t->mark();
     wz_launch_hist(L.post, e->pc, n, s);
     if (t) t->mark();
@@ -253,7 +254,8 @@ static void enqueue_post(wz_engine* e, Lane& L, bool rows, int n, StageTimer* t)
     wz_launch_nms(L.post, e->pc, n, s);
     if (t) t->mark();
     if (rows) {
-        wz_launch_rows(L.post, L.d_desc, e->d_cams, n, e->pc.max_total, L.d_rows, L.d_pass, s);
+        // the rows go straight into the lane's pinned host block (device-mapped): no D2H copy nodes behind the kernel
+        wz_launch_rows(L.post, L.d_desc, e->d_cams, n, e->pc.max_total, L.m_rows, L.m_pass, s);
         if (t) t->mark();
     }
 }
@@ -268,9 +270,6 @@ static void enqueue_batch(wz_engine* e, Lane& L, int n, StageTimer* t) {
     if (t) t->mark();
     enqueue_network(e, L, n, t);
     enqueue_post(e, L, true, n, t);
-    (void)hipMemcpyAsync(L.h_rows, L.d_rows, sizeof(wz_detection_t) * WZ_MAX_DETECTIONS * n,
-                         hipMemcpyDeviceToHost, s);
-    (void)hipMemcpyAsync(L.h_pass, L.d_pass, (size_t)WZ_MAX_DETECTIONS * n, hipMemcpyDeviceToHost, s);
 }
 
 static int run_batch(wz_engine* e, int slot, int n) {
@@ -506,8 +505,10 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
         CK(hipMalloc((void**)&L.d_desc, sizeof(WzFrameDesc) * max_batch));
         CK(hipMalloc((void**)&L.d_rows, sizeof(wz_detection_t) * WZ_MAX_DETECTIONS * max_batch));
         CK(hipMalloc((void**)&L.d_pass, (size_t)WZ_MAX_DETECTIONS * max_batch));
-        CK(hipHostMalloc((void**)&L.h_rows, sizeof(wz_detection_t) * WZ_MAX_DETECTIONS * max_batch, hipHostMallocDefault));
-        CK(hipHostMalloc((void**)&L.h_pass, (size_t)WZ_MAX_DETECTIONS * max_batch, hipHostMallocDefault));
+        CK(hipHostMalloc((void**)&L.h_rows, sizeof(wz_detection_t) * WZ_MAX_DETECTIONS * max_batch, hipHostMallocMapped));
+        CK(hipHostMalloc((void**)&L.h_pass, (size_t)WZ_MAX_DETECTIONS * max_batch, hipHostMallocMapped));
+        CK(hipHostGetDevicePointer((void**)&L.m_rows, L.h_rows, 0));
+        CK(hipHostGetDevicePointer((void**)&L.m_pass, L.h_pass, 0));
         CK(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
     }
     e->stream = e->lanes[0].stream;
