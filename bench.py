@@ -54,7 +54,10 @@ def algorithmic_cost(op, n):
     if op["kind"] == arch.OP_MBCONV:
         Min, cin, cmid, cout = n * op["hin"] * op["win"], op["cin"], op["cmid"], op["cout"]
         fl, by = 0.0, 0.0
-        if cin != cmid:                                              # 1x1 expand
+        if cin == 3:                                                 # stem conv folded in (3x3 s2 on the 4-channel input)
+            fl += 2.0 * Min * 32 * 27
+            by += 2.0 * (n * (2 * op["hin"]) * (2 * op["win"]) * 4 + Min * 32) + 27 * 32 * 4
+        elif cin != cmid:                                            # 1x1 expand
             fl += 2.0 * Min * cin * cmid
             by += 2.0 * (Min * cin + cin * cmid + Min * cmid)
         fl += 2.0 * M * cmid * 9                                     # depthwise 3x3
@@ -104,7 +107,8 @@ def roofline_from_stages(stages, ops, n, frame_bytes, size):
         if name in by_name and by_name[name]["kind"] == arch.OP_MBCONV:   # block input + weights + output, once each
             o = by_name[name]
             cin, cmid, cout = o["cin"], o["cmid"], o["cout"]
-            a["min_bytes"] += 2.0 * (n * o["hin"] * o["win"] * cin + (cin * cmid if cin != cmid else 0) + 9 * cmid +
+            inp = n * (2 * o["hin"]) * (2 * o["win"]) * 4 if cin == 3 else n * o["hin"] * o["win"] * cin
+            a["min_bytes"] += 2.0 * (inp + (cin * cmid if cin != cmid else 0) + 9 * cmid +
                                      cmid * cout + n * o["hout"] * o["wout"] * cout)
         else:
             a["min_bytes"] += by

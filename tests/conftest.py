@@ -61,6 +61,15 @@ def model_dir_unfused(synth_weights, tmp_path_factory):
 
 
 @pytest.fixture(scope="session")
+def model_dir_stem_separate(synth_weights, tmp_path_factory):
+    """Fused blocks with the stem as its own kernel: the program that is bit-identical to the per-layer one."""
+    from watsor_amd import engine
+    d = tmp_path_factory.mktemp("model_stem_separate")
+    engine.save_engine(engine.build_engine(synth_weights, fuse_stem=False), str(d / "mi355x.bin"))
+    return str(d)
+
+
+@pytest.fixture(scope="session")
 def model_dir_fp32(synth_weights, tmp_path_factory):
     """The `-p 32` engine: fp32 storage, exact-fp32 matrix cores."""
     from watsor_amd import engine

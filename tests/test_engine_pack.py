@@ -15,7 +15,13 @@ def blob(synth_weights):
 
 @pytest.fixture(scope="module")
 def fused_blob(synth_weights):
-    """the default program: one op per inverted-residual block"""
+    """one op per inverted-residual block, the stem still a kernel of its own"""
+    return engine.build_engine(synth_weights, fuse_stem=False)
+
+
+@pytest.fixture(scope="module")
+def default_blob(synth_weights):
+    """the default program: fused blocks, the stem folded into the first one"""
     return engine.build_engine(synth_weights)
 
 
@@ -36,7 +42,7 @@ def parse(blob):
         o = struct.unpack_from("<20i2q8i8q64s", blob, hdr["ops_off"] + engine.OP_RECORD_BYTES * i)
         d = dict(zip(keys, o[:20]))
         d.update(w_off=o[20], b_off=o[21], n_box=o[22], cmid=o[23], cin0=o[24], kc0=o[25], cmid_pad=o[26],
-                 nmid_pad=o[27], we_off=o[30], be_off=o[31], wd_off=o[32], bd_off=o[33],
+                 nmid_pad=o[27], stem=o[28], stem_pad=o[29], we_off=o[30], be_off=o[31], wd_off=o[32], bd_off=o[33],
                  name=o[38].split(b"\0")[0].decode())
         ops.append(d)
     return hdr, tensors, ops
@@ -69,7 +75,7 @@ def test_shapes_follow_tf_same_padding(blob):
     assert [o["anchor_off"] for o in heads] == [0, 1083, 1683, 1833, 1887, 1911]
 
 
-@pytest.mark.parametrize("which", ["blob", "fused_blob"])
+@pytest.mark.parametrize("which", ["blob", "fused_blob", "default_blob"])
 def test_slots_never_alias_live_tensors(which, request):
     hdr, tensors, ops = parse(request.getfixturevalue(which))
     last = {}
@@ -122,7 +128,7 @@ def test_fused_blocks_pack_the_same_weights(blob, fused_blob, synth_weights):
     fhdr, ftensors, fops = parse(fused_blob)
     assert fhdr["n_ops"] == 34 and sum(1 for o in fops if o["kind"] == arch.OP_MBCONV) == 17
     by_name = {o["name"]: o for o in ops}
-    fprog = arch.build(fuse=True)
+    fprog = arch.build(fuse=True, fuse_stem=False)
     names = {t["name"] for t in ftensors}
     assert "expanded_conv_13/expand" in names and "expanded_conv_12/expand" not in names   # SSD tap stays in HBM
     for o, op in zip(fops, fprog.ops):
@@ -152,6 +158,26 @@ def test_fused_blocks_pack_the_same_weights(blob, fused_blob, synth_weights):
                 np.frombuffer(blob, np.float32, ex["n_pad"], hdr["weights_off"] + ex["b_off"]))
         else:
             assert o["name"].endswith(("expanded_conv", "expanded_conv_13"))
+
+
+def test_stem_folded_into_the_first_block(default_blob, fused_blob, synth_weights):
+    """Default program: op 0 reads the 300x300x4 input, its expand stage is the stem conv as a K = 27 (-> 32) GEMM."""
+    hdr, tensors, ops = parse(default_blob)
+    _, _, fops = parse(fused_blob)
+    assert hdr["n_ops"] == 33 and "Conv" not in {t["name"] for t in tensors}
+    o, blk0 = ops[0], fops[1]
+    assert o["kind"] == arch.OP_MBCONV and o["stem"] == 1 and o["stem_pad"] == 0 and tensors[o["src"]]["name"] == "input"
+    assert (o["cin0"], o["kc0"], o["nmid_pad"], o["cmid"], o["hin"], o["hout"], o["stride"]) == (32, 1, 32, 32, 150, 150, 1)
+    assert (o["cout"], o["n_pad"], o["kc"], o["pad_t"]) == (blk0["cout"], blk0["n_pad"], blk0["kc"], blk0["pad_t"])
+    prog = arch.build(fuse=False)
+    wf, bf = engine.fold_batch_norm(synth_weights, prog.ops[0])                 # [3,3,3,32]
+    w = unpack_conv(default_blob, hdr, dict(ksize=1, n_pad=32, kc=1, w_off=o["we_off"]))   # [1][32][32]
+    ref = wf.reshape(27, 32).astype(np.float32).astype(np.float16).astype(np.float32)
+    np.testing.assert_array_equal(w[0, :27, :], ref)
+    assert not w[0, 27:, :].any()
+    np.testing.assert_array_equal(np.frombuffer(default_blob, np.float32, 32, hdr["weights_off"] + o["be_off"]), bf.astype(np.float32))
+    for a, b in zip(ops[1:], fops[2:]):                                        # everything behind it is unchanged
+        assert (a["kind"], a["name"], a["cin"], a["cout"]) == (b["kind"], b["name"], b["cin"], b["cout"])
 
 
 def test_fold_matches_oracle_fold(synth_weights):

@@ -117,12 +117,12 @@ def _compare_programs(e_unf, e_fused, x_half, rel):
     return a, b
 
 
-def test_fused_blocks_equal_unfused_layers(model_dir, model_dir_unfused, head_outputs):
+def test_fused_blocks_equal_unfused_layers(model_dir_stem_separate, model_dir_unfused, head_outputs):
     """One launch per inverted-residual block (k_mbconv.hip) rounds at the same points and, when the
     expanded channels are not spread over workgroups (WZ_SPLITK=0), accumulates in the same order as the
     per-layer kernels: every tensor both programs hold is bit-identical."""
     e_unf = _keep_engine(model_dir_unfused, WZ_SPLITK="0")
-    e_fus = _keep_engine(model_dir, WZ_SPLITK="0")
+    e_fus = _keep_engine(model_dir_stem_separate, WZ_SPLITK="0")
     try:
         a, b = _compare_programs(e_unf, e_fus, head_outputs[0], 0.0)
         np.testing.assert_array_equal(a[0], b[0])
@@ -132,18 +132,38 @@ def test_fused_blocks_equal_unfused_layers(model_dir, model_dir_unfused, head_ou
         e_fus.close()
 
 
-def test_fused_blocks_with_channel_groups_close_to_unfused(eng_keep, eng_keep_fused, head_outputs):
-    """Default program: late blocks sum fp32 partials of channel groups in a fixed order -- same values up to
-    the fp32 summation order, i.e. an fp16 ulp here and there, never more than 1 % of a tensor's range."""
-    a, b = _compare_programs(eng_keep, eng_keep_fused, head_outputs[0], 0.01)
-    assert np.abs(a[1] - b[1]).max() <= 0.02 and np.abs(a[0] - b[0]).max() <= 0.02
+def test_stem_fused_program_close_to_oracle(eng_keep_fused, head_outputs):
+    """The default program (stem inside the first block's launch): every tensor it holds vs the fp32 oracle."""
+    x_half, rbe, rlg, T = head_outputs
+    be, lg = eng_keep_fused.stage_forward(x_half)
+    names = [t[0] for t in eng_keep_fused.tensors()]
+    assert "Conv" not in names and "expanded_conv/output" in names
+    for idx, (name, h, w, c) in enumerate(eng_keep_fused.tensors()):
+        if name == "input":
+            continue
+        got = np.stack([eng_keep_fused.stage_read_tensor(idx, f) for f in range(2)]).astype(np.float32)
+        err, scale = np.abs(got - T[name]).max(), np.abs(T[name]).max()
+        assert err <= 0.04 * scale + 0.02, "%s: max abs err %.4f (max|ref| %.3f)" % (name, err, scale)
+    assert np.abs(be - rbe).max() <= BOXENC_TOL and np.abs(lg - rlg).max() <= LOGIT_TOL
+
+
+def test_fused_blocks_with_channel_groups_close_to_unfused(eng_keep, model_dir_stem_separate, head_outputs):
+    """Late blocks sum fp32 partials of channel groups in a fixed order -- same values as the per-layer program up
+    to the fp32 summation order, i.e. an fp16 ulp here and there, never more than 1 % of a tensor's range.  (Stem as
+    its own kernel in both programs: the stem-fused program has other stem numerics, see the test above.)"""
+    e = _keep_engine(model_dir_stem_separate)
+    try:
+        a, b = _compare_programs(eng_keep, e, head_outputs[0], 0.01)
+        assert np.abs(a[1] - b[1]).max() <= 0.02 and np.abs(a[0] - b[0]).max() <= 0.02
+    finally:
+        e.close()
 
 
 @pytest.fixture(scope="module")
-def nosplit_outputs(model_dir, head_outputs):
+def nosplit_outputs(model_dir_stem_separate, head_outputs):
     os.environ["WZ_SPLITK"] = "0"
     try:
-        e = make_engine(model_dir, max_batch=2)
+        e = make_engine(model_dir_stem_separate, max_batch=2)
     finally:
         os.environ.pop("WZ_SPLITK")
     try:
@@ -153,13 +173,13 @@ def nosplit_outputs(model_dir, head_outputs):
 
 
 @pytest.mark.parametrize("tile", [(4, 4), (5, 7), (8, 16), (16, 8), (3, 19)])
-def test_fused_blocks_any_tile_shape(model_dir, nosplit_outputs, head_outputs, tile):
+def test_fused_blocks_any_tile_shape(model_dir_stem_separate, nosplit_outputs, head_outputs, tile):
     """The workgroup tile is a tuning knob: results may not depend on it (channel groups off, so that the
     fp32 summation order is the same)."""
-    env = dict(WZ_MB_TH=str(tile[0]), WZ_MB_TW=str(tile[1]), WZ_SPLITK="0")
+    env = dict(WZ_MB_TH=str(tile[0]), WZ_MB_TW=str(tile[1]), WZ_SPLITK="0", WZ_MB_WAVE="2")   # workgroup-per-tile kernel everywhere
     os.environ.update(env)
     try:
-        e = make_engine(model_dir, max_batch=2)
+        e = make_engine(model_dir_stem_separate, max_batch=2)
         try:
             got = e.stage_forward(head_outputs[0])
         finally:

@@ -77,6 +77,8 @@ class Op:
     cmid: int = 0              # depthwise (= expanded) channels
     cin0: int = 0              # block input channels feeding the expand conv; 0 = no expand stage
     parts: Optional[list] = None
+    stem: bool = False         # OP_MBCONV whose expand stage is the stem conv (3x3 s2 on the network input, K 27 -> 32)
+    stem_pad: Tuple[int, int] = (0, 0)
 
 
 @dataclass
@@ -115,10 +117,13 @@ def _blk(i: int) -> str:
     return "expanded_conv" if i == 0 else "expanded_conv_%d" % i
 
 
-def build(size: int = INPUT_SIZE, fuse: bool = True) -> Program:
+def build(size: int = INPUT_SIZE, fuse: bool = True, fuse_stem: bool = True) -> Program:
     """fuse=True: every inverted-residual block is ONE op (OP_MBCONV); block 13 keeps its expand conv as
     a separate op because its output is the first SSD feature map.  fuse=False: one op per layer (the
-    program the per-layer parity tests walk); both programs compute bit-identical tensors."""
+    program the per-layer parity tests walk); both programs compute bit-identical tensors.
+    fuse_stem (with fuse): the stem conv becomes the expand stage of the first block -- input image to block
+    output in one launch; the stem then runs on the matrix cores with fp16 weights, so this program matches
+    the others to fp16 rounding, not bit for bit."""
     p = Program(size=size)
     ops: List[Op] = []
     ops.append(Op(OP_STEM, FE + "Conv", "input", "Conv", 3, 32, 3, 2, ACT_RELU6, True))
@@ -151,6 +156,12 @@ def build(size: int = INPUT_SIZE, fuse: bool = True) -> Program:
                 ops.extend(block)
             cur, cin = name + "/output", c
             idx += 1
+    if fuse and fuse_stem:
+        stem_op, blk0 = ops[0], ops[1]
+        assert stem_op.kind == OP_STEM and blk0.kind == OP_MBCONV and blk0.cin0 == 0 and blk0.src == stem_op.dst
+        blk0.src, blk0.cin0, blk0.stem = "input", 32, True
+        blk0.parts = [stem_op] + blk0.parts
+        ops.pop(0)
     ops.append(Op(OP_CONV, FE + "Conv_1", cur, "Conv_1", cin, 1280, 1, 1, ACT_RELU6, True))
     cur, cin = "Conv_1", 1280
     taps = [tap0, "Conv_1"]
@@ -167,8 +178,12 @@ def build(size: int = INPUT_SIZE, fuse: bool = True) -> Program:
     for op in ops:
         src = p.tensors[op.src]
         op.hin, op.win = src.h, src.w
-        op.hout, op.pad_t = tf_same(src.h, op.k, op.stride)
-        op.wout, op.pad_l = tf_same(src.w, op.k, op.stride)
+        if op.stem:                                        # the block sees the stem's output map
+            op.hin, st = tf_same(src.h, 3, 2)
+            op.win, sl = tf_same(src.w, 3, 2)
+            op.stem_pad = (st, sl)
+        op.hout, op.pad_t = tf_same(op.hin, op.k, op.stride)
+        op.wout, op.pad_l = tf_same(op.win, op.k, op.stride)
         p.tensors[op.dst] = Tensor(op.dst, op.hout, op.wout, op.cout)
 
     # heads: BoxEncodingPredictor and ClassPredictor of a feature map read the same input, so they run

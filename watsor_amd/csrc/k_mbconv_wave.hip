@@ -20,7 +20,10 @@
 // MPW: halo m-tiles (16 pixels) per wave, MQW: output m-tiles per wave, KCI: K chunks of the expand conv,
 // NTO: 16-column tiles of the project output, NKK: 32-channel chunks per pass (their two dependency chains --
 // expand -> LDS -> depthwise -> project -- are independent, so a pass of 2 costs about the latency of 1).
-template <int MPW, int MQW, int KCI, int NTO, int NKK>
+// STEM: the block is the network's first one and its "expand" stage is the stem convolution (3x3 s2, 3 -> 32,
+// K = 27 padded to 32): the B fragment of a halo pixel is the im2col of its 3x3x3 window, gathered straight from
+// the normalised 300x300x4 input -- the 150x150x32 stem output never exists in HBM.
+template <int MPW, int MQW, int KCI, int NTO, int NKK, bool STEM>
 __global__ __launch_bounds__(256) void wz_k_mbconv_wave(const WzMbArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wz_mbw_smem[];
     constexpr int CE = 32 * NKK, ES = CE + 8;   // NKK 32-channel K chunks of the project conv per pass
@@ -79,11 +82,41 @@ __global__ __launch_bounds__(256) void wz_k_mbconv_wave(const WzMbArgs a) {
         const int iy = iy_base + hy, ix = ix_base + hx;
         const bool ok = live && p < P && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
         inimg[i] = ok;
-        const half_t* src = a.in + ((size_t)(b * a.hin + (ok ? iy : 0)) * a.win + (ok ? ix : 0)) * a.cin0;
+        if constexpr (STEM) {
+            // k = g*8 + j = (ky*3 + kx)*3 + c: this lane needs taps tb .. tb+3 with tb = (g*8)/3 = {0, 2, 5, 8}
+            const int tb = (g * 8) / 3;
+            half4_t tp[4];
 #pragma unroll
-        for (int c = 0; c < KCI; ++c) {
-            const int k0 = c * 32 + g * 8;
-            xf[i][c] = (ok && k0 < a.cin0) ? *reinterpret_cast<const half8_t*>(src + k0) : zero8;
+            for (int q = 0; q < 4; ++q) {
+                const int tq = tb + q;
+                const int ky = tq / 3, kx = tq - ky * 3;
+                const int sy = iy * 2 - a.spad_t + ky, sx = ix * 2 - a.spad_l + kx;   // stem: stride 2 on the input image
+                const bool in = ok && tq < 9 && sy >= 0 && sy < a.sin_h && sx >= 0 && sx < a.sin_w;
+                const int cy = min(max(sy, 0), a.sin_h - 1), cx = min(max(sx, 0), a.sin_w - 1);
+                const half4_t v = *reinterpret_cast<const half4_t*>(a.in + ((size_t)(b * a.sin_h + cy) * a.sin_w + cx) * 4);
+                tp[q] = in ? v : (half4_t){0, 0, 0, 0};
+            }
+            half8_t x;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                // element j of lane group g: tap (g*8+j)/3 - tb, channel (g*8+j)%3, zero for k >= 27; the four cases are
+                // compile-time constants, g picks one
+                half_t e[4];
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) {
+                    const int k = gg * 8 + j;
+                    e[gg] = k < 27 ? tp[k / 3 - (gg * 8) / 3][k % 3] : (half_t)0.0f;
+                }
+                x[j] = g == 0 ? e[0] : g == 1 ? e[1] : g == 2 ? e[2] : e[3];
+            }
+            xf[i][0] = x;
+        } else {
+            const half_t* src = a.in + ((size_t)(b * a.hin + (ok ? iy : 0)) * a.win + (ok ? ix : 0)) * a.cin0;
+#pragma unroll
+            for (int c = 0; c < KCI; ++c) {
+                const int k0 = c * 32 + g * 8;
+                xf[i][c] = (ok && k0 < a.cin0) ? *reinterpret_cast<const half8_t*>(src + k0) : zero8;
+            }
         }
     }
 
@@ -222,11 +255,11 @@ static int wz_mbw_env(const char* name, int dflt) {
     return (e && atoi(e) > 0) ? atoi(e) : dflt;
 }
 
-template <int MPW, int MQW, int KCI, int NTO, int NKK>
+template <int MPW, int MQW, int KCI, int NTO, int NKK, bool STEM = false>
 static int wz_mbw_launch(WzMbArgs a, int n, hipStream_t s, bool prepare) {
     a.nb = n;
     const size_t lds = (size_t)4 * MPW * 16 * (32 * NKK + 8) * 2 + (size_t)a.cmid_pad * (9 * 2 + 2 * 4);
-    auto k = wz_k_mbconv_wave<MPW, MQW, KCI, NTO, NKK>;
+    auto k = wz_k_mbconv_wave<MPW, MQW, KCI, NTO, NKK, STEM>;
     if (prepare) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return lds <= 160 * 1024 ? 0 : -1;
@@ -242,8 +275,17 @@ static int wz_mbw_launch(WzMbArgs a, int n, hipStream_t s, bool prepare) {
 int wz_launch_mbconv_wave(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) {
     static const int enabled = wz_mbw_env("WZ_MB_WAVE", 1);
     static const int min_w = wz_mbw_env("WZ_MB_WAVE_MIN_W", 38);
-    if (enabled != 1 || a0.cin0 == 0 || a0.kc0 != 1 || a0.wout < min_w) return -2;
     const int nto = a0.n_pad / 16;
+    if (a0.stem) {   // stem + first block: only this kernel implements it
+        if (a0.kc0 != 1 || a0.stride != 1 || nto != 2) return -1;
+        WzMbArgs a = a0;
+        a.nsplit = 1;
+        a.th = 4; a.tw = 8;
+        a.tiles_y = (a.hout + a.th - 1) / a.th;
+        a.tiles_x = (a.wout + a.tw - 1) / a.tw;
+        return wz_mbw_launch<4, 2, 1, 2, 1, true>(a, n, s, prepare);
+    }
+    if (enabled != 1 || a0.cin0 == 0 || a0.kc0 != 1 || a0.wout < min_w) return -2;
     if (nto != 2 && nto != 4) return -2;
     WzMbArgs a = a0;
     a.nsplit = 1;

@@ -60,6 +60,7 @@ struct WzMbArgs {
     int32_t cmid, cmid_pad, kc;    // depthwise channels, padded row, K chunks of the project conv
     int32_t cout, n_pad;
     int32_t stride, pad_t, pad_l;
+    int32_t stem, sin_h, sin_w, spad_t, spad_l;   // stem fused in: `in` is the sin_h x sin_w x 4 network input, cin0 = 32 (K 27 padded)
     float* ws;             // fp32 workspace for channel-group partial sums (nullptr: never split)
     uint64_t ws_bytes;
     int32_t M;             // n * hout * wout

@@ -137,6 +137,12 @@ static WzMbArgs mb_args(wz_engine* e, const Lane& L, const WzOpDesc& op) {
     a.cmid = op.cmid; a.cmid_pad = op.cmid_pad; a.kc = op.kc;
     a.cout = op.cout; a.n_pad = op.n_pad;
     a.stride = op.stride; a.pad_t = op.pad_t; a.pad_l = op.pad_l;
+    a.stem = op.stem;
+    if (op.stem) {
+        const WzTensorDesc& in = e->tensors[op.src];
+        a.sin_h = in.h; a.sin_w = in.w;
+        a.spad_t = op.stem_pad >> 16; a.spad_l = op.stem_pad & 0xffff;
+    }
     return a;
 }
 
@@ -364,7 +370,14 @@ static int load_blob(wz_engine* e, const char* path) {
             return wz_fail(WZ_EFORMAT, "%s: fused blocks exist for the fp16 engine only", path);
         if (h.precision == 32 && ((op.kind == WZ_OP_CONV && op.cin % 4 != 0) || (op.kind == WZ_OP_DW && op.cin % 4 != 0)))
             return wz_fail(WZ_EFORMAT, "%s: op %u (%s) is malformed", path, i, op.name);
-        if (op.kind == WZ_OP_MBCONV) {
+        if (op.kind == WZ_OP_MBCONV && op.stem) {
+            if (e->tensors[op.src].c != 4 || op.cin0 != 32 || op.kc0 != 1 || (e->tensors[op.src].h + 1) / 2 != op.hin ||
+                (e->tensors[op.src].w + 1) / 2 != op.win)
+                return wz_fail(WZ_EFORMAT, "%s: op %u (%s): malformed stem fusion", path, i, op.name);
+            wz_engine::Lane none;
+            if (wz_launch_mbconv_wave(mb_args(e, none, op), 1, nullptr, true) < 0)
+                return wz_fail(WZ_EFORMAT, "%s: op %u (%s): no stem-fused kernel for this shape", path, i, op.name);
+        } else if (op.kind == WZ_OP_MBCONV) {
             wz_engine::Lane none;
             if (wz_launch_mbconv(mb_args(e, none, op), 1, nullptr, true) != 0)
                 return wz_fail(WZ_EFORMAT, "%s: op %u (%s): no fused-block kernel for this shape", path, i, op.name);
@@ -418,7 +431,7 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     for (uint32_t i = 0; i < e->hdr.n_ops; ++i)   // kernel attributes of the fused-block kernels, on THIS device
         if (e->ops[i].kind == WZ_OP_MBCONV) {
             wz_engine::Lane none;
-            (void)wz_launch_mbconv(mb_args(e, none, e->ops[i]), max_batch, nullptr, true);
+            if (!e->ops[i].stem) (void)wz_launch_mbconv(mb_args(e, none, e->ops[i]), max_batch, nullptr, true);
             (void)wz_launch_mbconv_wave(mb_args(e, none, e->ops[i]), max_batch, nullptr, true);
         }
 
@@ -806,7 +819,8 @@ extern "C" int wz_op_info(wz_engine_t* e, int idx, char* name, int namelen, int*
     if (name && namelen > 0) snprintf(name, namelen, "%s", o.name);
     if (dims) {
         // WZ_OP_MBCONV: cin = block input channels, slot 11 = depthwise (expanded) channels
-        const int v[12] = {o.kind, o.kind == WZ_OP_MBCONV ? (o.cin0 ? o.cin0 : o.cmid) : o.cin, o.cout, o.ksize, o.stride,
+        // (a stem-fused block reports cin = 3, the image channels)
+        const int v[12] = {o.kind, o.kind == WZ_OP_MBCONV ? (o.stem ? 3 : o.cin0 ? o.cin0 : o.cmid) : o.cin, o.cout, o.ksize, o.stride,
                            o.hin, o.win, o.hout, o.wout, o.n_pad, o.kc, o.kind == WZ_OP_MBCONV ? o.cmid : 0};
         memcpy(dims, v, sizeof(v));
     }

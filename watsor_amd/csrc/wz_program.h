@@ -8,7 +8,7 @@
 #include <stdint.h>
 
 #define WZ_MAGIC 0x35335A57u /* "WZ35" */
-#define WZ_FORMAT_VERSION 5u
+#define WZ_FORMAT_VERSION 6u
 
 enum WzOpKind { WZ_OP_STEM = 1, WZ_OP_DW = 2, WZ_OP_CONV = 3, WZ_OP_MBCONV = 4 };
 enum WzOutMode { WZ_OUT_ACT = 0, WZ_OUT_BOX = 1, WZ_OUT_CLS = 2, WZ_OUT_HEAD = 3 };
@@ -51,7 +51,9 @@ struct WzOpDesc {  // 256 bytes
     int32_t kc0;                            // 32-channel K chunks of the expand conv
     int32_t cmid_pad;                       // cmid rounded up to 32 (row length of the packed depthwise weights)
     int32_t nmid_pad;                       // packed output columns of the expand conv
-    int32_t reserved[2];
+    int32_t stem;                           // 1: the expand stage IS the stem conv (3x3 s2 on the 4-channel input tensor `src`,
+                                            //    K = 27 padded to 32); hin/win are the stem's OUTPUT map
+    int32_t stem_pad;                       // stem padding, pad_t << 16 | pad_l
     int64_t we_off, be_off;                 // expand weights (WZ_OP_CONV layout, 1 tap) / float bias[nmid_pad]
     int64_t wd_off, bd_off;                 // depthwise: half w[9][cmid_pad] / float bias[cmid_pad]
     int64_t reserved2[4];

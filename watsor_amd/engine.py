@@ -24,7 +24,7 @@ from . import arch
 from .anchors import ssd_anchor_table
 
 MAGIC = 0x35335A57
-FORMAT_VERSION = 5
+FORMAT_VERSION = 6
 BN_EPSILON = 1e-3          # watsor/test/model/prepare.py:48
 
 DEFAULT_POST = dict(max_total=100, max_per_class=100, score_threshold=1e-8, iou_threshold=0.6,
@@ -95,7 +95,7 @@ def _op_record(op, tindex, n_pad, kc, w_off, b_off, mb) -> bytes:
         op.pad_t, op.pad_l, op.act, op.out_mode,
         op.anchor_offset, op.anchors_per_loc, n_pad, kc,
         w_off, b_off,
-        op.n_box, mb["cmid"], mb["cin0"], mb["kc0"], mb["cmid_pad"], mb["nmid_pad"], 0, 0,
+        op.n_box, mb["cmid"], mb["cin0"], mb["kc0"], mb["cmid_pad"], mb["nmid_pad"], mb["stem"], mb["stem_pad"],
         mb["we_off"], mb["be_off"], mb["wd_off"], mb["bd_off"], 0, 0, 0, 0,
         op.scope.encode()[:63])
 
@@ -137,7 +137,8 @@ def assign_slots(prog: "arch.Program", tensor_names: List[str]) -> List[int]:
 
 
 def build_engine(weights: Dict[str, np.ndarray], precision: int = 16, model_width: int = 300,
-                 model_height: int = 300, post: Optional[dict] = None, fuse: bool = True) -> bytes:
+                 model_height: int = 300, post: Optional[dict] = None, fuse: bool = True,
+                 fuse_stem: bool = True) -> bytes:
     """Returns the engine image.  Mirrors `build_engine` of watsor/engine.py:17-51.
     fuse=False keeps one op per layer (used by the per-layer parity tests; same results, slower)."""
     if precision not in (16, 32):
@@ -148,7 +149,7 @@ def build_engine(weights: Dict[str, np.ndarray], precision: int = 16, model_widt
         raise ValueError("square model input expected")
     cfg = dict(DEFAULT_POST)
     cfg.update(post or {})
-    prog = arch.build(model_width, fuse=fuse)
+    prog = arch.build(model_width, fuse=fuse, fuse_stem=fuse_stem)
     missing = [n for n in prog.variable_shapes() if n not in weights]
     if missing:
         raise KeyError("model is missing %d variables, e.g. %s" % (len(missing), missing[0]))
@@ -184,10 +185,16 @@ def build_engine(weights: Dict[str, np.ndarray], precision: int = 16, model_widt
     op_recs = []
     for op in prog.ops:
         n_pad, kc = 0, 0
-        mb = dict(cmid=0, cin0=0, kc0=0, cmid_pad=0, nmid_pad=0, we_off=0, be_off=0, wd_off=0, bd_off=0)
+        mb = dict(cmid=0, cin0=0, kc0=0, cmid_pad=0, nmid_pad=0, we_off=0, be_off=0, wd_off=0, bd_off=0, stem=0, stem_pad=0)
         if op.kind == arch.OP_MBCONV:
             parts = list(op.parts)
-            if op.cin0:
+            if op.stem:                                    # the stem conv as a K = 27 (padded 32) "expand" GEMM
+                st = parts.pop(0)
+                w, b = fold_batch_norm(weights, st)        # [3,3,3,32]: k = (ky*3+kx)*3 + c
+                mb["we_off"] = put(pack_conv_weights(w.reshape(1, 1, 27, st.cout).astype(np.float32), 32, 1))
+                mb["be_off"] = put(b.astype(np.float32))
+                mb.update(nmid_pad=32, kc0=1, stem=1, stem_pad=(op.stem_pad[0] << 16) | op.stem_pad[1])
+            elif op.cin0:
                 ex = parts.pop(0)
                 mb["we_off"], mb["be_off"], mb["nmid_pad"], mb["kc0"] = put_conv(ex)
             dw, pj = parts
