@@ -280,9 +280,12 @@ int wz_launch_mbconv_wave(const WzMbArgs& a0, int n, hipStream_t s, bool prepare
         if (a0.kc0 != 1 || a0.stride != 1 || nto != 2) return -1;
         WzMbArgs a = a0;
         a.nsplit = 1;
-        a.th = 4; a.tw = 8;
+        static const int big = wz_mbw_env("WZ_MB_WAVE_STEM_TILE", 1);   // 1: 4x8 outputs per wave, 2: 8x8, 3: 4x4
+        a.th = big == 2 ? 8 : 4; a.tw = big == 3 ? 4 : 8;
         a.tiles_y = (a.hout + a.th - 1) / a.th;
         a.tiles_x = (a.wout + a.tw - 1) / a.tw;
+        if (big == 2) return wz_mbw_launch<7, 4, 1, 2, 1, true>(a, n, s, prepare);   // halo 10 x 10 = 100 pixels
+        if (big == 3) return wz_mbw_launch<3, 1, 1, 2, 1, true>(a, n, s, prepare);   // 4x4 outputs, halo 6 x 6 = 36
         return wz_mbw_launch<4, 2, 1, 2, 1, true>(a, n, s, prepare);
     }
     if (enabled != 1 || a0.cin0 == 0 || a0.kc0 != 1 || a0.wout < min_w) return -2;
