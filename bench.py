@@ -136,6 +136,10 @@ def roofline_from_stages(stages, ops, n, frame_bytes, size):
                 # what the launch has to move when intermediate tensors stay on chip (= algorithmic for unfused kernels)
                 fused_min_bytes_per_launch=dom["min_bytes_per_launch"],
                 frac_of_peak_on_fused_min_bytes=round(dom["min_gbs"] / HBM_PEAK_GBS, 5))
+    rp = rocprof_avg_us(dom["kernel"])
+    if rp:   # the same fraction at the duration the committed rocprofv3 trace reports for this kernel
+        roof["avg_launch_us_rocprof"] = rp
+        roof["frac_at_rocprof_duration"] = round(roof["frac"] * dom["avg_us"] / rp, 5)
     return roof, table
 
 
@@ -152,6 +156,16 @@ def pmc_traffic(kernel):
                     fetch_bytes_corrected=round(t["fetch_bytes_corrected"]), write_bytes=round(t["write_bytes"]),
                     source="profiles/pmc_traffic.json (rocprofv3 --pmc, mean per launch)")
     except (OSError, ValueError, KeyError):
+        return None
+
+
+def rocprof_avg_us(kernel):
+    """Average per-dispatch duration of `kernel` in the committed rocprofv3 kernel trace of this command
+    (profiles/rocprof_kernel_avg.json).  rocprofv3 counts dispatch + teardown into a duration, the HIP-event
+    bracket minus the empty-bracket calibration does not: the two differ by 2-3 us per launch."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "rocprof_kernel_avg.json"))).get(kernel, {}).get("avg_us")
+    except (OSError, ValueError):
         return None
 
 

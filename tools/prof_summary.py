@@ -3,7 +3,7 @@ import sqlite3
 import sys
 
 
-def main(path, out=None):
+def main(path, out=None, js=None):
     db = sqlite3.connect(path)
     cur = db.cursor()
     rows = list(cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels"))
@@ -32,7 +32,24 @@ def main(path, out=None):
     print(text)
     if out:
         open(out, "a").write(text + "\n")
+    if js:   # per bench.py kernel class: mean per-dispatch duration (read back by bench.py's roofline object)
+        import json
+        agg = {}
+        for name, calls, total, _, _ in rows:
+            k = name.replace("void ", "").split("(")[0].split("<")[0]
+            if k.startswith("_Z"):
+                k = "wz_k_stem" if "stem" in k else "wz_k_preprocess" if "preprocess" in k else k
+            if k.startswith("wz_k_mbconv"):
+                k = "wz_k_mbconv"
+            if k in ("wz_k_conv_lds", "wz_k_conv"):
+                k = "wz_k_conv<%s>" % name.split("<")[1].split(",")[0].split(">")[0]
+            a = agg.setdefault(k, [0.0, 0])
+            a[0] += total / 1e3 if total > 1e6 else total      # top_kernels reports ns in some versions
+            a[1] += calls
+        outd = {k: dict(avg_us=round(v[0] / v[1], 3), calls=v[1]) for k, v in agg.items()}
+        outd["_source"] = "rocprofv3 --kernel-trace --stats of bench.py (tools/prof_summary.py)"
+        json.dump(outd, open(js, "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None, sys.argv[3] if len(sys.argv) > 3 else None)
