@@ -35,7 +35,7 @@ def main(path, out=None, js=None):
     if js:   # per bench.py kernel class: mean per-dispatch duration (read back by bench.py's roofline object)
         import json
         agg = {}
-        for name, calls, total, _, _ in rows:
+        for name, calls, _, avg, _ in rows:
             k = name.replace("void ", "").split("(")[0].split("<")[0]
             if k.startswith("_Z"):
                 k = "wz_k_stem" if "stem" in k else "wz_k_preprocess" if "preprocess" in k else k
@@ -44,7 +44,7 @@ def main(path, out=None, js=None):
             if k in ("wz_k_conv_lds", "wz_k_conv"):
                 k = "wz_k_conv<%s>" % name.split("<")[1].split(",")[0].split(">")[0]
             a = agg.setdefault(k, [0.0, 0])
-            a[0] += total / 1e3 if total > 1e6 else total      # top_kernels reports ns in some versions
+            a[0] += avg * calls                                # the `average` column is what the table prints as avg_us
             a[1] += calls
         outd = {k: dict(avg_us=round(v[0] / v[1], 3), calls=v[1]) for k, v in agg.items()}
         outd["_source"] = "rocprofv3 --kernel-trace --stats of bench.py (tools/prof_summary.py)"
