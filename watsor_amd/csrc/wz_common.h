@@ -105,6 +105,7 @@ void wz_launch_dw_f32(const float* in, const float* w, const float* bias, float*
 void wz_launch_conv_f32(const WzConvArgs& a, hipStream_t s);   // + its split-K reduce when a.splitk > 1
 int wz_launch_mbconv(const WzMbArgs& a, int n, hipStream_t s, bool prepare);   // -1: no kernel; else #channel groups
 int wz_launch_mbconv_wave(const WzMbArgs& a, int n, hipStream_t s, bool prepare);   // wave-per-tile variant; -2: not applicable
+int wz_launch_mbconv_cs(const WzMbArgs& a, int n, hipStream_t s, bool prepare);     // channels split over waves (small maps); -2: n/a
 
 #define WZ_HIST_BINS 1024
 #define WZ_CAND_CAP 4096

@@ -173,6 +173,7 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t) {
             a.ws_bytes = WZ_WS_BYTES;
             a.dbg = e->d_mbdbg ? e->d_mbdbg + (size_t)i * 16 : nullptr;
             int groups = wz_launch_mbconv_wave(a, n, s, false);   // large maps: one wavefront per pixel tile
+            if (groups == -2 && e->use_splitk) groups = wz_launch_mbconv_cs(a, n, s, false);   // small maps: channels over waves
             if (groups == -2) groups = wz_launch_mbconv(a, n, s, false);
             if (e->d_mbdbg) e->mb_groups[i] = groups;
             if (t) t->mark();
@@ -433,6 +434,7 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
             wz_engine::Lane none;
             if (!e->ops[i].stem) (void)wz_launch_mbconv(mb_args(e, none, e->ops[i]), max_batch, nullptr, true);
             (void)wz_launch_mbconv_wave(mb_args(e, none, e->ops[i]), max_batch, nullptr, true);
+            (void)wz_launch_mbconv_cs(mb_args(e, none, e->ops[i]), max_batch, nullptr, true);
         }
 
     const WzBlobHeader& h = e->hdr;
