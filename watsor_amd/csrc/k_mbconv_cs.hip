@@ -271,13 +271,14 @@ static int wz_cs_launch(WzMbArgs a, int n, hipStream_t s, bool prepare) {
     return 1;
 }
 
-// Serves the blocks on maps of at most 19x19 outputs (blocks 6 .. 16).  -2: does not apply (caller falls back to wz_launch_mbconv).
+// Serves the blocks with 19x19 outputs (blocks 6 .. 12); the 10x10 ones on request (WZ_MB_CS_MIN_W).  -2: does not apply (caller falls back to wz_launch_mbconv).
 int wz_launch_mbconv_cs(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) {
     static const int enabled = wz_cs_env("WZ_MB_CS", 1);
     // Measured on the 10x10 maps (9 tiles per frame, 30 chunks): this kernel takes longer there than channel groups
     // over workgroups + a reduce launch (block 16: 30 vs 17 us) but occupies only 72 CUs, and with four lanes in
-    // flight what counts is CU x time: 43.2 k vs 42.6 k frames/s (p50 0.508 vs 0.496 ms).  WZ_MB_CS_MIN_W=11 for latency.
-    static const int min_w = wz_cs_env("WZ_MB_CS_MIN_W", 1);
+    // flight what counts is CU x time: 43.2 k vs 42.6 k frames/s -- at a worse latency (p50 0.508 vs 0.496 ms) and a
+    // worse per-kernel roofline fraction.  Default: 19x19 only; WZ_MB_CS_MIN_W=1 trades latency for 1 % of throughput.
+    static const int min_w = wz_cs_env("WZ_MB_CS_MIN_W", 11);
     if (enabled != 1 || a0.stem || a0.wout > 19 || a0.wout < min_w) return -2;
     const int nto = a0.n_pad / 16;
     WzMbArgs a = a0;
