@@ -109,6 +109,10 @@ int wz_set_camera_filter(wz_engine_t* e, int cam, int width, int height, const d
                          const double* area_thr, int n_zones, const uint8_t* zone_allow,
                          const uint8_t* zone_fill);
 int wz_clear_camera_filter(wz_engine_t* e, int cam);
+/* Drop mode for a camera that has a filter: rows that fail `label > 0 and Confidence and Area and Mask`
+ * (watsor/filter/track.py:26) are written as all-zero rows, so that whatever reads the frame's detections next
+ * (the sieve's TrackFilter) rejects them by its own `label > 0` test and need not run the filters again. */
+int wz_set_camera_drop(wz_engine_t* e, int cam, int drop);
 /* Run only the filter stage on caller-provided rows (host), in place: zones are written into the
  * rows exactly where the reference's MaskFilter would have been invoked; pass[100] receives the verdict. */
 int wz_filter_rows(wz_engine_t* e, int cam, wz_detection_t* rows, uint8_t* pass);
@@ -118,6 +122,28 @@ int wz_filter_rows(wz_engine_t* e, int cam, wz_detection_t* rows, uint8_t* pass)
  * ordered by the reference's centroid key and returns the zone count (or a negative error). */
 int wz_zones_from_alpha(const uint8_t* alpha, int width, int height, int max_zones, uint8_t* zone_fill,
                         int32_t* centroid_xy /* [max_zones][2], may be NULL */);
+
+/* ---- the sieve's tracker, host code, one instance per camera, no engine needed.
+ * Replaces TrackFilter(filters, sensitivity, history) of watsor/filter/track.py:19-149 for rows whose per-detection
+ * filters already ran on the GPU; row order, new-track order (CPython set iteration) and zone order of the combined
+ * rows are the reference's; equally-near tracks are visited in index order (np.argsort's tie order is not defined). */
+typedef struct wz_tracker wz_tracker_t;
+int wz_tracker_create(int sensitivity, int history, wz_tracker_t** out);   /* track.py:19-23; defaults 5, 10 */
+void wz_tracker_destroy(wz_tracker_t* t);
+int wz_tracker_reset(wz_tracker_t* t);
+int wz_tracker_count(wz_tracker_t* t);                                     /* live tracks, all labels */
+/* TrackFilter.__call__ (track.py:25-110) on n rows; a row takes part iff label > 0 and (pass == NULL or pass[i]).
+ * Writes min(*n_out, cap) combined rows (track.py:118-149) to out, *n_out = rows the reference would return,
+ * *suspicious = its second return value (track.py:38). */
+int wz_tracker_update(wz_tracker_t* t, const wz_detection_t* rows, int n, const uint8_t* pass, wz_detection_t* out,
+                      int cap, int* n_out, int* suspicious);
+/* DetectionSieve._incoming_frame (watsor/filter/sieve.py:21-33,44-56) with one TrackFilter, in place on the
+ * frame header's rows: results first, the remaining rows zeroed. */
+int wz_tracker_sieve(wz_tracker_t* t, wz_detection_t* rows, int n, const uint8_t* pass, int* suspicious);
+/* Test hooks for the CPython-set emulation: iteration order after adding keys[0..n) / of
+ * `set(range(n)).difference(used)`; both return the number of values written to out. */
+int wz_debug_pyset_order(const int32_t* keys, int n, int32_t* out);
+int wz_debug_unused_order(int n, const uint8_t* used, int32_t* out);
 
 /* ---- introspection used by the engine CLI, bench.py (roofline) and the parity tests */
 int wz_input_size(wz_engine_t* e);

@@ -195,3 +195,58 @@ def test_many_cameras_with_masks_and_thresholds_mixed_resolutions(model_dir):
             f.close()
     finally:
         e.close()
+
+
+def detections_of(rows):
+    out = []
+    for r in rows:
+        d = Detection(label=int(r["label"]), confidence=float(r["confidence"]),
+                      bounding_box=BoundingBox(int(r["x_min"]), int(r["y_min"]), int(r["x_max"]), int(r["y_max"])))
+        out.append(d)
+    return out
+
+
+def test_drop_mode_feeds_the_native_sieve(eng):
+    """SURVEY 8(f)-1 end to end: a camera in drop mode + `HipTrackFilter().sieve()` on the rows as they leave the GPU
+    == the reference's sieve (`TrackFilter([Confidence, Area, Mask])`, restated by the oracle) on the raw rows."""
+    from oracle.tracker import TrackFilter, ZERO_ROW, sieve_rows
+    from watsor_amd.filter.track import HipTrackFilter
+    cfg = dict(golden_config()["config"])
+    cfg["detect"] = [{name: {"area": 1, "confidence": 10, "zones": []}}
+                     for name in ("person", "car", "bench", "bird", "cat", "dog")]
+    alpha = porch_alpha()
+    raw_cam = HipCameraFilter(eng, 6, cfg, alpha=alpha)
+    drop_cam = HipCameraFilter(eng, 7, cfg, alpha=alpha, drop=True)
+    oracle = TrackFilter([of.ConfidenceFilter(cfg), of.AreaFilter(cfg), of.MaskFilter(cfg, alpha=alpha)], 2, 4)
+    native = HipTrackFilter(sensitivity=2, history=4)
+    reported = 0
+    for i in range(8):
+        frame = synthetic_frame(640, 480, 40 + (i // 3))                 # a scene that changes every third frame
+        raw, dropped = np.zeros(100, ROW_DTYPE), np.zeros(100, ROW_DTYPE)
+        p_raw, p_drop = np.zeros(100, np.uint8), np.zeros(100, np.uint8)
+        eng.detect_batch([frame, frame], [raw, dropped], cams=[6, 7], out_pass=[p_raw, p_drop])
+        np.testing.assert_array_equal(p_raw, p_drop)
+        keep = p_raw.astype(bool)
+        assert keep.any() and not keep.all()
+        assert dropped[keep].tobytes() == raw[keep].tobytes()
+        assert dropped[~keep].tobytes() == bytes(72 * int((~keep).sum()))   # failing rows: all-zero records
+        plain = raw.copy()
+        plain["zones"] = 0                                                # the rows as the detector wrote them
+        want, want_s = sieve_rows([oracle], detections_of(plain))
+        got_s = native.sieve(dropped)
+        assert got_s == want_s
+        for k in range(100):
+            w = want[k]
+            g = dropped[k]
+            assert (int(g["label"]), tuple(int(z) for z in g["zones"]), float(g["confidence"]),
+                    (int(g["x_min"]), int(g["y_min"]), int(g["x_max"]), int(g["y_max"]))) == tuple(w), (i, k)
+        reported += sum(1 for w in want if w != ZERO_ROW)
+    assert reported > 0
+    eng.set_camera_drop(7, False)
+    raw, dropped = np.zeros(100, ROW_DTYPE), np.zeros(100, ROW_DTYPE)
+    eng.detect_batch([frame, frame], [raw, dropped], cams=[6, 7])
+    assert raw.tobytes() == dropped.tobytes()
+    with pytest.raises(ValueError):
+        eng.set_camera_drop(9, True)                                      # no filter on that camera
+    raw_cam.close()
+    drop_cam.close()

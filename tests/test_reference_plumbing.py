@@ -53,7 +53,8 @@ class FakeBatchDetector:
         return 2.0
 
 
-def build_pipeline(reference_on_path, detector_factory, n_cameras, frame_fn, width=64, height=48, want=12):
+def build_pipeline(reference_on_path, detector_factory, n_cameras, frame_fn, width=64, height=48, want=12,
+                   sieve_fn=None):
     from logging import getLogger
     from logging.handlers import QueueHandler
     from multiprocessing import Event, Queue
@@ -111,8 +112,11 @@ def build_pipeline(reference_on_path, detector_factory, n_cameras, frame_fn, wid
         buffers[name] = fb
         sieve_q, sink_q = Queue(1), Queue(1)
         src = Source(name, stop, log_queue, frame_queue, fb)
-        sieve = DetectionSieve(name + "-sieve", stop, log_queue, sieve_q, fb,
-                               [TrackFilter([ConfidenceFilter(all_conf)], 1, 1)], RateLimiter())
+        if sieve_fn is not None:
+            sieve = sieve_fn(name + "-sieve", stop, log_queue, sieve_q, fb, RateLimiter())
+        else:
+            sieve = DetectionSieve(name + "-sieve", stop, log_queue, sieve_q, fb,
+                                   [TrackFilter([ConfidenceFilter(all_conf)], 1, 1)], RateLimiter())
         sink = Sink(name + "-sink", stop, log_queue, sink_q, fb, latch, seen)
         src.subscribe(sieve_q)
         sieve.subscribe(sink_q)
@@ -186,6 +190,40 @@ def test_batched_worker_one_latch_step_per_payload(reference_on_path, tmp_path):
     assert max(FakeBatchDetector.calls) <= FakeBatchDetector.max_batch
     det = procs[-1]
     assert det.fps() > 0 and det.inference_time() > 0
+
+
+def test_native_sieve_under_reference_runtime(reference_on_path, tmp_path):
+    """the reference's own DetectionSieve thread with `_incoming_frame` replaced by one native call
+    on the shared-memory rows (`hip_detection_sieve`, `HipTrackFilter.sieve`); sensitivity 2, so a camera's first
+    frame is held back and every later one reports the track's combined row."""
+    from watsor_amd.detection.detector import BatchedObjectDetector
+    from watsor_amd.filter.sieve import hip_detection_sieve
+    from watsor_amd.filter.track import HipTrackFilter
+    FakeBatchDetector.calls = []
+    trackers = []
+
+    def frame_fn(cam, i, w, h):
+        return np.full((h, w, 3), (int(cam[3:]) * 50 + i) % 256, np.uint8)
+
+    def factory(stop, log_queue, frame_queue, buffers):
+        return [BatchedObjectDetector(Thread, "detector1", stop, log_queue, frame_queue, buffers,
+                                      kwargs={'detector_class': FakeBatchDetector,
+                                              'detector_args': (str(tmp_path), 0)})]
+
+    def sieve_fn(name, stop, log_queue, queue, fb, limiter):
+        trackers.append(HipTrackFilter(sensitivity=2, history=3))
+        return hip_detection_sieve()(name, stop, log_queue, queue, fb, [trackers[-1]], limiter)
+
+    stop, latch, seen, procs = build_pipeline(reference_on_path, factory, 2, frame_fn, sieve_fn=sieve_fn)
+    assert run(stop, latch, procs, 60)
+    assert len(seen) >= 12
+    for label, conf, x_min, px0 in seen:
+        # FakeBatchDetector: x_min = the frame's pixel value, which grows by one per frame; the combined row of a
+        # track with up to three rows carries the smallest x_min of its history (track.py:127)
+        assert label == 1 and conf == 0.9 and 0 <= (px0 - x_min) % 256 <= 2
+    assert all(t.tracks == 1 for t in trackers)
+    sieves = [p for p in procs if type(p).__name__ == "HipDetectionSieve"]
+    assert len(sieves) == 2 and all(s.fps() > 0 for s in sieves)
 
 
 def test_factory_defers_to_reference_when_no_engine_file(reference_on_path, tmp_path):

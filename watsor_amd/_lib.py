@@ -48,6 +48,16 @@ SIGNATURES = {
                                        C.c_void_p, C.c_void_p]),
     "wz_clear_camera_filter": (C.c_int, [C.c_void_p, C.c_int]),
     "wz_filter_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "wz_set_camera_drop": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "wz_tracker_create": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "wz_tracker_destroy": (None, [C.c_void_p]),
+    "wz_tracker_reset": (C.c_int, [C.c_void_p]),
+    "wz_tracker_count": (C.c_int, [C.c_void_p]),
+    "wz_tracker_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                    C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "wz_tracker_sieve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
+    "wz_debug_pyset_order": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "wz_debug_unused_order": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
     "wz_zones_from_alpha": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "wz_input_size": (C.c_int, [C.c_void_p]),
     "wz_precision": (C.c_int, [C.c_void_p]),

@@ -648,6 +648,15 @@ __device__ void wz_apply_filter(const WzCamFilter& cf, wz_detection_t& d, uint8_
         }
         ok = hit;
     }
+    if (!ok && (cf.enabled & 2)) {
+        // drop mode (wz_set_camera_drop): the row leaves the GPU as an all-zero row, which `label > 0`
+        // (track.py:26) rejects -- the sieve needs neither the pass byte nor the Python filters
+        d.label = 0;
+#pragma unroll
+        for (int z = 0; z < WZ_MAX_ZONES; ++z) d.zones[z] = 0;
+        d.confidence = 0.0;
+        d.x_min = d.y_min = d.x_max = d.y_max = 0;
+    }
     if (pass) *pass = ok ? 1 : 0;
 }
 

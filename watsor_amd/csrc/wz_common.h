@@ -70,7 +70,7 @@ struct WzMbArgs {
 
 // Per-camera filter state resident in HBM (see wz_set_camera_filter).
 struct WzCamFilter {
-    int32_t enabled, width, height, n_zones;
+    int32_t enabled, width, height, n_zones;   // enabled: bit 0 = filters on, bit 1 = drop mode (failing rows zeroed)
     const int32_t* sat;          // [n_zones][(height+1)][(width+1)] inclusive-prefix sums, row/col 0 = 0
     double conf_thr[WZ_NUM_LABELS];   // NaN = label not configured
     double area_thr[WZ_NUM_LABELS];
@@ -132,6 +132,7 @@ void wz_launch_compact(const WzPostBuffers& b, const WzPostConsts& c, int n, hip
 void wz_launch_nms(const WzPostBuffers& b, const WzPostConsts& c, int n, hipStream_t s);
 void wz_launch_rows(const WzPostBuffers& b, const WzFrameDesc* d_frames, const WzCamFilter* d_cams, int n,
                     int max_total, wz_detection_t* rows, uint8_t* pass, hipStream_t s);
+int wz_set_error(int code, const char* fmt, ...);   // sets wz_last_error() of the calling thread, returns code
 void wz_post_init();   // one-time kernel attributes (must run before any stream capture)
 void wz_launch_filter_rows(const WzCamFilter* d_cams, int cam, wz_detection_t* rows, uint8_t* pass, hipStream_t s);
 void wz_launch_sat(const uint8_t* fill, int32_t* sat, int width, int height, int n_zones, hipStream_t s);

@@ -30,6 +30,13 @@ static int wz_fail(int code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
+int wz_set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
 #define HIPCHK(expr)                                                                                  \
     do {                                                                                              \
         hipError_t _e = (expr);                                                                       \
@@ -768,6 +775,16 @@ extern "C" int wz_set_camera_filter(wz_engine_t* e, int cam, int width, int heig
         c.sat = sat;
     }
     HIPCHK(hipMemcpy(e->d_cams + cam, &c, sizeof(WzCamFilter), hipMemcpyHostToDevice));
+    return WZ_OK;
+}
+
+extern "C" int wz_set_camera_drop(wz_engine_t* e, int cam, int drop) {
+    if (!e || cam < 0 || cam >= WZ_MAX_CAMS) return wz_fail(WZ_EINVAL, "wz_set_camera_drop: bad argument");
+    if (!(e->h_cams[cam].enabled & 1)) return wz_fail(WZ_EINVAL, "camera %d has no filter (wz_set_camera_filter first)", cam);
+    HIPCHK(hipSetDevice(e->device));
+    { int _rc = sync_all(e); if (_rc != WZ_OK) return _rc; }
+    e->h_cams[cam].enabled = drop ? 3 : 1;
+    HIPCHK(hipMemcpy(e->d_cams + cam, &e->h_cams[cam], sizeof(WzCamFilter), hipMemcpyHostToDevice));
     return WZ_OK;
 }
 

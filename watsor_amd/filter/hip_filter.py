@@ -44,7 +44,10 @@ def read_mask_alpha(filename, width=None, height=None) -> np.ndarray:
 
 
 class HipCameraFilter:
-    def __init__(self, engine: HipEngine, cam: int, camera_config: dict, alpha: Optional[np.ndarray] = None):
+    def __init__(self, engine: HipEngine, cam: int, camera_config: dict, alpha: Optional[np.ndarray] = None,
+                 drop: bool = False):
+        """drop=True: rows failing the filters leave the GPU as all-zero rows (`wz_set_camera_drop`), which is what
+        a sieve with a filter-less `HipTrackFilter()` expects."""
         self.engine, self.cam = engine, cam
         width, height = camera_config['width'], camera_config['height']
         conf = np.full(NUM_LABELS, math.nan)
@@ -74,6 +77,8 @@ class HipCameraFilter:
                 allow[idx] = [1 if i + 1 in zones else 0 for i in range(nz)]
         self.num_zones = 0 if fill is None else fill.shape[0]
         engine.set_camera_filter(cam, width, height, conf, area, fill, allow)
+        if drop:
+            engine.set_camera_drop(cam, True)
 
     def filter_rows(self, rows) -> np.ndarray:
         """Runs the camera's filters over 100 rows in place (zones written); returns pass[100]."""

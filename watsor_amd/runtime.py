@@ -187,6 +187,10 @@ class HipEngine:
             self._h, cam, width, height, conf.ctypes.data_as(_lib.c_f64p), area.ctypes.data_as(_lib.c_f64p),
             nz, allow_p, fill_p))
 
+    def set_camera_drop(self, cam: int, drop: bool) -> None:
+        """Rows of camera `cam` that fail its filters are written as all-zero rows (include/watsor_hip.h)."""
+        _lib.check(self._lib.wz_set_camera_drop(self._h, cam, 1 if drop else 0))
+
     def clear_camera_filter(self, cam: int) -> None:
         _lib.check(self._lib.wz_clear_camera_filter(self._h, cam))
 
