@@ -212,8 +212,8 @@ def test_drop_mode_feeds_the_native_sieve(eng):
     from oracle.tracker import TrackFilter, ZERO_ROW, sieve_rows
     from watsor_amd.filter.track import HipTrackFilter
     cfg = dict(golden_config()["config"])
-    cfg["detect"] = [{name: {"area": 1, "confidence": 10, "zones": []}}
-                     for name in ("person", "car", "bench", "bird", "cat", "dog")]
+    # every class the seeded random-init network reports may pass on confidence; area and the porch zones decide
+    cfg["detect"] = [{name: {"area": 2, "confidence": 2, "zones": []}} for name in dict.fromkeys(COCO_CLASSES[1:])]
     alpha = porch_alpha()
     raw_cam = HipCameraFilter(eng, 6, cfg, alpha=alpha)
     drop_cam = HipCameraFilter(eng, 7, cfg, alpha=alpha, drop=True)

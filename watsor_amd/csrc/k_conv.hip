@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void wz_k_splitk_reduce(const WzConvArgs a, co
 // (no staging registers): the LDS image of a tile is a list of 1 KiB MFMA fragments, lane l's 16 bytes
 // at l*16, which is exactly what the DMA writes (wave-uniform base + lane * 16) and what `ds_read_b128`
 // reads back conflict-free.  Weight fragments are contiguous in the packed layout; an activation
-// fragment is a per-lane gather (lane = pixel r16 x channel group g) whose out-of-frame lanes read a
+// tile is staged pixel-major in full 128-byte lines (see the kernel) with out-of-frame pixels read from a
 // zero page.  Two LDS buffers: the DMA of step s+1 runs under the MFMAs of step s, one barrier per step.
 // --------------------------------------------------------------------------------------------
 #define WZ_LDS_TM 128
@@ -321,15 +321,36 @@ __device__ __forceinline__ void wz_glds16(const void* gsrc, unsigned char* lds_w
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int KS, int NW>
-__global__ __launch_bounds__(256) void wz_k_conv_lds(const WzConvArgs a) {
+// NBUF LDS buffers = NBUF - 1 K steps of DMA in flight per workgroup.  With one step in flight the kernel is bound by
+// latency, not bandwidth (bytes in flight per CU / L2 latency); the waits are explicit `s_waitcnt vmcnt(n)` on the
+// wave's own DMA instructions (NW + 4 per step, always issued, completing in order) followed by a bare `s_barrier`:
+// `__syncthreads()` would drain every outstanding DMA.
+template <int N>
+__device__ __forceinline__ void wz_wait_dma_then_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// SPEC: producer / consumer wavefronts.  In-kernel cycle counts (tools/conv_probe.py) showed a K step of the plain
+// variant costing 2 360 cycles per wave = 1 140 to ISSUE its eight DMA instructions (each stalls ~140 cycles in the
+// address path while others are in flight) + 960 for the fragment reads and 32 MFMAs + 250 waiting -- serialised,
+// because a wave issues in order and there is one wave per SIMD.  With SPEC the workgroup has eight waves: 4..7 only
+// issue the DMAs of step s + D, 0..3 only compute step s; the two halves meet at one barrier per step.
+template <int KS, int NW, int NBUF, bool SPEC>
+__global__ __launch_bounds__(SPEC ? 512 : 256) void wz_k_conv_lds(const WzConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wz_cl_smem[];
     constexpr int taps = KS * KS;
     constexpr int ABYTES = 4 * NW * 1024, BUF = WZ_LDS_BUF(NW);
     const int n_tiles = a.n_pad >> 4;   // packed 16-channel tiles; a partial last workgroup tile stages zeros beyond
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
+    const bool producer = !SPEC || threadIdx.x >= 256, consumer = !SPEC || threadIdx.x < 256;   // wave-uniform
     const int r16 = lane & 15, g = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
+    // diagnostics (a.dbg != nullptr only in engines created with WZ_MB_DEBUG=1): phase timestamps (100 MHz) of the
+    // first workgroup (slots 0..7) and of the last one (8..15)
+    const bool stamp = a.dbg && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1);
+    unsigned long long* const dbg = a.dbg + (blockIdx.x == 0 ? 0 : 8);
+#define CL_STAMP(i) do { if (stamp) dbg[i] = wall_clock64(); } while (0)
+    CL_STAMP(0);
     // XCD-aware tile order: workgroup L runs on XCD L % 8 (each XCD has its own L2).  Renumber so that
     // the workgroups of one XCD are CONSECUTIVE tiles, pixel tile fastest: the tiles that stream the same
     // weight slice (same channel tile, same K split) then share one L2 instead of pulling it eight times.
@@ -347,13 +368,20 @@ __global__ __launch_bounds__(256) void wz_k_conv_lds(const WzConvArgs a) {
     const int m_base = bx * WZ_LDS_TM;
     const int nt0 = by * (2 * NW);
 
-    // the two activation m-tiles this wave stages (2*wave, 2*wave+1): pixel of this lane
+    // Activations are staged in FULL 128-byte lines: one DMA instruction = 8 pixels x 64 channels (a K step), lane l
+    // fetching 16-byte chunk (l & 7) of pixel (l >> 3) -- 8 cache lines per instruction instead of the 16 half lines a
+    // fragment-shaped gather (16 pixels x 64 bytes) touches, which halves the address-path work per byte.  The LDS
+    // image is pixel-major, 128 bytes per pixel; a B fragment (16 pixels at a 128-byte stride) would hit two bank
+    // groups 8 ways, so chunk j of pixel P is stored at slot j ^ ((P >> 1) & 7): the swizzle is applied to the SOURCE
+    // address (the DMA writes lane-linearly) and again when the fragment is read.
+    // This wave stages pixels [wave * 32, wave * 32 + 32) of the tile, 8 per instruction.
     const int hw = a.hout * a.wout;
-    int iy0[2], ix0[2], boff[2];
-    bool mv[2];
+    int iy0[4], ix0[4], boff[4];
+    bool mv[4];
+    const int dma_j = lane & 7;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m_base + (wave * 2 + i) * 16 + r16;
+    for (int i = 0; i < 4; ++i) {
+        const int m = m_base + wave * 32 + i * 8 + (lane >> 3);
         mv[i] = m < a.M;
         const int mm = mv[i] ? m : 0;
         const int b = mm / hw, rem = mm - b * hw;
@@ -362,6 +390,8 @@ __global__ __launch_bounds__(256) void wz_k_conv_lds(const WzConvArgs a) {
         ix0[i] = ox * a.stride - a.pad_l;
         boff[i] = b * a.hin;
     }
+    // (P >> 1) & 7 of the pixel this lane fetches in instruction i: P = wave*32 + i*8 + (lane>>3)  ->  (i*4 + (lane>>4)) & 7
+    const int dma_swz = lane >> 4;   // + i * 4, & 7 below
 
     // K steps of this split (a step = 2 consecutive 32-channel chunks of one filter tap; kc is even)
     const int nsteps = a.kchunks >> 1;
@@ -370,8 +400,11 @@ __global__ __launch_bounds__(256) void wz_k_conv_lds(const WzConvArgs a) {
 
     auto stage = [&](int s, int buf) {
         unsigned char* base = wz_cl_smem + buf * BUF;
-        const int q = s * 2;
-        const int t = (KS == 1) ? 0 : q / a.kc, c = (KS == 1) ? q : q - t * a.kc;
+        // K order: channel pair outermost, filter tap innermost -- the nine taps of a channel pair read (almost) the same
+        // pixel lines, 21 KiB per tile, which then stay in the 32 KiB L1 instead of being fetched from L2 nine times
+        // (tap-major order puts 9 steps x every workgroup's traffic between two uses of a line)
+        const int t = (KS == 1) ? 0 : ((a.order & 4) ? (s * 2) / a.kc : s % taps);
+        const int c = (KS == 1) ? s * 2 : ((a.order & 4) ? s * 2 - t * a.kc : (s / taps) * 2);
         const int ky = (KS == 1) ? 0 : t / KS, kx = (KS == 1) ? 0 : t - ky * KS;
         // A: this wave stages NW/2 channel tiles x (kc = 0/1): each 2 KiB contiguous in the packed weights
 #pragma unroll
@@ -383,15 +416,14 @@ __global__ __launch_bounds__(256) void wz_k_conv_lds(const WzConvArgs a) {
             wz_glds16(wsrc, base + (ntl * 2 + 0) * 1024);
             wz_glds16(have ? wsrc + 512 : wsrc, base + (ntl * 2 + 1) * 1024);
         }
-        // B: fragments (mt = 2*wave + i, kc = 0/1)
+        // B: 8 pixels x 128 bytes per instruction
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 4; ++i) {
             const int iy = iy0[i] + ky, ix = ix0[i] + kx;
             const bool ok = mv[i] && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
-            const half_t* src = ok ? a.in + ((size_t)(boff[i] + iy) * a.win + ix) * a.cin + c * 32 + g * 8 : a.zeros;
-            unsigned char* dst = base + ABYTES + ((wave * 2 + i) * 2) * 1024;
-            wz_glds16(src, dst);
-            wz_glds16(ok ? src + 32 : a.zeros, dst + 1024);
+            const int chunk = dma_j ^ ((i * 4 + dma_swz) & 7);
+            const half_t* src = ok ? a.in + ((size_t)(boff[i] + iy) * a.win + ix) * a.cin + c * 32 + chunk * 8 : a.zeros;
+            wz_glds16(src, base + ABYTES + (wave * 4 + i) * 1024);
         }
     };
 
@@ -401,12 +433,37 @@ __global__ __launch_bounds__(256) void wz_k_conv_lds(const WzConvArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NW; ++nt) acc[mt][nt] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
-    if (s0 < s1) stage(s0, 0);
+    constexpr int D = NBUF - 1, PER = NW + 4;   // prefetch distance; DMA instructions per wave per step
+    if (producer) {
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (s0 + d < s1) stage(s0 + d, d);
+    }
+    CL_STAMP(1);
+    long long cyc_wait = 0, cyc_stage = 0, cyc_loop = stamp ? clock64() : 0;
+    int buf = 0;
     for (int s = s0; s < s1; ++s) {
-        const int buf = (s - s0) & 1;
-        __syncthreads();   // this step's DMA has landed (vmcnt(0) is part of the barrier); the other buffer is free
-        if (s + 1 < s1) stage(s + 1, buf ^ 1);
+        const long long c0 = stamp ? clock64() : 0;
+        // step s has landed once at most the DMAs of the steps issued after it are outstanding (in-order completion);
+        // past the barrier every wave is done reading the buffer of step s - 1, which step s + D reuses
+        const int later = min(D - 1, s1 - 1 - s);
+        if (NBUF == 2 || later == 0)
+            wz_wait_dma_then_barrier<0>();
+        else if (NBUF == 3 || later == 1)
+            wz_wait_dma_then_barrier<PER>();
+        else
+            wz_wait_dma_then_barrier<2 * PER>();
+        if (s == s0) CL_STAMP(2);
+        const long long c1 = stamp ? clock64() : 0;
+        if (producer && s + D < s1) stage(s + D, buf == 0 ? NBUF - 1 : buf - 1);
+        if (stamp) {
+            const long long c2 = clock64();
+            cyc_wait += c1 - c0;
+            cyc_stage += c2 - c1;
+        }
         const unsigned char* base = wz_cl_smem + buf * BUF;
+        buf = buf + 1 == NBUF ? 0 : buf + 1;
+        if (!consumer) continue;
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) {
             half8_t fa[NW], fb[4];
@@ -414,8 +471,9 @@ __global__ __launch_bounds__(256) void wz_k_conv_lds(const WzConvArgs a) {
             for (int nt = 0; nt < NW; ++nt)
                 fa[nt] = *reinterpret_cast<const half8_t*>(base + ((wn * NW + nt) * 2 + kc) * 1024 + lane * 16);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-                fb[mt] = *reinterpret_cast<const half8_t*>(base + ABYTES + ((wm * 4 + mt) * 2 + kc) * 1024 + lane * 16);
+            for (int mt = 0; mt < 4; ++mt)   // pixel P = (wm*4 + mt)*16 + r16, chunk kc*4 + g, slot swizzled by (P >> 1) & 7
+                fb[mt] = *reinterpret_cast<const half8_t*>(base + ABYTES + ((wm * 4 + mt) * 16 + r16) * 128 +
+                                                           (((kc * 4 + g) ^ ((r16 >> 1) & 7)) * 16));
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -424,12 +482,251 @@ __global__ __launch_bounds__(256) void wz_k_conv_lds(const WzConvArgs a) {
         }
     }
 
+    if (!consumer) return;
+    CL_STAMP(3);
+    if (stamp) {
+        dbg[5] = (unsigned long long)cyc_wait;
+        dbg[7] = (unsigned long long)cyc_stage;
+        dbg[6] = (unsigned long long)(s1 - s0) | ((unsigned long long)(clock64() - cyc_loop) << 16);
+    }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         const int m = m_base + (wm * 4 + mt) * 16 + r16;
 #pragma unroll
         for (int nt = 0; nt < NW; ++nt) {
             const int n4 = (nt0 + wn * NW + nt) * 16 + g * 4;
+            if (a.splitk > 1) {
+                if (m < a.M && n4 < a.n_pad)
+                    *reinterpret_cast<float4_t*>(reinterpret_cast<float*>(a.out) +
+                                                 ((size_t)bz * a.M + m) * a.n_pad + n4) = acc[mt][nt];
+            } else {
+                wz_epilogue4(a, m, n4, acc[mt][nt]);
+            }
+        }
+    }
+    if (stamp) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        dbg[4] = wall_clock64();
+    }
+#undef CL_STAMP
+}
+
+// --------------------------------------------------------------------------------------------
+// Register-staged variant of the LDS-tiled implicit GEMM (same tile, same XCD-aware order, same LDS image of the
+// activations).  Why: the `global_load_lds` path measured ~16 bytes per clock per CU no matter how it was driven (more
+// buffers in flight, dedicated producer waves, full-line sources -- tools/conv_probe.py), i.e. ~2 000 cycles for the
+// 32 KiB of a K step against 512 cycles of MFMA.  Here nothing goes through the DMA engine:
+//   * waves are laid out 1 (pixels) x 4 (channels): a wave owns NW/2 channel tiles for all 128 pixels, so its weight
+//     fragments are needed by no other wave -- they are loaded straight into VGPRs (the packed layout IS fragment order:
+//     one coalesced 1 KiB load per fragment), two K steps ahead, and never touch LDS;
+//   * the activation tile (shared by the four waves) is loaded in full 128-byte lines into VGPRs one step ahead and
+//     written to LDS with `ds_write_b128` (lane-linear image, chunk swizzle applied on the source side) -- 16 KiB per
+//     step instead of 32 KiB, through the ordinary vector-memory path.
+// One `__syncthreads()` per K step, two 16 KiB LDS buffers.
+// --------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) unsigned int uint4_t;
+#ifndef WZ_RS_STAMPS
+#define WZ_RS_STAMPS 0
+#endif
+
+// SPEC: eight waves; 0..3 only compute (and fetch their own weight fragments), 4..7 only move the activation tile
+// (global -> VGPR -> LDS).  A wave issues in order, so with four waves the ~1 000 cycles of loads, waits and LDS writes
+// of a step sit in front of its ~750 cycles of fragment reads and MFMAs; split over two waves per SIMD they overlap.
+template <int KS, int NW, bool SPEC>
+__global__ __launch_bounds__(SPEC ? 512 : 256, 2) void wz_k_conv_rs(const WzConvArgs a) {   // <= 256 registers: two waves per SIMD
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 16384];
+    constexpr int taps = KS * KS;
+    constexpr int NTW = NW / 2;   // 16-channel tiles per wave
+    constexpr unsigned OOB = 0x7ffffff0u;   // buffer offset beyond every tensor: the load returns zeros
+    const int n_tiles = a.n_pad >> 4;
+    const int lane = threadIdx.x & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform
+    const int wave = wave8 & 3;
+    const bool mover = !SPEC || wave8 >= 4, worker = !SPEC || wave8 < 4;
+    const int r16 = lane & 15, g = lane >> 4;
+    int bx, by, bz;
+    {   // XCD-aware tile order, as in wz_k_conv_lds
+        const int total = a.grid_m * a.grid_n * a.splitk;
+        const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+        const int qd = total >> 3, rm = total & 7;
+        int V = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + slot;
+        if (a.order == 1) V = L;
+        bx = V % a.grid_m;
+        const int rest = V / a.grid_m;
+        by = rest % a.grid_n;
+        bz = rest / a.grid_n;
+    }
+    const int m_base = bx * WZ_LDS_TM;
+    const int nt_w = by * (2 * NW) + wave * NTW;   // first channel tile of this wave
+
+    // Addressing is the expensive part of an implicit GEMM step if done naively (a first version spent 900 of its
+    // 2 400 cycles per step on 64-bit address arithmetic and bounds tests): both operands are read through buffer
+    // descriptors with 32-bit offsets, everything that depends on the K step is wave-uniform (SGPR offset), and what
+    // depends on the lane is computed once: the byte offset of the lane's pixel/chunk at tap (0, 0) and a 9-bit mask of
+    // the taps that fall inside the frame.  An out-of-frame lane gets an out-of-range offset, for which the hardware
+    // returns zeros -- no zero page, no branch.
+    const int hw = a.hout * a.wout;
+    const int n_frames = (a.M + hw - 1) / hw;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.in, 0, n_frames * a.hin * a.win * a.cin * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.w, 0, n_tiles * taps * a.kc * 1024, 0x00020000);
+
+    // activation staging: instruction i of this wave = pixels wave*32 + i*8 + (lane >> 3), 16-byte chunk (lane & 7)
+    // stored at slot chunk ^ ((P >> 1) & 7) of the pixel's 128 bytes (lane-linear LDS write, swizzled source)
+    int pix_off[4];
+    unsigned tapmask[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m_base + wave * 32 + i * 8 + (lane >> 3);
+        const bool mv = m < a.M;
+        const int mm = mv ? m : 0;
+        const int b = mm / hw, rem = mm - b * hw;
+        const int oy = rem / a.wout, ox = rem - oy * a.wout;
+        const int iy0 = oy * a.stride - a.pad_t, ix0 = ox * a.stride - a.pad_l;
+        const int chunk = (lane & 7) ^ ((i * 4 + (lane >> 4)) & 7);
+        pix_off[i] = (((b * a.hin + iy0) * a.win + ix0) * a.cin + chunk * 8) * 2;
+        unsigned mask = 0;
+#pragma unroll
+        for (int t = 0; t < taps; ++t) {
+            const int iy = iy0 + t / KS, ix = ix0 + t % KS;
+            if (mv && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win) mask |= 1u << t;
+        }
+        tapmask[i] = mask;
+    }
+
+    const int nsteps = a.kchunks >> 1;
+    const int per = (nsteps + a.splitk - 1) / a.splitk;
+    const int s0 = bz * per, s1 = min(s0 + per, nsteps);
+
+    // K order: channel pair outermost, filter tap innermost (the nine taps of a channel pair read almost the same lines)
+    auto load_b = [&](int s, uint4_t (&r)[4]) {
+        const int t = (KS == 1) ? 0 : s % taps;
+        const int c = (KS == 1) ? s * 2 : (s / taps) * 2;
+        const int ky = (KS == 1) ? 0 : t / KS, kx = (KS == 1) ? 0 : t - ky * KS;
+        const int tap_off = (ky * a.win + kx) * a.cin * 2;   // bytes, wave-uniform
+        const int soff = c * 64;                             // 32 channels = 64 bytes per chunk
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned voff = ((tapmask[i] >> t) & 1u) ? (unsigned)(pix_off[i] + tap_off) : OOB;
+            r[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff, soff, 0);
+        }
+    };
+    auto store_b = [&](int buf, const uint4_t (&r)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<uint4_t*>(smem + buf * 16384 + (wave * 4 + i) * 1024 + lane * 16) = r[i];
+    };
+    auto load_a = [&](int s, half8_t (&f)[NTW][2]) {
+        const int t = (KS == 1) ? 0 : s % taps;
+        const int c = (KS == 1) ? s * 2 : (s / taps) * 2;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            // fragment (tile, tap, chunk) = 1 KiB at ((tile * taps + tap) * kc + chunk) * 1 KiB; tiles past the end read zeros
+            const unsigned soff = nt_w + nt < n_tiles ? (unsigned)(((nt_w + nt) * taps + t) * a.kc + c) * 1024u : OOB;
+            const uint4_t lo = __builtin_amdgcn_raw_buffer_load_b128(rs_w, lane * 16, soff, 0);
+            const uint4_t hi = __builtin_amdgcn_raw_buffer_load_b128(rs_w, lane * 16 + 1024, soff, 0);
+            f[nt][0] = __builtin_bit_cast(half8_t, lo);
+            f[nt][1] = __builtin_bit_cast(half8_t, hi);
+        }
+    };
+
+    float4_t acc[8][NTW];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int buf, const half8_t (&f)[NTW][2]) {
+        const unsigned char* base = smem + buf * 16384;
+        // all sixteen activation fragments of the step first, then the MFMAs back to back: left to itself the
+        // scheduler recycles two fragment registers and exposes the LDS latency sixteen times per step
+        half8_t fb[2][8];
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt)   // pixel P = mt*16 + r16, chunk kc*4 + g, slot swizzled by (P >> 1) & 7
+                fb[kc][mt] = *reinterpret_cast<const half8_t*>(base + (mt * 16 + r16) * 128 + (((kc * 4 + g) ^ ((r16 >> 1) & 7)) * 16));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[nt][kc], fb[kc][mt], acc[mt][nt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // Two K steps per trip so that the two weight-fragment sets and the two LDS buffers have static names; loads past
+    // the last step are clamped to it (a redundant reload instead of a branch), an odd last step runs after the loop.
+    // Half-step (parity p): LDS buffer p and fragment set p hold its step, `rb` holds the activations of the next step
+    // (loaded one half-step ago), fragment set p ^ 1 the next weights (loaded one and a half half-steps ago).
+    uint4_t rb[4];
+    half8_t fa0[NTW][2], fa1[NTW][2];
+    const int last = s1 - 1, pairs = (s1 - s0) >> 1;
+    if (s0 < s1) {
+        if (mover) {
+            load_b(s0, rb);
+            store_b(0, rb);
+            load_b(min(s0 + 1, last), rb);
+        }
+        if (worker) {
+            load_a(s0, fa0);
+            load_a(min(s0 + 1, last), fa1);
+        }
+        __syncthreads();
+        int s = s0;
+        // phase cycle counts for tools/rs_probe.py: compiled in only with -DWZ_RS_STAMPS=1 (they cost registers)
+        const bool stamp = WZ_RS_STAMPS && a.dbg && (threadIdx.x & 255) == 0 && blockIdx.x == 0;
+        long long cy[5] = {0, 0, 0, 0, 0};
+        for (int p = 0; p < pairs; ++p, s += 2) {
+            const long long c0 = stamp ? clock64() : 0;
+            long long c1 = c0, c2 = c0, c3 = c0;
+            if (mover) {
+                store_b(1, rb);   // buffer 1 was last read before the previous barrier
+                c1 = stamp ? clock64() : 0;
+                load_b(min(s + 2, last), rb);
+                c2 = c3 = stamp ? clock64() : 0;
+            }
+            if (worker) {
+                if (SPEC) c1 = c2 = stamp ? clock64() : 0;
+                compute(0, fa0);
+                c3 = stamp ? clock64() : 0;
+                load_a(min(s + 2, last), fa0);
+            }
+            const long long c4 = stamp ? clock64() : 0;
+            __syncthreads();
+            if (stamp) {
+                const long long c5 = clock64();
+                cy[0] += c1 - c0; cy[1] += c2 - c1; cy[2] += c3 - c2; cy[3] += c4 - c3; cy[4] += c5 - c4;
+            }
+            if (mover) {
+                store_b(0, rb);
+                load_b(min(s + 3, last), rb);
+            }
+            if (worker) {
+                compute(1, fa1);
+                load_a(min(s + 3, last), fa1);
+            }
+            __syncthreads();
+        }
+        if (worker && ((s1 - s0) & 1)) compute(0, fa0);
+        if (stamp && pairs > 0) {
+            unsigned long long* const d = a.dbg + (threadIdx.x == 0 ? 0 : 8);   // slots 8.. = a mover wave
+#pragma unroll
+            for (int i = 0; i < 5; ++i) d[i] = (unsigned long long)(cy[i] / pairs);
+            d[5] = (unsigned long long)pairs;
+        }
+    }
+    if (!worker) return;
+
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+        const int m = m_base + mt * 16 + r16;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int n4 = (nt_w + nt) * 16 + g * 4;
             if (a.splitk > 1) {
                 if (m < a.M && n4 < a.n_pad)
                     *reinterpret_cast<float4_t*>(reinterpret_cast<float*>(a.out) +
@@ -460,12 +757,19 @@ static int wz_lds_nw(int M, int n_pad, int kchunks) {
     return (n_pad >= 256 && M >= 512 && kchunks >= 64) ? 4 : 2;   // measured: the two big heads gain, Conv_1 (K = 320) loses
 }
 
+static int wz_lds_nbuf();
+static int wz_lds_spec();
 int wz_choose_splitk_lds(int M, int n_pad, int kchunks) {
-    static const int target = wz_env_int("WZ_LDS_WGS", 256);   // the DMA path saturates near one workgroup per CU
+    static const int target = wz_env_int("WZ_LDS_WGS", 192);   // measured 64 .. 512: fewer, longer K slices win (less partial-sum traffic); 192 best
     const int tn = WZ_LDS_TN(wz_lds_nw(M, n_pad, kchunks));
     const int wgs = ((M + WZ_LDS_TM - 1) / WZ_LDS_TM) * ((n_pad + tn - 1) / tn);
     const int nsteps = kchunks / 2;
     int s = (target + wgs - 1) / wgs;
+    // with more than 80 KiB of LDS per workgroup only one fits a CU: a grid beyond 256 workgroups would need a second,
+    // nearly empty round
+    static const int rs_mode = wz_env_int("WZ_LDS_RS", 1);
+    const bool one_per_cu = rs_mode ? wz_lds_spec() != 0 : wz_lds_nbuf() * WZ_LDS_BUF(wz_lds_nw(M, n_pad, kchunks)) > 80 * 1024;
+    if (one_per_cu && s * wgs > 256) s = 256 / wgs;
     if (s > nsteps / 4) s = nsteps / 4;   // >= 4 steps per split
     if (s > 32) s = 32;
     return s < 1 ? 1 : s;
@@ -501,11 +805,41 @@ static void wz_launch_conv_cfg(const WzConvArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((wz_k_conv<3, MT, NT, U>), grid, dim3(256), 0, s, a);
 }
 
+static int wz_lds_nbuf() { return 2; }
+
+static int wz_lds_spec() {
+    static const int v = wz_env_int("WZ_LDS_SPEC", 0);
+    return v;
+}
+
+template <int KS, int NW, int NBUF, bool SPEC>
+static void wz_conv_lds_attr() {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wz_k_conv_lds<KS, NW, NBUF, SPEC>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, NBUF * WZ_LDS_BUF(NW));
+}
+template <int KS, int NW>
+static void wz_conv_lds_attrs() {
+    wz_conv_lds_attr<KS, NW, 2, false>();
+}
 void wz_conv_init() {   // kernel attributes (before any stream capture)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wz_k_conv_lds<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WZ_LDS_BUF(2));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wz_k_conv_lds<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WZ_LDS_BUF(2));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wz_k_conv_lds<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WZ_LDS_BUF(4));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wz_k_conv_lds<3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WZ_LDS_BUF(4));
+    wz_conv_lds_attrs<1, 2>();
+    wz_conv_lds_attrs<3, 2>();
+    wz_conv_lds_attrs<1, 4>();
+    wz_conv_lds_attrs<3, 4>();
+}
+
+// Default: the register-staged kernel (wz_k_conv_rs).  WZ_LDS_RS=0 selects the LDS-DMA kernel (two buffers), kept for
+// comparison; its deeper rings (WZ_LDS_NBUF 3/4) and its producer/consumer form are instantiated only with
+// -DWZ_LDS_VARIANTS=1 -- they measured no faster.
+template <int KS, int NW>
+static void wz_launch_conv_lds(const WzConvArgs& a, dim3 grid, hipStream_t s) {
+    static const int rs = wz_env_int("WZ_LDS_RS", 1);
+    if (rs && wz_lds_spec())
+        hipLaunchKernelGGL((wz_k_conv_rs<KS, NW, true>), grid, dim3(512), 0, s, a);
+    else if (rs)
+        hipLaunchKernelGGL((wz_k_conv_rs<KS, NW, false>), grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((wz_k_conv_lds<KS, NW, 2, false>), grid, dim3(256), 2 * WZ_LDS_BUF(NW), s, a);
 }
 
 void wz_launch_conv(const WzConvArgs& a0, hipStream_t s) {
@@ -514,17 +848,19 @@ void wz_launch_conv(const WzConvArgs& a0, hipStream_t s) {
         a.grid_m = (a.M + WZ_LDS_TM - 1) / WZ_LDS_TM;
         const int nw = wz_lds_nw(a.M, a.n_pad, a.kchunks);
         a.grid_n = (a.n_pad + WZ_LDS_TN(nw) - 1) / WZ_LDS_TN(nw);
+        static const int order = wz_env_int("WZ_LDS_ORDER", 0);
+        a.order = order;
         dim3 grid(a.grid_m * a.grid_n * a.splitk);
         if (nw == 4) {
             if (a.ksize == 1)
-                hipLaunchKernelGGL((wz_k_conv_lds<1, 4>), grid, dim3(256), 2 * WZ_LDS_BUF(4), s, a);
+                wz_launch_conv_lds<1, 4>(a, grid, s);
             else
-                hipLaunchKernelGGL((wz_k_conv_lds<3, 4>), grid, dim3(256), 2 * WZ_LDS_BUF(4), s, a);
+                wz_launch_conv_lds<3, 4>(a, grid, s);
         } else {
             if (a.ksize == 1)
-                hipLaunchKernelGGL((wz_k_conv_lds<1, 2>), grid, dim3(256), 2 * WZ_LDS_BUF(2), s, a);
+                wz_launch_conv_lds<1, 2>(a, grid, s);
             else
-                hipLaunchKernelGGL((wz_k_conv_lds<3, 2>), grid, dim3(256), 2 * WZ_LDS_BUF(2), s, a);
+                wz_launch_conv_lds<3, 2>(a, grid, s);
         }
         return;
     }

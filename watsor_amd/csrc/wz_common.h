@@ -42,6 +42,8 @@ struct WzConvArgs {
     const half_t* zeros;        // 4 KiB of zeros in HBM: source of out-of-frame lanes / absent tiles in the LDS-tiled kernel
     int32_t grid_m, grid_n;     // LDS-tiled kernel: pixel tiles x channel tiles (filled in by the launcher)
     float* ws;                  // fp32 engine: split-K workspace (the fp16 kernels get it through `out`)
+    unsigned long long* dbg;    // WZ_MB_DEBUG=1: 16 slots of phase timestamps (LDS-tiled kernel), else nullptr
+    int32_t order;              // tile order of the LDS-tiled kernels (experiment knob WZ_LDS_ORDER)
 };
 
 // One fused inverted-residual block (k_mbconv.hip).  cin/kc/n_pad/cout describe the project conv.

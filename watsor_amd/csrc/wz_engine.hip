@@ -226,6 +226,7 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t) {
                 a.n_box = op.n_box;
             }
             a.zeros = e->d_zeros;
+            a.dbg = e->d_mbdbg ? e->d_mbdbg + (size_t)i * 16 : nullptr;
             if (f32) {   // a.kc / a.kchunks count 16-channel chunks here
                 int sk = e->use_splitk ? wz_choose_splitk(a.M, a.n_pad, a.kchunks / 2) : 1;
                 while (sk > 1 && (size_t)sk * a.M * a.n_pad * 4 > WZ_WS_BYTES) --sk;
