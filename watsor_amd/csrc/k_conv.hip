@@ -301,6 +301,26 @@ __global__ __launch_bounds__(256) void wz_k_splitk_reduce(const WzConvArgs a, co
     wz_epilogue4(a, m, n4, v);
 }
 
+// The reductions of several convolutions in one launch: a workgroup finds its entry from the prefix table, then does
+// exactly what wz_k_splitk_reduce does (same order over the splits: bit-identical results).
+__global__ __launch_bounds__(256) void wz_k_splitk_reduce_group(const WzReduceGroup g) {
+    int e = 0;
+    while (e + 1 < g.n && (int)blockIdx.x >= g.first[e + 1]) ++e;   // wave-uniform
+    const WzConvArgs& a = g.a[e];
+    const float* __restrict__ ws = g.ws[e];
+    const int tid = ((int)blockIdx.x - g.first[e]) * 256 + threadIdx.x;
+    const int n4s = a.n_pad >> 2;
+    if (tid >= a.M * n4s) return;
+    const int m = tid / n4s, n4 = (tid - m * n4s) * 4;
+    float4_t v = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < a.splitk; ++z) {
+        const float4_t p = *reinterpret_cast<const float4_t*>(ws + ((size_t)z * a.M + m) * a.n_pad + n4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += p[r];
+    }
+    wz_epilogue4(a, m, n4, v);
+}
+
 // --------------------------------------------------------------------------------------------
 // LDS-tiled implicit GEMM for the layers with a long K loop (the 3x3 SSD heads, the 3x3 extras, Conv_1):
 // workgroup = 128 pixels x 64 channels, K step = 64 (two MFMA K chunks), 4 waves as 2 (pixels) x 2
@@ -869,6 +889,16 @@ void wz_launch_conv(const WzConvArgs& a0, hipStream_t s) {
         wz_launch_conv_cfg<4, 4, 2>(a, s);
     else
         wz_launch_conv_cfg<2, 2, 4>(a, s);
+}
+
+void wz_reduce_group_add(WzReduceGroup& g, const WzConvArgs& a, const float* ws) {
+    const int i = g.n++;
+    g.a[i] = a;
+    g.ws[i] = ws;
+    g.first[i + 1] = g.first[i] + (a.M * (a.n_pad >> 2) + 255) / 256;
+}
+void wz_launch_splitk_reduce_group(const WzReduceGroup& g, hipStream_t s) {
+    hipLaunchKernelGGL(wz_k_splitk_reduce_group, dim3(g.first[g.n]), dim3(256), 0, s, g);
 }
 
 void wz_launch_splitk_reduce(const WzConvArgs& a, const float* ws, hipStream_t s) {

@@ -95,6 +95,16 @@ void wz_launch_dw(const half_t* in, const half_t* w, const float* bias, half_t* 
                   int c, int hout, int wout, int stride, int pad_t, int pad_l, int act, hipStream_t s);
 void wz_launch_conv(const WzConvArgs& a, hipStream_t s);
 void wz_launch_splitk_reduce(const WzConvArgs& a, const float* ws, hipStream_t s);
+// several split-K reductions (each with its own epilogue arguments and partial sums) in ONE launch
+#define WZ_REDUCE_GROUP_MAX 8
+struct WzReduceGroup {
+    int32_t n;
+    int32_t first[WZ_REDUCE_GROUP_MAX + 1];   // first workgroup of entry i; first[n] = grid size
+    WzConvArgs a[WZ_REDUCE_GROUP_MAX];
+    const float* ws[WZ_REDUCE_GROUP_MAX];
+};
+void wz_reduce_group_add(WzReduceGroup& g, const WzConvArgs& a, const float* ws);
+void wz_launch_splitk_reduce_group(const WzReduceGroup& g, hipStream_t s);
 int wz_choose_splitk(int M, int n_pad, int kchunks);
 bool wz_conv_use_lds(const WzConvArgs& a);               // the LDS-tiled kernel will serve this conv
 int wz_choose_splitk_lds(int M, int n_pad, int kchunks);

@@ -71,6 +71,7 @@ struct wz_engine {
     const WzOpDesc* ops = nullptr;
     int max_batch = 0, max_w = 0, max_h = 0;
     bool no_reuse = false, use_graph = true, use_splitk = true;
+    bool defer_heads = true;   // the SSD heads' split-K reductions run as one launch after the last head (WZ_DEFER_HEADS=0: one each)
 
     uint8_t* d_weights = nullptr;
     half_t* d_zeros = nullptr;               // 4 KiB of zeros
@@ -156,6 +157,13 @@ static WzMbArgs mb_args(wz_engine* e, const Lane& L, const WzOpDesc& op) {
 static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t) {
     hipStream_t s = L.stream;
     const bool f32 = e->hdr.precision == 32;
+    // The heads write only into the box / logit buffers that the post kernels read at the very end, so their partial
+    // sums can wait: each head's slab is parked at the top of the workspace and ONE launch reduces them all after the
+    // last op (six launches fewer per batch).  Everything else uses the workspace below `ws_top`.
+    size_t ws_top = WZ_WS_BYTES;
+    WzReduceGroup heads;
+    heads.n = 0;
+    heads.first[0] = 0;
     for (uint32_t i = 0; i < e->hdr.n_ops; ++i) {
         const WzOpDesc& op = e->ops[i];
         const uint8_t* wbase = e->d_weights;
@@ -177,7 +185,7 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t) {
             WzMbArgs a = mb_args(e, L, op);
             a.M = n * op.hout * op.wout;
             a.ws = e->use_splitk ? L.d_ws : nullptr;
-            a.ws_bytes = WZ_WS_BYTES;
+            a.ws_bytes = ws_top;
             a.dbg = e->d_mbdbg ? e->d_mbdbg + (size_t)i * 16 : nullptr;
             int groups = wz_launch_mbconv_wave(a, n, s, false);   // large maps: one wavefront per pixel tile
             if (groups == -2 && e->use_splitk) groups = wz_launch_mbconv_cs(a, n, s, false);   // small maps: channels over waves
@@ -229,7 +237,7 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t) {
             a.dbg = e->d_mbdbg ? e->d_mbdbg + (size_t)i * 16 : nullptr;
             if (f32) {   // a.kc / a.kchunks count 16-channel chunks here
                 int sk = e->use_splitk ? wz_choose_splitk(a.M, a.n_pad, a.kchunks / 2) : 1;
-                while (sk > 1 && (size_t)sk * a.M * a.n_pad * 4 > WZ_WS_BYTES) --sk;
+                while (sk > 1 && (size_t)sk * a.M * a.n_pad * 4 > ws_top) --sk;
                 a.splitk = sk;
                 a.ws = L.d_ws;
                 a.out = final_out;
@@ -240,7 +248,20 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t) {
             int sk = 1;
             if (e->use_splitk)
                 sk = wz_conv_use_lds(a) ? wz_choose_splitk_lds(a.M, a.n_pad, a.kchunks) : wz_choose_splitk(a.M, a.n_pad, a.kchunks);
-            while (sk > 1 && (size_t)sk * a.M * a.n_pad * 4 > WZ_WS_BYTES) --sk;
+            const size_t slab = (((size_t)sk * a.M * a.n_pad * 4) + 255) & ~(size_t)255;
+            if (sk > 1 && e->defer_heads && op.out_mode != WZ_OUT_ACT && heads.n < WZ_REDUCE_GROUP_MAX &&
+                slab + (WZ_WS_BYTES >> 1) <= ws_top) {   // keep at least half of the workspace for the other ops
+                ws_top -= slab;
+                float* const park = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(L.d_ws) + ws_top);
+                a.splitk = sk;
+                a.out = park;
+                wz_launch_conv(a, s);
+                if (t) { t->mark(); t->mark(); }   // its own reduce slot stays empty
+                a.out = final_out;
+                wz_reduce_group_add(heads, a, park);
+                continue;
+            }
+            while (sk > 1 && (size_t)sk * a.M * a.n_pad * 4 > ws_top) --sk;
             a.splitk = sk;
             if (sk > 1) {
                 a.out = L.d_ws;
@@ -256,6 +277,8 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t) {
         }
         if (t) t->mark();
     }
+    if (heads.n > 0) wz_launch_splitk_reduce_group(heads, s);
+    if (t) t->mark();
 }
 
 static void enqueue_post(wz_engine* e, Lane& L, bool rows, int n, StageTimer* t) {
@@ -419,6 +442,7 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     e->no_reuse = (env = getenv("WZ_NO_BUFFER_REUSE")) && atoi(env) != 0;
     e->use_graph = !((env = getenv("WZ_GRAPH")) && atoi(env) == 0);
     e->use_splitk = !((env = getenv("WZ_SPLITK")) && atoi(env) == 0);
+    e->defer_heads = !((env = getenv("WZ_DEFER_HEADS")) && atoi(env) == 0);
     if ((env = getenv("WZ_LANES")) && atoi(env) >= 1 && atoi(env) <= WZ_SLOTS) e->n_lanes = atoi(env);
 
 #define CK(expr)                                                                                        \
@@ -552,6 +576,7 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
         if (e->ops[i].kind == WZ_OP_CONV || e->ops[i].kind == WZ_OP_MBCONV)
             e->stage_names.push_back(std::string(e->ops[i].name) + "#splitk_reduce");
     }
+    e->stage_names.push_back("heads#splitk_reduce");
     e->stage_names.push_back("post/decode");
     e->stage_names.push_back("post/hist");
     e->stage_names.push_back("post/compact");
