@@ -15,6 +15,8 @@
 //                  read the same way (pixel r16, channels k0 + 4g ..), and the four MFMAs of a 16-channel
 //                  chunk consume component t of both float4s (k = k0 + 4g + t)
 //  wz_k_splitk_reduce_f32
+#include <stdlib.h>
+
 #include "wz_common.h"
 
 __global__ __launch_bounds__(256) void wz_k_stem_f32(const half_t* __restrict__ in, const float* __restrict__ w,
@@ -274,8 +276,67 @@ void wz_launch_dw_f32(const float* in, const float* w, const float* bias, float*
                        hout, wout, stride, pad_t, pad_l, act);
 }
 
+// ---- the register-staged LDS-tiled kernel (k_conv_rs.h) in fp32: the long-K convolutions
+#include "k_conv_rs.h"
+
+struct WzEpiF32 {
+    static __device__ __forceinline__ void apply(const WzConvArgs& a, int m, int n4, float4_t v) { wz_epilogue4_f32(a, m, n4, v); }
+    static __device__ __forceinline__ float* partials(const WzConvArgs& a) { return a.ws; }
+};
+
+template <int KS, int NW>
+__global__ __launch_bounds__(256, 2) void wz_k_conv_rs_f32(const WzConvArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 16384];
+    wz_conv_rs_body<KS, NW, false, true, WzEpiF32>(a, smem);
+}
+
+// whole 64-column tiles, whole 32-channel K steps, enough pixels and a K loop long enough to pay for the tile
+bool wz_conv_f32_use_rs(const WzConvArgs& a) {
+    static const bool on = [] { const char* e = getenv("WZ_F32_RS"); return !(e && atoi(e) == 0); }();
+    // (channel tiles past n_pad read zeros and are never stored: n_pad need not be a multiple of the tile)
+    return on && a.kc % 2 == 0 && a.cin % 32 == 0 && a.M >= 128 && a.kchunks >= 8;
+}
+
+// This variant is MFMA-bound (4 096 cycles of fp32 MFMA per step against ~1 000 of loads and LDS traffic).  Measured
+// targets 256 / 512 / 768 workgroups: 12.2 / 12.1 / 11.9 k frames/s -- a second workgroup per CU does not pay.
+int wz_choose_splitk_rs_f32(int M, int n_pad, int kchunks) {
+    static const int target = [] { const char* e = getenv("WZ_F32_WGS"); return (e && atoi(e) > 0) ? atoi(e) : 256; }();
+    const int tn = wz_lds_nw(M, n_pad, kchunks) * 32;
+    const int wgs = ((M + WZ_RS_TM - 1) / WZ_RS_TM) * ((n_pad + tn - 1) / tn);
+    const int nsteps = kchunks / 2;
+    int s = (target + wgs - 1) / wgs;
+    if (s > nsteps / 4) s = nsteps / 4;   // >= 4 steps per split
+    if (s > 32) s = 32;
+    return s < 1 ? 1 : s;
+}
+
 // a.splitk > 1: partials go to a.ws and the reduce kernel is enqueued right behind
-void wz_launch_conv_f32(const WzConvArgs& a, hipStream_t s) {
+void wz_launch_conv_f32(const WzConvArgs& a0, hipStream_t s) {
+    if (wz_conv_f32_use_rs(a0)) {
+        WzConvArgs a = a0;
+        const int nw = wz_lds_nw(a.M, a.n_pad, a.kchunks);
+        a.grid_m = (a.M + WZ_RS_TM - 1) / WZ_RS_TM;
+        a.grid_n = (a.n_pad + nw * 32 - 1) / (nw * 32);
+        a.order = 0;
+        const dim3 grid(a.grid_m * a.grid_n * a.splitk);
+        if (nw == 4) {
+            if (a.ksize == 1)
+                hipLaunchKernelGGL((wz_k_conv_rs_f32<1, 4>), grid, dim3(256), 0, s, a);
+            else
+                hipLaunchKernelGGL((wz_k_conv_rs_f32<3, 4>), grid, dim3(256), 0, s, a);
+        } else {
+            if (a.ksize == 1)
+                hipLaunchKernelGGL((wz_k_conv_rs_f32<1, 2>), grid, dim3(256), 0, s, a);
+            else
+                hipLaunchKernelGGL((wz_k_conv_rs_f32<3, 2>), grid, dim3(256), 0, s, a);
+        }
+        if (a.splitk > 1) {
+            const int total = a.M * (a.n_pad >> 2);
+            hipLaunchKernelGGL(wz_k_splitk_reduce_f32, dim3((total + 255) / 256), dim3(256), 0, s, a);
+        }
+        return;
+    }
+    const WzConvArgs& a = a0;
     const int mtiles = (a.M + 31) / 32;
     dim3 grid((mtiles + 3) / 4, a.n_pad / 32, a.splitk);
     if (a.ksize == 1)

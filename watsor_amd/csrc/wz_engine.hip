@@ -236,7 +236,7 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t) {
             a.zeros = e->d_zeros;
             a.dbg = e->d_mbdbg ? e->d_mbdbg + (size_t)i * 16 : nullptr;
             if (f32) {   // a.kc / a.kchunks count 16-channel chunks here
-                int sk = e->use_splitk ? wz_choose_splitk(a.M, a.n_pad, a.kchunks / 2) : 1;
+                int sk = !e->use_splitk ? 1 : wz_conv_f32_use_rs(a) ? wz_choose_splitk_rs_f32(a.M, a.n_pad, a.kchunks) : wz_choose_splitk(a.M, a.n_pad, a.kchunks / 2);
                 while (sk > 1 && (size_t)sk * a.M * a.n_pad * 4 > ws_top) --sk;
                 a.splitk = sk;
                 a.ws = L.d_ws;
