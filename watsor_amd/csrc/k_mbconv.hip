@@ -167,12 +167,7 @@ __global__ __launch_bounds__(256) void wz_k_mbconv(const WzMbArgs a) {
 #pragma unroll
                     for (int c = 0; c < KCI; ++c)
                         d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[c], h.xf[i][c], d, 0, 0, 0);
-                    half4_t o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float v = fminf(fmaxf(d[r] + bv[r], 0.0f), 6.0f);
-                        o[r] = h.inimg[i] ? (half_t)v : (half_t)0.0f;
-                    }
+                    const half4_t o = wz_relu6_pack(d, bv, h.inimg[i]);
                     *reinterpret_cast<half4_t*>(E + (mt * 16 + r16) * ES + nt * 16 + g * 4) = o;
                 }
             }
