@@ -197,6 +197,7 @@ __device__ __forceinline__ float wz_iou(const float4_t a, const float4_t c) {
 struct WzIouThr {
     double mid;
     float lo, hi;   // thr * (1 -/+ 1e-3)
+    float cl, ch;   // lo / (1 + lo), hi / (1 + hi): inter > lo * uni  <=>  inter > cl * (area_a + area_c)
     bool tie_up;
 };
 __device__ __forceinline__ WzIouThr wz_iou_thr(float thr) {
@@ -206,6 +207,8 @@ __device__ __forceinline__ WzIouThr wz_iou_thr(float thr) {
     t.tie_up = (__float_as_uint(thr) & 1u) != 0u;
     t.lo = thr * 0.999f;
     t.hi = thr * 1.001f;
+    t.cl = (float)((double)t.lo / (1.0 + (double)t.lo));
+    t.ch = (float)((double)t.hi / (1.0 + (double)t.hi));
     return t;
 }
 __device__ __forceinline__ bool wz_iou_exceeds(const float4_t a, float area_a, const float4_t c, float area_c,
@@ -220,6 +223,32 @@ __device__ __forceinline__ bool wz_iou_exceeds(const float4_t a, float area_a, c
     if (inter > t.hi * uni) return true;
     const double lhs = (double)inter, rhs = t.mid * (double)uni;
     return lhs > rhs || (t.tie_up && lhs == rhs);
+}
+// The pair loop of the walk runs on ONE CU and is VALU-bound, so the per-box half of the clear-case test is hoisted:
+// pre = {cl * area, ch * area, area, class bits}, with +inf in the first two when the area is not positive (IOU() is 0
+// for such a box).  inter > lo * uni  <=>  inter * (1 + lo) > lo * (area_a + area_c)  <=>  inter > pre_a[0] + pre_c[0];
+// the roundings of the products and of the sum (< 3e-7 relative) are far inside the 1e-3 margins, and everything
+// between the two margins still goes through the exact test.
+__device__ __forceinline__ float4_t wz_pair_pre(float area, int cls, const WzIouThr t) {
+    const float inf = __builtin_inff();
+    const bool ok = area > 0.0f;
+    return (float4_t){ok ? t.cl * area : inf, ok ? t.ch * area : inf, area, __int_as_float(cls)};
+}
+__device__ __forceinline__ bool wz_pair_suppresses(const float4_t a, const float4_t pa, const float4_t c,
+                                                   const float4_t pc, const WzIouThr t) {
+    // straight-line except for the rare near-threshold case: divergent branches cost more here than the arithmetic
+    const bool same = __float_as_int(pa[3]) == __float_as_int(pc[3]);
+    const float iy0 = fmaxf(a[0], c[0]), ix0 = fmaxf(a[1], c[1]);
+    const float iy1 = fminf(a[2], c[2]), ix1 = fminf(a[3], c[3]);
+    const float inter = fmaxf(iy1 - iy0, 0.0f) * fmaxf(ix1 - ix0, 0.0f);
+    const bool above_lo = inter > pa[0] + pc[0], above_hi = inter > pa[1] + pc[1];
+    bool r = same & above_hi;
+    if (same & above_lo & !above_hi) {
+        const float uni = pa[2] + pc[2] - inter;   // as IOU() computes it
+        const double lhs = (double)inter, rhs = t.mid * (double)uni;
+        r = lhs > rhs || (t.tie_up && lhs == rhs);
+    }
+    return r;
 }
 __device__ __forceinline__ float4_t wz_norm_box(const float4_t b, float& area) {
     const float4_t n = {fminf(b[0], b[2]), fminf(b[1], b[3]), fmaxf(b[0], b[2]), fmaxf(b[1], b[3])};
@@ -244,6 +273,8 @@ struct NmsShared {   // carved from dynamic LDS, every member 16-byte aligned
     unsigned long long supp[NMS_CHUNK][NMS_CHUNK / 64];   // supp[j] = mask of earlier chunk members i < j that suppress j
     float4_t cnorm[NMS_CHUNK];                            // candidate boxes normalised to (ymin,xmin,ymax,xmax)
     float4_t knorm[NMS_KEEP_MAX];                         // the same for the kept list
+    float4_t cpre[NMS_CHUNK];                             // wz_pair_pre of the chunk members
+    float4_t kpre[NMS_KEEP_MAX];                          // ... and of the kept list
     float carea[NMS_CHUNK];
     float karea[NMS_KEEP_MAX];
     int32_t ccls[NMS_CHUNK];
@@ -277,6 +308,7 @@ __device__ __forceinline__ int wz_try_keep(NmsShared* S, int kept, const float4_
             S->kbox[kept] = box;
             S->knorm[kept] = wz_norm_box(box, ar);
             S->karea[kept] = ar;
+            S->kpre[kept] = wz_pair_pre(ar, cls, wz_iou_thr(k.iou_thr));
             S->kcls[kept] = cls;
             S->kscore[kept] = score;
         }
@@ -365,8 +397,10 @@ __device__ int wz_nms_band(NmsShared* S, const WzPostBuffers& b, const WzPostCon
                 float ar;
                 S->cnorm[i] = wz_norm_box(S->sbox[base + i], ar);
                 S->carea[i] = ar;
+                S->cpre[i] = wz_pair_pre(ar, S->ccls[i], ithr);
             } else {
                 S->ccls[i] = -1;
+                S->cpre[i] = wz_pair_pre(0.0f, -1, ithr);
             }
         }
         for (int c = tid; c < ncls; c += NMS_THREADS) {
@@ -378,20 +412,17 @@ __device__ int wz_nms_band(NmsShared* S, const WzPostBuffers& b, const WzPostCon
         if (tid == 0 && base == 0) b.dbg[(size_t)f * 16 + 11] = wall_clock64();
         for (int p = tid; p < m * kept; p += NMS_THREADS) {          // vs boxes kept before this chunk
             const int i = p / kept, j = p - i * kept;
-            if (S->kcls[j] == S->ccls[i] && wz_iou_exceeds(S->cnorm[i], S->carea[i], S->knorm[j], S->karea[j], ithr))
+            if (wz_pair_suppresses(S->cnorm[i], S->cpre[i], S->knorm[j], S->kpre[j], ithr))
                 S->cdead[i] = 1u;                                    // benign race: every writer stores 1
         }
         {   // supp[j][w]: thread = (chunk member j, word w of earlier members 64w .. 64w+63), built in a register
             const int j = tid & (NMS_CHUNK - 1), w = tid >> 8;
             unsigned long long bits = 0ull;
             if (j < m) {
-                const float4_t bj = S->cnorm[j];
-                const float aj = S->carea[j];
-                const int cj = S->ccls[j];
+                const float4_t bj = S->cnorm[j], pj = S->cpre[j];
                 const int i_end = min(w * 64 + 64, j);               // i before j
                 for (int i = w * 64; i < i_end; ++i)                  // i is wave-uniform: LDS broadcasts
-                    if (S->ccls[i] == cj && wz_iou_exceeds(bj, aj, S->cnorm[i], S->carea[i], ithr))
-                        bits |= 1ull << (i & 63);
+                    bits |= wz_pair_suppresses(bj, pj, S->cnorm[i], S->cpre[i], ithr) ? 1ull << (i & 63) : 0ull;
             }
             S->supp[j][w] = bits;
         }
@@ -484,6 +515,7 @@ __device__ int wz_nms_band(NmsShared* S, const WzPostBuffers& b, const WzPostCon
             S->kbox[j] = S->sbox[base + i];
             S->knorm[j] = S->cnorm[i];
             S->karea[j] = S->carea[i];
+            S->kpre[j] = S->cpre[i];
             S->kcls[j] = S->ccls[i];
             S->kscore[j] = __uint_as_float((uint32_t)(comp >> 32));
         }
