@@ -568,7 +568,16 @@ __device__ int wz_nms_band_serial(NmsShared* S, const WzPostBuffers& b, const Wz
     return kept;
 }
 
-__global__ __launch_bounds__(NMS_THREADS) void wz_k_nms(WzPostBuffers b, WzPostConsts k) {
+// row fill + per-camera filters of one detection (defined with wz_k_rows below)
+__device__ void wz_make_row(const WzFrameDesc& fd, const WzCamFilter* __restrict__ cams, bool on, const float4_t bx,
+                            float score, int label, wz_detection_t* __restrict__ row, uint8_t* __restrict__ pass);
+
+// frames != nullptr: the kernel also writes the frame's 100 Detection rows (what wz_k_rows does from the det_* arrays) --
+// one launch less per batch
+__global__ __launch_bounds__(NMS_THREADS) void wz_k_nms(WzPostBuffers b, WzPostConsts k,
+                                                        const WzFrameDesc* __restrict__ frames,
+                                                        const WzCamFilter* __restrict__ cams,
+                                                        wz_detection_t* __restrict__ rows, uint8_t* __restrict__ pass) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     NmsShared* S = reinterpret_cast<NmsShared*>(smem);
     const int f = blockIdx.x, tid = threadIdx.x;
@@ -638,6 +647,12 @@ __global__ __launch_bounds__(NMS_THREADS) void wz_k_nms(WzPostBuffers b, WzPostC
         b.det_classes[(size_t)f * k.max_total + i] = (on ? S->kcls[i] : 0) + 1;
     }
     if (tid == 0) b.det_num[f] = kept;
+    if (frames && tid < WZ_MAX_DETECTIONS) {
+        const bool on = tid < kept;
+        wz_make_row(frames[f], cams, tid < k.max_total, on ? S->kbox[tid] : (float4_t){0.f, 0.f, 0.f, 0.f},
+                    on ? S->kscore[tid] : 0.0f, (on ? S->kcls[tid] : 0) + 1,
+                    rows + (size_t)f * WZ_MAX_DETECTIONS + tid, pass + (size_t)f * WZ_MAX_DETECTIONS + tid);
+    }
     NMS_STAMP(4);
     if (tid == 0) b.dbg[(size_t)f * 16 + 10] = processed;
 }
@@ -692,11 +707,8 @@ __device__ void wz_apply_filter(const WzCamFilter& cf, wz_detection_t& d, uint8_
     if (pass) *pass = ok ? 1 : 0;
 }
 
-__global__ __launch_bounds__(128) void wz_k_rows(WzPostBuffers b, const WzFrameDesc* __restrict__ frames,
-                                                 const WzCamFilter* __restrict__ cams, int max_total,
-                                                 wz_detection_t* __restrict__ rows, uint8_t* __restrict__ pass) {
-    const int f = blockIdx.x, i = threadIdx.x;
-    if (i >= WZ_MAX_DETECTIONS) return;
+__device__ void wz_make_row(const WzFrameDesc& fd, const WzCamFilter* __restrict__ cams, bool on, const float4_t bx,
+                            float score, int label, wz_detection_t* __restrict__ row, uint8_t* __restrict__ pass) {
     wz_detection_t d;
     d.label = 0;
 #pragma unroll
@@ -704,14 +716,12 @@ __global__ __launch_bounds__(128) void wz_k_rows(WzPostBuffers b, const WzFrameD
     d._pad = 0;
     d.confidence = 0.0;
     d.x_min = d.y_min = d.x_max = d.y_max = 0;
-    const WzFrameDesc fd = frames[f];
-    if (i < max_total) {
+    if (on) {
         // tensorflow_cpu.py:79-90: label=int(class), confidence=score (float32 widened to double),
         // int(box * (dim-1)) with the product exact in double, truncation toward zero, no clamp
-        const float4_t bx = *reinterpret_cast<const float4_t*>(b.det_boxes + ((size_t)f * max_total + i) * 4);
         const double mh = (double)(fd.h - 1), mw = (double)(fd.w - 1);
-        d.label = b.det_classes[(size_t)f * max_total + i];
-        d.confidence = (double)b.det_scores[(size_t)f * max_total + i];
+        d.label = label;
+        d.confidence = (double)score;
         d.y_min = (int)((double)bx[0] * mh);
         d.x_min = (int)((double)bx[1] * mw);
         d.y_max = (int)((double)bx[2] * mh);
@@ -719,8 +729,19 @@ __global__ __launch_bounds__(128) void wz_k_rows(WzPostBuffers b, const WzFrameD
     }
     uint8_t p = (d.label > 0) ? 1 : 0;
     if (fd.cam >= 0 && cams[fd.cam].enabled) wz_apply_filter(cams[fd.cam], d, &p);
-    rows[(size_t)f * WZ_MAX_DETECTIONS + i] = d;
-    pass[(size_t)f * WZ_MAX_DETECTIONS + i] = p;
+    *row = d;
+    *pass = p;
+}
+
+__global__ __launch_bounds__(128) void wz_k_rows(WzPostBuffers b, const WzFrameDesc* __restrict__ frames,
+                                                 const WzCamFilter* __restrict__ cams, int max_total,
+                                                 wz_detection_t* __restrict__ rows, uint8_t* __restrict__ pass) {
+    const int f = blockIdx.x, i = threadIdx.x;
+    if (i >= WZ_MAX_DETECTIONS) return;
+    const bool on = i < max_total;
+    const size_t src = (size_t)f * max_total + (on ? i : 0);
+    wz_make_row(frames[f], cams, on, *reinterpret_cast<const float4_t*>(b.det_boxes + src * 4), b.det_scores[src],
+                b.det_classes[src], rows + (size_t)f * WZ_MAX_DETECTIONS + i, pass + (size_t)f * WZ_MAX_DETECTIONS + i);
 }
 
 __global__ __launch_bounds__(128) void wz_k_filter_rows(const WzCamFilter* __restrict__ cams, int cam,
@@ -784,8 +805,9 @@ void wz_post_init() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wz_k_nms), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)sizeof(NmsShared));
 }
-void wz_launch_nms(const WzPostBuffers& b, const WzPostConsts& c, int n, hipStream_t s) {
-    hipLaunchKernelGGL(wz_k_nms, dim3(n), dim3(NMS_THREADS), sizeof(NmsShared), s, b, c);
+void wz_launch_nms(const WzPostBuffers& b, const WzPostConsts& c, int n, hipStream_t s, const WzFrameDesc* d_frames,
+                   const WzCamFilter* d_cams, wz_detection_t* rows, uint8_t* pass) {
+    hipLaunchKernelGGL(wz_k_nms, dim3(n), dim3(NMS_THREADS), sizeof(NmsShared), s, b, c, d_frames, d_cams, rows, pass);
 }
 void wz_launch_rows(const WzPostBuffers& b, const WzFrameDesc* d_frames, const WzCamFilter* d_cams, int n,
                     int max_total, wz_detection_t* rows, uint8_t* pass, hipStream_t s) {

@@ -159,7 +159,9 @@ struct WzPostBuffers {
 void wz_launch_decode(const WzPostBuffers& b, const WzPostConsts& c, int n, hipStream_t s);
 void wz_launch_hist(const WzPostBuffers& b, const WzPostConsts& c, int n, hipStream_t s);
 void wz_launch_compact(const WzPostBuffers& b, const WzPostConsts& c, int n, hipStream_t s);
-void wz_launch_nms(const WzPostBuffers& b, const WzPostConsts& c, int n, hipStream_t s);
+// d_frames != nullptr: the kernel also writes the Detection rows + pass bytes (then no wz_launch_rows is needed)
+void wz_launch_nms(const WzPostBuffers& b, const WzPostConsts& c, int n, hipStream_t s, const WzFrameDesc* d_frames = nullptr,
+                   const WzCamFilter* d_cams = nullptr, wz_detection_t* rows = nullptr, uint8_t* pass = nullptr);
 void wz_launch_rows(const WzPostBuffers& b, const WzFrameDesc* d_frames, const WzCamFilter* d_cams, int n,
                     int max_total, wz_detection_t* rows, uint8_t* pass, hipStream_t s);
 int wz_set_error(int code, const char* fmt, ...);   // sets wz_last_error() of the calling thread, returns code

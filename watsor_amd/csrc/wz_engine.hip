@@ -289,13 +289,14 @@ static void enqueue_post(wz_engine* e, Lane& L, bool rows, int n, StageTimer* t)
     if (t) t->mark();
     wz_launch_compact(L.post, e->pc, n, s);
     if (t) t->mark();
-    wz_launch_nms(L.post, e->pc, n, s);
+    // with `rows` the NMS kernel also fills the Detection rows (straight into the lane's pinned, device-mapped host
+    // block: no D2H copy node, no separate row kernel); the "post/rows" stage slot stays empty
+    if (rows)
+        wz_launch_nms(L.post, e->pc, n, s, L.d_desc, e->d_cams, L.m_rows, L.m_pass);
+    else
+        wz_launch_nms(L.post, e->pc, n, s);
     if (t) t->mark();
-    if (rows) {
-        // the rows go straight into the lane's pinned host block (device-mapped): no D2H copy nodes behind the kernel
-        wz_launch_rows(L.post, L.d_desc, e->d_cams, n, e->pc.max_total, L.m_rows, L.m_pass, s);
-        if (t) t->mark();
-    }
+    if (rows && t) t->mark();
 }
 
 // everything between "descriptors are in h_desc[slot]" and "rows are in h_rows[slot]"
