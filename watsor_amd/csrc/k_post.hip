@@ -234,12 +234,17 @@ __device__ __forceinline__ float4_t wz_pair_pre(float area, int cls, const WzIou
     const bool ok = area > 0.0f;
     return (float4_t){ok ? t.cl * area : inf, ok ? t.ch * area : inf, area, __int_as_float(cls)};
 }
+// max / min of two NON-NEGATIVE floats (no -0.0, see wz_norm_box) as unsigned integers: one instruction each, where
+// `fmaxf` / `fminf` on values that come out of LDS cost an extra canonicalising v_max_f32 per operand
+__device__ __forceinline__ float wz_max_nn(float a, float b) { return __uint_as_float(max(__float_as_uint(a), __float_as_uint(b))); }
+__device__ __forceinline__ float wz_min_nn(float a, float b) { return __uint_as_float(min(__float_as_uint(a), __float_as_uint(b))); }
 __device__ __forceinline__ bool wz_pair_suppresses(const float4_t a, const float4_t pa, const float4_t c,
                                                    const float4_t pc, const WzIouThr t) {
-    // straight-line except for the rare near-threshold case: divergent branches cost more here than the arithmetic
+    // straight-line except for the rare near-threshold case: the pair loop is issue-bound (one CU, ~30 instructions
+    // per pair), so every instruction and every divergent branch counts
     const bool same = __float_as_int(pa[3]) == __float_as_int(pc[3]);
-    const float iy0 = fmaxf(a[0], c[0]), ix0 = fmaxf(a[1], c[1]);
-    const float iy1 = fminf(a[2], c[2]), ix1 = fminf(a[3], c[3]);
+    const float iy0 = wz_max_nn(a[0], c[0]), ix0 = wz_max_nn(a[1], c[1]);
+    const float iy1 = wz_min_nn(a[2], c[2]), ix1 = wz_min_nn(a[3], c[3]);
     const float inter = fmaxf(iy1 - iy0, 0.0f) * fmaxf(ix1 - ix0, 0.0f);
     const bool above_lo = inter > pa[0] + pc[0], above_hi = inter > pa[1] + pc[1];
     bool r = same & above_hi;
@@ -251,7 +256,9 @@ __device__ __forceinline__ bool wz_pair_suppresses(const float4_t a, const float
     return r;
 }
 __device__ __forceinline__ float4_t wz_norm_box(const float4_t b, float& area) {
-    const float4_t n = {fminf(b[0], b[2]), fminf(b[1], b[3]), fmaxf(b[0], b[2]), fmaxf(b[1], b[3])};
+    // + 0.0f turns a -0.0 into +0.0 (the boxes are clipped to [0, 1]): the pair test compares the components as
+    // unsigned integers.  Same values, same area.
+    const float4_t n = {fminf(b[0], b[2]) + 0.0f, fminf(b[1], b[3]) + 0.0f, fmaxf(b[0], b[2]) + 0.0f, fmaxf(b[1], b[3]) + 0.0f};
     area = (n[2] - n[0]) * (n[3] - n[1]);
     return n;
 }
@@ -415,16 +422,34 @@ __device__ int wz_nms_band(NmsShared* S, const WzPostBuffers& b, const WzPostCon
             if (wz_pair_suppresses(S->cnorm[i], S->cpre[i], S->knorm[j], S->kpre[j], ithr))
                 S->cdead[i] = 1u;                                    // benign race: every writer stores 1
         }
-        {   // supp[j][w]: thread = (chunk member j, word w of earlier members 64w .. 64w+63), built in a register
-            const int j = tid & (NMS_CHUNK - 1), w = tid >> 8;
-            unsigned long long bits = 0ull;
+        {   // supp[j][w]: bit i of word w = "member 64w + i (before j) suppresses j", built in registers.
+            // The (64 members j) x (64 members i) blocks below the diagonal cost 64 pair tests per lane, the diagonal
+            // ones half of that, the ones above nothing: 8 units of work in all.  The loop is VALU-bound and a wave
+            // stays on SIMD (wave & 3), so blocks are dealt out by hand, 2 units per SIMD: each full block as two
+            // 32-member halves on two waves of one SIMD, the four diagonal blocks on the fourth SIMD.
+            //                                   wave:  0   1   2   3   4   5   6   7   8   9  10  11  12  13  14  15
+            constexpr unsigned char TASK_JB[16] = {1,  2,  3,  0,  1,  2,  3,  1,  2,  3,  3,  2,  2,  3,  3,  3};
+            constexpr unsigned char TASK_W[16]  = {0,  1,  1,  0,  0,  1,  1,  1,  0,  0,  2,  2,  0,  0,  2,  3};
+            constexpr unsigned char TASK_H[16]  = {0,  0,  0,  2,  1,  1,  1,  2,  0,  0,  0,  2,  1,  1,  1,  2};   // 2 = whole word
+            const int wv = tid >> 6;
+            const int j = TASK_JB[wv] * 64 + (tid & 63), w = TASK_W[wv], half = TASK_H[wv];
+            uint32_t* const word = reinterpret_cast<uint32_t*>(&S->supp[j][w]);
+            float4_t bj = {0.f, 0.f, 0.f, 0.f}, pj = {0.f, 0.f, 0.f, 0.f};
             if (j < m) {
-                const float4_t bj = S->cnorm[j], pj = S->cpre[j];
-                const int i_end = min(w * 64 + 64, j);               // i before j
-                for (int i = w * 64; i < i_end; ++i)                  // i is wave-uniform: LDS broadcasts
-                    bits |= wz_pair_suppresses(bj, pj, S->cnorm[i], S->cpre[i], ithr) ? 1ull << (i & 63) : 0ull;
+                bj = S->cnorm[j];
+                pj = S->cpre[j];
             }
-            S->supp[j][w] = bits;
+            for (int h = (half == 2 ? 0 : half); h <= (half == 2 ? 1 : half); ++h) {   // 32 earlier members at a time
+                const int i0 = w * 64 + h * 32;
+                const int i_end = j < m ? min(i0 + 32, j) : i0;      // i before j
+                uint32_t bits = 0u;
+                for (int i = i0; i < i_end; ++i)                      // i is wave-uniform: LDS broadcasts
+                    bits |= wz_pair_suppresses(bj, pj, S->cnorm[i], S->cpre[i], ithr) ? 1u << (i - i0) : 0u;
+                word[h] = bits;
+            }
+        }
+        if (tid < NMS_CHUNK) {   // words above the diagonal (members behind j) are empty
+            for (int w = (tid >> 6) + 1; w < NMS_CHUNK / 64; ++w) S->supp[tid][w] = 0ull;
         }
         if (count_classes) {   // per-class chains in band order (only needed when the per-class cap can bind)
             for (int j = tid; j < kept; j += NMS_THREADS) atomicAdd(&ccount[S->kcls[j]], 1);
