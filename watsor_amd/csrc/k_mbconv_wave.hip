@@ -24,7 +24,7 @@
 // K = 27 padded to 32): the B fragment of a halo pixel is the im2col of its 3x3x3 window, gathered straight from
 // the normalised 300x300x4 input -- the 150x150x32 stem output never exists in HBM.
 template <int MPW, int MQW, int KCI, int NTO, int NKK, bool STEM>
-__global__ __launch_bounds__(256) void wz_k_mbconv_wave(const WzMbArgs a) {
+__global__ __launch_bounds__(256, 4) void wz_k_mbconv_wave(const WzMbArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wz_mbw_smem[];
     constexpr int CE = 32 * NKK, ES = CE + 8;   // NKK 32-channel K chunks of the project conv per pass
     constexpr int EBYTES = MPW * 16 * ES * 2;
