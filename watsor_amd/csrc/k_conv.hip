@@ -219,12 +219,12 @@ __device__ __forceinline__ void wz_conv_mfma(const ConvFrags<MT, NT, U>& f, floa
 }
 
 template <int KS, int MT, int NT, int U>
-__global__ __launch_bounds__(256) void wz_k_conv(const WzConvArgs a) {
+__device__ __forceinline__ void wz_conv_body(const WzConvArgs& a, int bx, int by, int bz) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
-    const int m_base = (blockIdx.x * 4 + wave) * (MT * 16);
-    const int nt0 = blockIdx.y * NT;
+    const int m_base = (bx * 4 + wave) * (MT * 16);
+    const int nt0 = by * NT;
     if (m_base >= a.M) return;   // whole wave out of range (no barriers in this kernel)
 
     const int hw = a.hout * a.wout;
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void wz_k_conv(const WzConvArgs a) {
 
     // K range of this split (flattened chunk index q = tap * kc + c)
     const int per = (a.kchunks + a.splitk - 1) / a.splitk;
-    const int q0 = blockIdx.z * per;
+    const int q0 = bz * per;
     const int q1 = min(q0 + per, a.kchunks);
     const half_t* wlane = a.w + (size_t)lane * 8;
     const int cg8 = g * 8;
@@ -279,12 +279,27 @@ __global__ __launch_bounds__(256) void wz_k_conv(const WzConvArgs a) {
             if (a.splitk > 1) {
                 if (m < a.M)
                     *reinterpret_cast<float4_t*>(reinterpret_cast<float*>(a.out) +
-                                                 ((size_t)blockIdx.z * a.M + m) * a.n_pad + n4) = acc[mt][nt];
+                                                 ((size_t)bz * a.M + m) * a.n_pad + n4) = acc[mt][nt];
             } else {
                 wz_epilogue4(a, m, n4, acc[mt][nt]);
             }
         }
     }
+}
+
+template <int KS, int MT, int NT, int U>
+__global__ __launch_bounds__(256) void wz_k_conv(const WzConvArgs a) {
+    wz_conv_body<KS, MT, NT, U>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Several small 3x3 convolutions that do not depend on each other (the SSD heads on the 3x3 ... 1x1 maps) in one launch:
+// a workgroup finds its entry from the prefix table and runs wz_k_conv's body on it.
+__global__ __launch_bounds__(256) void wz_k_conv_group(const WzConvGroup g) {
+    int e = 0;
+    while (e + 1 < g.n && (int)blockIdx.x >= g.first[e + 1]) ++e;   // wave-uniform
+    const int L = (int)blockIdx.x - g.first[e];
+    const int gx = g.gx[e], gy = g.gy[e];
+    wz_conv_body<3, 2, 2, 4>(g.a[e], L % gx, (L / gx) % gy, L / (gx * gy));
 }
 
 __global__ __launch_bounds__(256) void wz_k_splitk_reduce(const WzConvArgs a, const float* __restrict__ ws) {
@@ -675,6 +690,22 @@ void wz_launch_conv(const WzConvArgs& a0, hipStream_t s) {
         wz_launch_conv_cfg<4, 4, 2>(a, s);
     else
         wz_launch_conv_cfg<2, 2, 4>(a, s);
+}
+
+// the 3x3 convolutions wz_launch_conv would give to wz_k_conv<3, 2, 2, 4>
+bool wz_conv_groupable(const WzConvArgs& a) {
+    return a.ksize == 3 && !wz_conv_use_lds(a) && !wz_conv_big(a.M, a.n_pad, a.kchunks);
+}
+void wz_conv_group_add(WzConvGroup& g, const WzConvArgs& a) {
+    const int i = g.n++;
+    const int mtiles = (a.M + 31) / 32;
+    g.a[i] = a;
+    g.gx[i] = (mtiles + 3) / 4;
+    g.gy[i] = a.n_pad / 32;
+    g.first[i + 1] = g.first[i] + g.gx[i] * g.gy[i] * a.splitk;
+}
+void wz_launch_conv_group(const WzConvGroup& g, hipStream_t s) {
+    hipLaunchKernelGGL(wz_k_conv_group, dim3(g.first[g.n]), dim3(256), 0, s, g);
 }
 
 void wz_reduce_group_add(WzReduceGroup& g, const WzConvArgs& a, const float* ws) {

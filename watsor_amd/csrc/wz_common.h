@@ -119,6 +119,17 @@ struct WzReduceGroup {
     const float* ws[WZ_REDUCE_GROUP_MAX];
 };
 void wz_reduce_group_add(WzReduceGroup& g, const WzConvArgs& a, const float* ws);
+// several independent small 3x3 convolutions (wz_k_conv<3, 2, 2, 4> shapes) in ONE launch
+#define WZ_CONV_GROUP_MAX 4
+struct WzConvGroup {
+    int32_t n;
+    int32_t first[WZ_CONV_GROUP_MAX + 1];
+    int32_t gx[WZ_CONV_GROUP_MAX], gy[WZ_CONV_GROUP_MAX];
+    WzConvArgs a[WZ_CONV_GROUP_MAX];
+};
+bool wz_conv_groupable(const WzConvArgs& a);
+void wz_conv_group_add(WzConvGroup& g, const WzConvArgs& a);
+void wz_launch_conv_group(const WzConvGroup& g, hipStream_t s);
 void wz_launch_splitk_reduce_group(const WzReduceGroup& g, hipStream_t s);
 int wz_choose_splitk(int M, int n_pad, int kchunks);
 bool wz_conv_use_lds(const WzConvArgs& a);               // the LDS-tiled kernel will serve this conv

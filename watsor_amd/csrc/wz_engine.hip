@@ -164,6 +164,10 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t) {
     WzReduceGroup heads;
     heads.n = 0;
     heads.first[0] = 0;
+    // ... and the small heads themselves (3x3 ... 1x1 maps: a handful of workgroups each) share one launch as well
+    WzConvGroup small;
+    small.n = 0;
+    small.first[0] = 0;
     for (uint32_t i = 0; i < e->hdr.n_ops; ++i) {
         const WzOpDesc& op = e->ops[i];
         const uint8_t* wbase = e->d_weights;
@@ -255,7 +259,10 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t) {
                 float* const park = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(L.d_ws) + ws_top);
                 a.splitk = sk;
                 a.out = park;
-                wz_launch_conv(a, s);
+                if (small.n < WZ_CONV_GROUP_MAX && wz_conv_groupable(a))
+                    wz_conv_group_add(small, a);   // launched with the other small heads after the last op
+                else
+                    wz_launch_conv(a, s);
                 if (t) { t->mark(); t->mark(); }   // its own reduce slot stays empty
                 a.out = final_out;
                 wz_reduce_group_add(heads, a, park);
@@ -277,6 +284,8 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t) {
         }
         if (t) t->mark();
     }
+    if (small.n > 0) wz_launch_conv_group(small, s);
+    if (t) t->mark();
     if (heads.n > 0) wz_launch_splitk_reduce_group(heads, s);
     if (t) t->mark();
 }
@@ -577,6 +586,7 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
         if (e->ops[i].kind == WZ_OP_CONV || e->ops[i].kind == WZ_OP_MBCONV)
             e->stage_names.push_back(std::string(e->ops[i].name) + "#splitk_reduce");
     }
+    e->stage_names.push_back("heads#small_convs");
     e->stage_names.push_back("heads#splitk_reduce");
     e->stage_names.push_back("post/decode");
     e->stage_names.push_back("post/hist");
