@@ -100,7 +100,7 @@ def roofline_from_stages(stages, ops, n, frame_bytes, size):
             k, fl, by = "wz_k_splitk_reduce", 0.0, 0.0
             if ms < 5e-4:
                 continue
-        elif name == "heads#small_convs":                  # the small SSD heads' shared launch: their flops / bytes are
+        elif name in ("heads#small_convs", "heads#big_convs"):   # the SSD heads' shared launches: their flops / bytes are
             k, fl, by = "wz_k_conv<3>", 0.0, 0.0            # counted in their own (empty) op slots below
             if ms < 5e-4:
                 continue

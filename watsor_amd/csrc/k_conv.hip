@@ -556,7 +556,22 @@ struct WzEpiF16 {
 template <int KS, int NW, bool SPEC>
 __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void wz_k_conv_rs(const WzConvArgs a) {   // <= 256 registers: two waves per SIMD
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 16384];
-    wz_conv_rs_body<KS, NW, SPEC, false, WzEpiF16>(a, smem);
+    wz_conv_rs_body<KS, NW, SPEC, false, WzEpiF16>(a, smem, blockIdx.x);
+}
+
+// The SSD heads served by the register-staged tile kernel (the two big ones with 128 x 128 tiles, the 5x5 one with
+// 128 x 64) in one launch: the workgroups of the later entries fill the CUs the first one's last round leaves idle, two
+// workgroups share a CU and cover each other's stalls, and the kernel boundaries between them go away
+// (measured for the two big heads: 32 us together against 23 + 26 us apart).
+__global__ __launch_bounds__(256, 2) void wz_k_conv_rs_group(const WzConvGroup g) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 16384];
+    int e = 0;
+    while (e + 1 < g.n && (int)blockIdx.x >= g.first[e + 1]) ++e;   // wave-uniform
+    const int L = (int)blockIdx.x - g.first[e];
+    if (g.gx[e] == 4)   // channel tiles per wave pair of this entry (wave-uniform)
+        wz_conv_rs_body<3, 4, false, false, WzEpiF16>(g.a[e], smem, L);
+    else
+        wz_conv_rs_body<3, 2, false, false, WzEpiF16>(g.a[e], smem, L);
 }
 
 static int wz_env_int(const char* name, int dflt) {
@@ -706,6 +721,27 @@ void wz_conv_group_add(WzConvGroup& g, const WzConvArgs& a) {
 }
 void wz_launch_conv_group(const WzConvGroup& g, hipStream_t s) {
     hipLaunchKernelGGL(wz_k_conv_group, dim3(g.first[g.n]), dim3(256), 0, s, g);
+}
+
+// the convolutions wz_launch_conv would give to wz_k_conv_rs<3, 4>
+bool wz_conv_rs_groupable(const WzConvArgs& a) {
+    static const int rs = wz_env_int("WZ_LDS_RS", 1);
+    return rs && !wz_lds_spec() && a.ksize == 3 && wz_conv_use_lds(a);
+}
+void wz_conv_rs_group_add(WzConvGroup& g, const WzConvArgs& a0) {
+    const int i = g.n++;
+    WzConvArgs& a = g.a[i];
+    a = a0;
+    const int nw = wz_lds_nw(a.M, a.n_pad, a.kchunks);
+    a.grid_m = (a.M + WZ_LDS_TM - 1) / WZ_LDS_TM;
+    a.grid_n = (a.n_pad + WZ_LDS_TN(nw) - 1) / WZ_LDS_TN(nw);
+    a.order = 0;
+    g.gx[i] = nw;
+    g.gy[i] = 0;
+    g.first[i + 1] = g.first[i] + ((a.grid_m * a.grid_n * a.splitk + 7) & ~7);   // entries start on an XCD boundary
+}
+void wz_launch_conv_rs_group(const WzConvGroup& g, hipStream_t s) {
+    hipLaunchKernelGGL(wz_k_conv_rs_group, dim3(g.first[g.n]), dim3(256), 0, s, g);
 }
 
 void wz_reduce_group_add(WzReduceGroup& g, const WzConvArgs& a, const float* ws) {

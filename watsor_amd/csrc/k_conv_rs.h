@@ -30,8 +30,10 @@ typedef __attribute__((ext_vector_type(4))) unsigned int uint4_t;
 // SPEC: eight waves; 0..3 only compute (and fetch their own weight fragments), 4..7 only move the activation tile
 // (global -> VGPR -> LDS).  A wave issues in order, so with four waves the ~1 000 cycles of loads, waits and LDS writes
 // of a step sit in front of its ~750 cycles of fragment reads and MFMAs; split over two waves per SIMD they overlap.
+// L = index of this workgroup within the convolution's own grid (blockIdx.x, or blockIdx.x minus the entry's first
+// workgroup in a grouped launch, where entries start at multiples of 8 so that L & 7 is still the XCD).
 template <int KS, int NW, bool SPEC, bool F32, class EPI>
-__device__ __forceinline__ void wz_conv_rs_body(const WzConvArgs& a, unsigned char* smem) {
+__device__ __forceinline__ void wz_conv_rs_body(const WzConvArgs& a, unsigned char* smem, const int L) {
     constexpr int EB = F32 ? 4 : 2;   // bytes per element
     constexpr int taps = KS * KS;
     constexpr int NTW = NW / 2;   // 16-channel tiles per wave
@@ -45,7 +47,8 @@ __device__ __forceinline__ void wz_conv_rs_body(const WzConvArgs& a, unsigned ch
     int bx, by, bz;
     {   // XCD-aware tile order, as in wz_k_conv_lds
         const int total = a.grid_m * a.grid_n * a.splitk;
-        const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+        if (L >= total) return;   // padding workgroup of a grouped launch
+        const int xcd = L & 7, slot = L >> 3;
         const int qd = total >> 3, rm = total & 7;
         int V = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + slot;
         if (a.order == 1) V = L;
@@ -184,7 +187,7 @@ __device__ __forceinline__ void wz_conv_rs_body(const WzConvArgs& a, unsigned ch
         __syncthreads();
         int s = s0;
         // phase cycle counts for tools/rs_probe.py: compiled in only with -DWZ_RS_STAMPS=1 (they cost registers)
-        const bool stamp = WZ_RS_STAMPS && a.dbg && (threadIdx.x & 255) == 0 && blockIdx.x == 0;
+        const bool stamp = WZ_RS_STAMPS && a.dbg && (threadIdx.x & 255) == 0 && L == 0;
         long long cy[5] = {0, 0, 0, 0, 0};
         for (int p = 0; p < pairs; ++p, s += 2) {
             const long long c0 = stamp ? clock64() : 0;

@@ -287,7 +287,7 @@ struct WzEpiF32 {
 template <int KS, int NW>
 __global__ __launch_bounds__(256, 2) void wz_k_conv_rs_f32(const WzConvArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 16384];
-    wz_conv_rs_body<KS, NW, false, true, WzEpiF32>(a, smem);
+    wz_conv_rs_body<KS, NW, false, true, WzEpiF32>(a, smem, blockIdx.x);
 }
 
 // whole 64-column tiles, whole 32-channel K steps, enough pixels and a K loop long enough to pay for the tile

@@ -130,6 +130,10 @@ struct WzConvGroup {
 bool wz_conv_groupable(const WzConvArgs& a);
 void wz_conv_group_add(WzConvGroup& g, const WzConvArgs& a);
 void wz_launch_conv_group(const WzConvGroup& g, hipStream_t s);
+// ... and the convolutions of the register-staged 128 x 128 tile kernel (the two big heads)
+bool wz_conv_rs_groupable(const WzConvArgs& a);
+void wz_conv_rs_group_add(WzConvGroup& g, const WzConvArgs& a);
+void wz_launch_conv_rs_group(const WzConvGroup& g, hipStream_t s);
 void wz_launch_splitk_reduce_group(const WzReduceGroup& g, hipStream_t s);
 int wz_choose_splitk(int M, int n_pad, int kchunks);
 bool wz_conv_use_lds(const WzConvArgs& a);               // the LDS-tiled kernel will serve this conv

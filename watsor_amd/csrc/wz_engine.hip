@@ -165,9 +165,9 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t) {
     heads.n = 0;
     heads.first[0] = 0;
     // ... and the small heads themselves (3x3 ... 1x1 maps: a handful of workgroups each) share one launch as well
-    WzConvGroup small;
-    small.n = 0;
-    small.first[0] = 0;
+    WzConvGroup small, big;
+    small.n = big.n = 0;
+    small.first[0] = big.first[0] = 0;
     for (uint32_t i = 0; i < e->hdr.n_ops; ++i) {
         const WzOpDesc& op = e->ops[i];
         const uint8_t* wbase = e->d_weights;
@@ -261,6 +261,8 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t) {
                 a.out = park;
                 if (small.n < WZ_CONV_GROUP_MAX && wz_conv_groupable(a))
                     wz_conv_group_add(small, a);   // launched with the other small heads after the last op
+                else if (big.n < WZ_CONV_GROUP_MAX && wz_conv_rs_groupable(a))
+                    wz_conv_rs_group_add(big, a);  // the heads on the tile kernel: one launch, too
                 else
                     wz_launch_conv(a, s);
                 if (t) { t->mark(); t->mark(); }   // its own reduce slot stays empty
@@ -284,6 +286,8 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t) {
         }
         if (t) t->mark();
     }
+    if (big.n > 0) wz_launch_conv_rs_group(big, s);
+    if (t) t->mark();
     if (small.n > 0) wz_launch_conv_group(small, s);
     if (t) t->mark();
     if (heads.n > 0) wz_launch_splitk_reduce_group(heads, s);
@@ -586,6 +590,7 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
         if (e->ops[i].kind == WZ_OP_CONV || e->ops[i].kind == WZ_OP_MBCONV)
             e->stage_names.push_back(std::string(e->ops[i].name) + "#splitk_reduce");
     }
+    e->stage_names.push_back("heads#big_convs");
     e->stage_names.push_back("heads#small_convs");
     e->stage_names.push_back("heads#splitk_reduce");
     e->stage_names.push_back("post/decode");
