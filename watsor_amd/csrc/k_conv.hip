@@ -292,6 +292,75 @@ __global__ __launch_bounds__(256) void wz_k_conv(const WzConvArgs a) {
     wz_conv_body<KS, MT, NT, U>(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
+// Split-K inside the workgroup, for the convolutions of the SSD extras chain (10x10 ... 1x1 maps, K up to 2 304, each
+// feeding the next one): the 8 waves of a workgroup share ONE 32-pixel x 32-channel tile and each walks an eighth of
+// the K chunks; the eight accumulator sets meet in LDS and are summed in wave order (deterministic).  No partial sums
+// in HBM and no reduce launch behind the convolution -- on this chain a kernel boundary costs as much as the kernel.
+template <int KS>
+__global__ __launch_bounds__(512) void wz_k_conv_ws(const WzConvArgs a) {
+    constexpr int MT = 2, NT = 2, U = 4, WAVES = 8;
+    __shared__ float4_t red[WAVES][MT * NT][64];   // 32 KiB
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    const int m_base = blockIdx.x * (MT * 16);
+    const int nt0 = blockIdx.y * NT;
+
+    const int hw = a.hout * a.wout;
+    int iy0[MT], ix0[MT], boff[MT];
+    bool mv[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = m_base + mt * 16 + r16;
+        mv[mt] = m < a.M;
+        const int mm = mv[mt] ? m : 0;
+        const int b = mm / hw, rem = mm - b * hw;
+        const int oy = rem / a.wout, ox = rem - oy * a.wout;
+        iy0[mt] = oy * a.stride - a.pad_t;
+        ix0[mt] = ox * a.stride - a.pad_l;
+        boff[mt] = b * a.hin;
+    }
+    float4_t acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int per = (a.kchunks + WAVES - 1) / WAVES;
+    const int q0 = wave * per, q1 = min(q0 + per, a.kchunks);
+    if (q0 < q1) {
+        const half_t* wlane = a.w + (size_t)lane * 8;
+        const int cg8 = g * 8;
+        int ql = q0, t = (KS == 1) ? 0 : q0 / a.kc, c = (KS == 1) ? q0 : q0 - t * a.kc;
+        ConvFrags<MT, NT, U> fa, fb;
+        wz_conv_load<KS, MT, NT, U>(a, fa, ql, q1, t, c, iy0, ix0, boff, mv, wlane, nt0, cg8);
+        for (int q = q0; q < q1;) {
+            wz_conv_load<KS, MT, NT, U>(a, fb, ql, q1, t, c, iy0, ix0, boff, mv, wlane, nt0, cg8);
+            wz_conv_mfma(fa, acc);
+            q += U;
+            if (q >= q1) break;
+            wz_conv_load<KS, MT, NT, U>(a, fa, ql, q1, t, c, iy0, ix0, boff, mv, wlane, nt0, cg8);
+            wz_conv_mfma(fb, acc);
+            q += U;
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) red[wave][mt * NT + nt][lane] = acc[mt][nt];
+    __syncthreads();
+    if (wave < MT * NT) {   // wave w finishes tile w: sum over the eight K slices in wave order, then the epilogue
+        float4_t v = red[0][wave][lane];
+#pragma unroll
+        for (int z = 1; z < WAVES; ++z) {
+            const float4_t p = red[z][wave][lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += p[r];
+        }
+        wz_epilogue4(a, m_base + (wave / NT) * 16 + r16, (nt0 + wave % NT) * 16 + g * 4, v);
+    }
+}
+
 // Several small 3x3 convolutions that do not depend on each other (the SSD heads on the 3x3 ... 1x1 maps) in one launch:
 // a workgroup finds its entry from the prefix table and runs wz_k_conv's body on it.
 __global__ __launch_bounds__(256) void wz_k_conv_group(const WzConvGroup g) {
@@ -705,6 +774,19 @@ void wz_launch_conv(const WzConvArgs& a0, hipStream_t s) {
         wz_launch_conv_cfg<4, 4, 2>(a, s);
     else
         wz_launch_conv_cfg<2, 2, 4>(a, s);
+}
+
+// small maps, a K loop long enough for eight slices, whole 32-channel tiles
+bool wz_conv_ws_applies(const WzConvArgs& a) {
+    static const int on = wz_env_int("WZ_CONV_WS", 1);
+    return on && a.out_mode == WZ_OUT_ACT && a.M <= 1024 && a.kchunks >= 8 && a.n_pad % 32 == 0;
+}
+void wz_launch_conv_ws(const WzConvArgs& a, hipStream_t s) {
+    const dim3 grid((a.M + 31) / 32, a.n_pad / 32);
+    if (a.ksize == 1)
+        hipLaunchKernelGGL(wz_k_conv_ws<1>, grid, dim3(512), 0, s, a);
+    else
+        hipLaunchKernelGGL(wz_k_conv_ws<3>, grid, dim3(512), 0, s, a);
 }
 
 // the 3x3 convolutions wz_launch_conv would give to wz_k_conv<3, 2, 2, 4>

@@ -127,6 +127,9 @@ struct WzConvGroup {
     int32_t gx[WZ_CONV_GROUP_MAX], gy[WZ_CONV_GROUP_MAX];
     WzConvArgs a[WZ_CONV_GROUP_MAX];
 };
+// split-K across the waves of a workgroup (no partials in HBM, no reduce launch): the extras chain
+bool wz_conv_ws_applies(const WzConvArgs& a);
+void wz_launch_conv_ws(const WzConvArgs& a, hipStream_t s);
 bool wz_conv_groupable(const WzConvArgs& a);
 void wz_conv_group_add(WzConvGroup& g, const WzConvArgs& a);
 void wz_launch_conv_group(const WzConvGroup& g, hipStream_t s);

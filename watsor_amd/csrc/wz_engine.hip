@@ -270,6 +270,13 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t) {
                 wz_reduce_group_add(heads, a, park);
                 continue;
             }
+            if (sk > 1 && wz_conv_ws_applies(a)) {   // the K split happens inside the workgroups: nothing to reduce
+                a.splitk = 1;
+                a.out = final_out;
+                wz_launch_conv_ws(a, s);
+                if (t) { t->mark(); t->mark(); }
+                continue;
+            }
             while (sk > 1 && (size_t)sk * a.M * a.n_pad * 4 > ws_top) --sk;
             a.splitk = sk;
             if (sk > 1) {
