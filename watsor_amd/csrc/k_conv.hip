@@ -387,7 +387,34 @@ __global__ __launch_bounds__(256) void wz_k_splitk_reduce(const WzConvArgs a, co
 
 // The reductions of several convolutions in one launch: a workgroup finds its entry from the prefix table, then does
 // exactly what wz_k_splitk_reduce does (same order over the splits: bit-identical results).
+// box decode + clip of one anchor from its finished encoding (ty, tx, th, tw): the arithmetic of wz_k_decode
+// (k_post.hip, which is compiled without contraction -- hence the pragma), operation for operation
+__device__ __forceinline__ void wz_decode_anchor(const float4_t e, const float4_t an, const WzPostConsts& k,
+                                                 float* __restrict__ box_out, uint8_t* __restrict__ valid_out) {
+#pragma clang fp contract(off)
+    const float ty = e[0] / k.scale_y, tx = e[1] / k.scale_x, th = e[2] / k.scale_h, tw = e[3] / k.scale_w;
+    const float w = expf(tw) * an[3];
+    const float h = expf(th) * an[2];
+    const float yc = ty * an[2] + an[0];
+    const float xc = tx * an[3] + an[1];
+    const float hh = h / 2.0f, hw = w / 2.0f;
+    float ymin = yc - hh, xmin = xc - hw, ymax = yc + hh, xmax = xc + hw;
+    ymin = fminf(fmaxf(ymin, 0.0f), 1.0f);
+    xmin = fminf(fmaxf(xmin, 0.0f), 1.0f);
+    ymax = fminf(fmaxf(ymax, 0.0f), 1.0f);
+    xmax = fminf(fmaxf(xmax, 0.0f), 1.0f);
+    const float area = (ymax - ymin) * (xmax - xmin);
+    *reinterpret_cast<float4_t*>(box_out) = (float4_t){ymin, xmin, ymax, xmax};
+    *valid_out = area > 0.0f ? 1 : 0;
+}
+
 __global__ __launch_bounds__(256) void wz_k_splitk_reduce_group(const WzReduceGroup g) {
+    if (g.decode) {   // first kernel of the post-processing chain in this mode: clear its per-frame scratch
+        const int i = blockIdx.x * 256 + threadIdx.x;
+        if (i < g.n_frames * WZ_HIST_BINS) g.hist[i] = 0u;
+        if (i < g.n_frames) g.count[i] = 0u;
+        if (i < 2 * g.n_frames) g.band[i] = 0u;
+    }
     int e = 0;
     while (e + 1 < g.n && (int)blockIdx.x >= g.first[e + 1]) ++e;   // wave-uniform
     const WzConvArgs& a = g.a[e];
@@ -403,6 +430,19 @@ __global__ __launch_bounds__(256) void wz_k_splitk_reduce_group(const WzReduceGr
         for (int r = 0; r < 4; ++r) v[r] += p[r];
     }
     wz_epilogue4(a, m, n4, v);
+    const int n_box = a.out_mode == WZ_OUT_HEAD ? a.n_box : (a.out_mode == WZ_OUT_BOX ? a.cout : 0);
+    if (g.decode && n4 < n_box) {   // columns n4 .. n4+3 = the encoding of anchor (pixel, n4 / 4)
+        const float4_t bv = *reinterpret_cast<const float4_t*>(a.bias + n4);
+        float4_t enc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) enc[r] = v[r] + bv[r];   // what the epilogue stored
+        const int hw = a.hout * a.wout;
+        const int b = m / hw, pix = m - b * hw;
+        const int anchor = (int)(a.out_off >> 2) + pix * (n_box >> 2) + (n4 >> 2);
+        const size_t i = (size_t)b * g.pc.num_anchors + anchor;
+        wz_decode_anchor(enc, *reinterpret_cast<const float4_t*>(g.anchors + (size_t)anchor * 4), g.pc, g.boxes + i * 4,
+                         g.valid + i);
+    }
 }
 
 // --------------------------------------------------------------------------------------------

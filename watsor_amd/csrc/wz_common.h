@@ -117,6 +117,14 @@ struct WzReduceGroup {
     int32_t first[WZ_REDUCE_GROUP_MAX + 1];   // first workgroup of entry i; first[n] = grid size
     WzConvArgs a[WZ_REDUCE_GROUP_MAX];
     const float* ws[WZ_REDUCE_GROUP_MAX];
+    // decode != 0: the thread that finishes the four box-encoding columns of an anchor also decodes + clips the box
+    // (exactly wz_k_decode's arithmetic) and the launch clears hist / count / band -- wz_k_decode is then not launched
+    int32_t decode, n_frames;
+    WzPostConsts pc;
+    const float* anchors;
+    float* boxes;
+    uint8_t* valid;
+    uint32_t *hist, *count, *band;
 };
 void wz_reduce_group_add(WzReduceGroup& g, const WzConvArgs& a, const float* ws);
 // several independent small 3x3 convolutions (wz_k_conv<3, 2, 2, 4> shapes) in ONE launch

@@ -71,6 +71,7 @@ struct wz_engine {
     const WzOpDesc* ops = nullptr;
     int max_batch = 0, max_w = 0, max_h = 0;
     bool no_reuse = false, use_graph = true, use_splitk = true;
+    bool fuse_decode = true;   // WZ_FUSE_DECODE=0: keep wz_k_decode as its own launch
     bool defer_heads = true;   // the SSD heads' split-K reductions run as one launch after the last head (WZ_DEFER_HEADS=0: one each)
 
     uint8_t* d_weights = nullptr;
@@ -94,6 +95,7 @@ struct wz_engine {
         float* d_box_enc = nullptr;
         float* d_logits = nullptr;
         float* d_ws = nullptr;
+        bool decode_fused = false;           // set by enqueue_network: the grouped head reduce decoded the boxes
         uint8_t* d_frames = nullptr;         // staging for host frames of this lane [max_batch][frame_stride] (lazy)
         WzPostBuffers post;
         void* d_post_scratch = nullptr;      // hist + count (memset per batch)
@@ -164,6 +166,8 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t) {
     WzReduceGroup heads;
     heads.n = 0;
     heads.first[0] = 0;
+    heads.decode = 0;
+    int box_ops = 0, box_ops_grouped = 0;   // ops that produce box encodings / how many of them went into `heads`
     // ... and the small heads themselves (3x3 ... 1x1 maps: a handful of workgroups each) share one launch as well
     WzConvGroup small, big;
     small.n = big.n = 0;
@@ -252,6 +256,8 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t) {
             int sk = 1;
             if (e->use_splitk)
                 sk = wz_conv_use_lds(a) ? wz_choose_splitk_lds(a.M, a.n_pad, a.kchunks) : wz_choose_splitk(a.M, a.n_pad, a.kchunks);
+            const bool makes_boxes = op.out_mode == WZ_OUT_HEAD || op.out_mode == WZ_OUT_BOX;
+            if (makes_boxes) ++box_ops;
             const size_t slab = (((size_t)sk * a.M * a.n_pad * 4) + 255) & ~(size_t)255;
             if (sk > 1 && e->defer_heads && op.out_mode != WZ_OUT_ACT && heads.n < WZ_REDUCE_GROUP_MAX &&
                 slab + (WZ_WS_BYTES >> 1) <= ws_top) {   // keep at least half of the workspace for the other ops
@@ -268,6 +274,7 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t) {
                 if (t) { t->mark(); t->mark(); }   // its own reduce slot stays empty
                 a.out = final_out;
                 wz_reduce_group_add(heads, a, park);
+                if (makes_boxes) ++box_ops_grouped;
                 continue;
             }
             if (sk > 1 && wz_conv_ws_applies(a)) {   // the K split happens inside the workgroups: nothing to reduce
@@ -297,13 +304,26 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t) {
     if (t) t->mark();
     if (small.n > 0) wz_launch_conv_group(small, s);
     if (t) t->mark();
+    // every box encoding is finished by the grouped reduce: let it decode the boxes as well (one launch less)
+    L.decode_fused = heads.n > 0 && box_ops > 0 && box_ops == box_ops_grouped && e->fuse_decode;
+    if (L.decode_fused) {
+        heads.decode = 1;
+        heads.n_frames = n;
+        heads.pc = e->pc;
+        heads.anchors = L.post.anchors;
+        heads.boxes = L.post.boxes;
+        heads.valid = L.post.valid;
+        heads.hist = L.post.hist;
+        heads.count = L.post.count;
+        heads.band = L.post.band;
+    }
     if (heads.n > 0) wz_launch_splitk_reduce_group(heads, s);
     if (t) t->mark();
 }
 
-static void enqueue_post(wz_engine* e, Lane& L, bool rows, int n, StageTimer* t) {
+static void enqueue_post(wz_engine* e, Lane& L, bool rows, int n, StageTimer* t, bool decode_done = false) {
     hipStream_t s = L.stream;
-    wz_launch_decode(L.post, e->pc, n, s);   // (also clears hist / count / band)
+    if (!decode_done) wz_launch_decode(L.post, e->pc, n, s);   // (also clears hist / count / band)
     if (t) t->mark();
     wz_launch_hist(L.post, e->pc, n, s);
     if (t) t->mark();
@@ -328,7 +348,7 @@ static void enqueue_batch(wz_engine* e, Lane& L, int n, StageTimer* t) {
     wz_launch_preprocess(L.d_desc, n, (int)e->hdr.input_size, L.tptr[input_tensor_index(e)], s);
     if (t) t->mark();
     enqueue_network(e, L, n, t);
-    enqueue_post(e, L, true, n, t);
+    enqueue_post(e, L, true, n, t, L.decode_fused);
 }
 
 static int run_batch(wz_engine* e, int slot, int n) {
@@ -464,6 +484,7 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     e->use_graph = !((env = getenv("WZ_GRAPH")) && atoi(env) == 0);
     e->use_splitk = !((env = getenv("WZ_SPLITK")) && atoi(env) == 0);
     e->defer_heads = !((env = getenv("WZ_DEFER_HEADS")) && atoi(env) == 0);
+    e->fuse_decode = !((env = getenv("WZ_FUSE_DECODE")) && atoi(env) == 0);
     if ((env = getenv("WZ_LANES")) && atoi(env) >= 1 && atoi(env) <= WZ_SLOTS) e->n_lanes = atoi(env);
 
 #define CK(expr)                                                                                        \
