@@ -382,6 +382,33 @@ def test_submit_host_equals_detect_batch(eng):
         eng.host_unregister(arena)
 
 
+@pytest.mark.parametrize("knob", ["WZ_DEFER_HEADS", "WZ_FUSE_DECODE"])
+def test_grouped_head_launches_are_bit_identical_to_separate_ones(eng, model_dir, knob):
+    """The launch-count work on the SSD heads must not change a bit: `WZ_DEFER_HEADS=0` runs every head and its split-K
+    reduction as launches of their own (same split counts, same summation order), `WZ_FUSE_DECODE=0` keeps the box
+    decode in wz_k_decode instead of the grouped reduce (same arithmetic, compiled without contraction)."""
+    frames = [synthetic_frame(640, 480, 300 + i) for i in range(4)]
+    ref = [np.zeros(100, ROW_DTYPE) for _ in frames]
+    eng.detect_batch(frames, ref)
+    os.environ[knob] = "0"
+    try:
+        other = make_engine(model_dir)
+    finally:
+        os.environ.pop(knob)
+    try:
+        got = [np.zeros(100, ROW_DTYPE) for _ in frames]
+        other.detect_batch(frames, got)
+        for a, b in zip(ref, got):
+            assert a.tobytes() == b.tobytes()
+        one = [np.zeros(100, ROW_DTYPE)]                       # batch of 1: other split counts, other group shapes
+        other.detect_batch(frames[:1], one)
+        ref1 = [np.zeros(100, ROW_DTYPE)]
+        eng.detect_batch(frames[:1], ref1)
+        assert one[0].tobytes() == ref1[0].tobytes()
+    finally:
+        other.close()
+
+
 def test_limits_and_errors(model_dir):
     e = make_engine(model_dir, max_batch=2, max_width=640, max_height=480)
     try:
