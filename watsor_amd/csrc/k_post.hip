@@ -614,29 +614,139 @@ __device__ int wz_nms_band_serial(NmsShared* S, const WzPostBuffers& b, const Wz
 __device__ void wz_make_row(const WzFrameDesc& fd, const WzCamFilter* __restrict__ cams, bool on, const float4_t bx,
                             float score, int label, wz_detection_t* __restrict__ row, uint8_t* __restrict__ pass);
 
+// Self-scan mode: one pass of the frame's workgroup over its 1917 x 91 logits collects the candidates of a band of score
+// bins [lo, hi) into the LDS list -- no histogram, no compaction kernel, no 256-CU launches in front of the walk.
+//   * A logit below `logit_floor(lo)` cannot reach bin lo (sigmoid is monotone; the floor is lowered by a margin four
+//     orders of magnitude above its rounding error), so all but a few hundred entries cost one load and one compare;
+//     the survivors go through exactly wz_candidate()'s arithmetic.
+//   * The walk is exact for ANY sequence of bands that partitions the score range from the top down (a candidate's
+//     fate depends only on higher-scored boxes of its class), so the band edges need not come from a histogram: the
+//     first band starts at a per-slot hint (where it started last time, nudged so that it holds a few hundred
+//     candidates); a band that overflows the list is retried with its lower edge raised (down to a single bin, which
+//     then takes the serial path); when a band runs dry before max_total rows are kept the next one reaches further
+//     down, twice as far each time, until bin 0.
+__device__ __forceinline__ float wz_logit_floor(int bin) {
+    if (bin <= 0) return -__builtin_inff();
+    const float s = __uint_as_float((uint32_t)bin << 20);
+    if (!(s < 1.0f)) return 15.0f;                       // sigmoid(x) rounds to 1.0f only for x > 16.6
+    const float l = logf(s / (1.0f - s));
+    return l - 0.01f - 1e-3f * fabsf(l);
+}
+__device__ uint32_t wz_nms_scan_band(NmsShared* S, const WzPostBuffers& b, const WzPostConsts& k, int f, int lo_bin,
+                                     int hi_bin) {
+    const int tid = threadIdx.x;
+    const int C = k.num_classes, n_entries = k.num_anchors * C;
+    const float* __restrict__ lg = b.logits + (size_t)f * n_entries;
+    const float lf = wz_logit_floor(lo_bin);
+    if (tid == 0) S->ncand = 0;
+    __syncthreads();
+    auto consider = [&](int j, float x) {
+        if (!(x >= lf)) return;
+        const int a = j / C, col = j - a * C;
+        if (col == 0 || !b.valid[(size_t)f * k.num_anchors + a]) return;
+        const float sc = wz_sigmoid(x);                   // wz_candidate()'s arithmetic
+        if (!(sc > k.score_thr)) return;
+        const uint32_t key = __float_as_uint(sc);
+        const int bin = (int)(key >> 20);
+        if (bin < lo_bin || bin >= hi_bin) return;
+        const uint32_t tie = (uint32_t)(col - 1) * (uint32_t)k.num_anchors + (uint32_t)a;
+        const uint32_t pos = atomicAdd(&S->ncand, 1u);
+        if (pos < WZ_CAND_CAP) S->keys[pos] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - tie);
+    };
+    // 16-byte loads where the frame's logits allow it (n_entries is odd for 1917 x 91: the frame base is only 4-byte
+    // aligned in general), scalar loads for the ragged head and tail
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(lg);
+    const int head = (int)(((16 - (addr & 15)) & 15) >> 2);           // entries before the first 16-byte boundary
+    const int n4 = (n_entries - min(head, n_entries)) >> 2;
+    // eight loads in flight per thread: taken one at a time the scan is a chain of ~43 memory latencies (29 us)
+    constexpr int UN = 8;
+    for (int q0 = tid; q0 < n4; q0 += NMS_THREADS * UN) {
+        float4_t v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int q = q0 + u * NMS_THREADS;
+            v[u] = q < n4 ? *reinterpret_cast<const float4_t*>(lg + head + 4 * q) : (float4_t){-1e30f, -1e30f, -1e30f, -1e30f};
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const float m = fmaxf(fmaxf(v[u][0], v[u][1]), fmaxf(v[u][2], v[u][3]));
+            if (m >= lf) {
+                const int q = q0 + u * NMS_THREADS;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) consider(head + 4 * q + r, v[u][r]);
+            }
+        }
+    }
+    for (int j = tid; j < head && j < n_entries; j += NMS_THREADS) consider(j, lg[j]);
+    for (int j = head + 4 * n4 + tid; j < n_entries; j += NMS_THREADS) consider(j, lg[j]);
+    __syncthreads();
+    const uint32_t cnt = S->ncand;
+    __syncthreads();
+    return cnt;
+}
+
 // frames != nullptr: the kernel also writes the frame's 100 Detection rows (what wz_k_rows does from the det_* arrays) --
 // one launch less per batch
 __global__ __launch_bounds__(NMS_THREADS) void wz_k_nms(WzPostBuffers b, WzPostConsts k,
                                                         const WzFrameDesc* __restrict__ frames,
                                                         const WzCamFilter* __restrict__ cams,
-                                                        wz_detection_t* __restrict__ rows, uint8_t* __restrict__ pass) {
+                                                        wz_detection_t* __restrict__ rows, uint8_t* __restrict__ pass,
+                                                        int self_scan) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     NmsShared* S = reinterpret_cast<NmsShared*>(smem);
     const int f = blockIdx.x, tid = threadIdx.x;
     const int A = k.num_anchors;
-
+#define NMS_STAMP(i) do { if (tid == 0) b.dbg[(size_t)f * 16 + (i)] = wall_clock64(); } while (0)
+    NMS_STAMP(0);
+    uint32_t processed = 0;
+    int kept = 0;
+    if (tid == 0) S->kept = 0;
+    if (self_scan) {
+        NMS_STAMP(1);
+        int hi_bin = WZ_HIST_BINS;
+        int lo_bin = min((int)b.hint[f], WZ_HIST_BINS - 1);
+        int reach = 4;                                     // bins the next band extends below the current one
+        uint32_t first_cnt = 0;
+        int first_lo = lo_bin;
+        bool first = true;
+        for (;;) {
+            uint32_t cnt = wz_nms_scan_band(S, b, k, f, lo_bin, hi_bin);
+            while (cnt > WZ_CAND_CAP && lo_bin + 1 < hi_bin) {   // too many for the list: raise the band's lower edge
+                lo_bin += (hi_bin - lo_bin + 1) >> 1;
+                cnt = wz_nms_scan_band(S, b, k, f, lo_bin, hi_bin);
+            }
+            if (first) {
+                first_cnt = cnt;
+                first_lo = lo_bin;
+                NMS_STAMP(2);
+            }
+            if (cnt > WZ_CAND_CAP)                           // one bin holds more than the list: exact serial walk
+                kept = wz_nms_band_serial(S, b, k, f, kept, (unsigned long long)((uint32_t)lo_bin << 20) << 32,
+                                          (unsigned long long)((uint32_t)hi_bin << 20) << 32);
+            else if (cnt > 0)
+                kept = wz_nms_band(S, b, k, f, (int)cnt, kept);
+            processed += cnt;
+            if (first) { NMS_STAMP(3); if (tid == 0) { b.dbg[(size_t)f * 16 + 8] = cnt; b.dbg[(size_t)f * 16 + 9] = kept; } }
+            first = false;
+            if (kept >= k.max_total || lo_bin == 0) break;
+            hi_bin = lo_bin;
+            lo_bin = max(lo_bin - reach, 0);
+            reach *= 2;
+        }
+        if (tid == 0) {   // where to start next time: a first band of roughly 200 .. 800 candidates
+            int h = first_lo;
+            if (first_cnt < WZ_CAND_TARGET) h = max(first_lo - 2, 1);
+            else if (first_cnt > 4 * WZ_CAND_TARGET) h = min(first_lo + 1, WZ_HIST_BINS - 1);
+            b.hint[f] = (uint32_t)h;
+        }
+    } else {
     // Bands of the score histogram, highest first.  Band 0 = bins [thr, 1024) was compacted by
     // wz_k_compact; further bands (needed only when NMS suppresses so much that band 0 runs dry
     // before max_total rows are kept) are collected here by one scan over the frame's candidates.
-#define NMS_STAMP(i) do { if (tid == 0) b.dbg[(size_t)f * 16 + (i)] = wall_clock64(); } while (0)
-    NMS_STAMP(0);
     const uint32_t total = b.band[2 * f + 1];
     int lo_bin = (int)b.band[2 * f];
     NMS_STAMP(1);
     int hi_bin = WZ_HIST_BINS;
-    uint32_t processed = 0;
-    int kept = 0;
-    if (tid == 0) S->kept = 0;
     bool first = true;
     while (total > 0) {
         uint32_t cnt_raw;
@@ -677,6 +787,7 @@ __global__ __launch_bounds__(NMS_THREADS) void wz_k_nms(WzPostBuffers b, WzPostC
         hi_bin = lo_bin;
         lo_bin = wz_threshold_bin(b.hist + (size_t)f * WZ_HIST_BINS, S->hist, WZ_CAND_TARGET, nullptr, hi_bin);
         first = false;
+    }
     }
     __syncthreads();
 
@@ -848,8 +959,9 @@ void wz_post_init() {
                               (int)sizeof(NmsShared));
 }
 void wz_launch_nms(const WzPostBuffers& b, const WzPostConsts& c, int n, hipStream_t s, const WzFrameDesc* d_frames,
-                   const WzCamFilter* d_cams, wz_detection_t* rows, uint8_t* pass) {
-    hipLaunchKernelGGL(wz_k_nms, dim3(n), dim3(NMS_THREADS), sizeof(NmsShared), s, b, c, d_frames, d_cams, rows, pass);
+                   const WzCamFilter* d_cams, wz_detection_t* rows, uint8_t* pass, bool self_scan) {
+    hipLaunchKernelGGL(wz_k_nms, dim3(n), dim3(NMS_THREADS), sizeof(NmsShared), s, b, c, d_frames, d_cams, rows, pass,
+                       self_scan ? 1 : 0);
 }
 void wz_launch_rows(const WzPostBuffers& b, const WzFrameDesc* d_frames, const WzCamFilter* d_cams, int n,
                     int max_total, wz_detection_t* rows, uint8_t* pass, hipStream_t s) {

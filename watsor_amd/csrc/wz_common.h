@@ -175,6 +175,7 @@ struct WzPostBuffers {
     uint32_t* hist;           // [n][WZ_HIST_BINS]
     uint32_t* count;          // [n]  (directly behind hist so one memset clears both)
     uint32_t* band;           // [n][2] threshold bin of band 0 and the frame's candidate total (written by wz_k_compact)
+    uint32_t* hint;           // [n] self-scan mode of wz_k_nms: the score bin the first band of this frame slot started at last time
     uint2* cand;              // [n][WZ_CAND_CAP] (score bits, tie index c*A + a)
     float* det_boxes;         // [n][100][4]
     float* det_scores;        // [n][100]
@@ -186,8 +187,10 @@ void wz_launch_decode(const WzPostBuffers& b, const WzPostConsts& c, int n, hipS
 void wz_launch_hist(const WzPostBuffers& b, const WzPostConsts& c, int n, hipStream_t s);
 void wz_launch_compact(const WzPostBuffers& b, const WzPostConsts& c, int n, hipStream_t s);
 // d_frames != nullptr: the kernel also writes the Detection rows + pass bytes (then no wz_launch_rows is needed)
+// self_scan: the kernel selects its candidates itself (no wz_k_hist / wz_k_compact in front of it)
 void wz_launch_nms(const WzPostBuffers& b, const WzPostConsts& c, int n, hipStream_t s, const WzFrameDesc* d_frames = nullptr,
-                   const WzCamFilter* d_cams = nullptr, wz_detection_t* rows = nullptr, uint8_t* pass = nullptr);
+                   const WzCamFilter* d_cams = nullptr, wz_detection_t* rows = nullptr, uint8_t* pass = nullptr,
+                   bool self_scan = false);
 void wz_launch_rows(const WzPostBuffers& b, const WzFrameDesc* d_frames, const WzCamFilter* d_cams, int n,
                     int max_total, wz_detection_t* rows, uint8_t* pass, hipStream_t s);
 int wz_set_error(int code, const char* fmt, ...);   // sets wz_last_error() of the calling thread, returns code

@@ -71,6 +71,7 @@ struct wz_engine {
     const WzOpDesc* ops = nullptr;
     int max_batch = 0, max_w = 0, max_h = 0;
     bool no_reuse = false, use_graph = true, use_splitk = true;
+    bool post_self = true;     // WZ_POST_SELF=0: histogram + compaction kernels in front of the NMS kernel
     bool fuse_decode = true;   // WZ_FUSE_DECODE=0: keep wz_k_decode as its own launch
     bool defer_heads = true;   // the SSD heads' split-K reductions run as one launch after the last head (WZ_DEFER_HEADS=0: one each)
 
@@ -325,16 +326,18 @@ static void enqueue_post(wz_engine* e, Lane& L, bool rows, int n, StageTimer* t,
     hipStream_t s = L.stream;
     if (!decode_done) wz_launch_decode(L.post, e->pc, n, s);   // (also clears hist / count / band)
     if (t) t->mark();
-    wz_launch_hist(L.post, e->pc, n, s);
+    // default: the NMS kernel selects its candidates itself, one workgroup per frame; WZ_POST_SELF=0 puts the two
+    // 256-CU scans (histogram of the scores, compaction of the band above its threshold) back in front of it
+    if (!e->post_self) wz_launch_hist(L.post, e->pc, n, s);
     if (t) t->mark();
-    wz_launch_compact(L.post, e->pc, n, s);
+    if (!e->post_self) wz_launch_compact(L.post, e->pc, n, s);
     if (t) t->mark();
     // with `rows` the NMS kernel also fills the Detection rows (straight into the lane's pinned, device-mapped host
     // block: no D2H copy node, no separate row kernel); the "post/rows" stage slot stays empty
     if (rows)
-        wz_launch_nms(L.post, e->pc, n, s, L.d_desc, e->d_cams, L.m_rows, L.m_pass);
+        wz_launch_nms(L.post, e->pc, n, s, L.d_desc, e->d_cams, L.m_rows, L.m_pass, e->post_self);
     else
-        wz_launch_nms(L.post, e->pc, n, s);
+        wz_launch_nms(L.post, e->pc, n, s, nullptr, nullptr, nullptr, nullptr, e->post_self);
     if (t) t->mark();
     if (rows && t) t->mark();
 }
@@ -485,6 +488,7 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     e->use_splitk = !((env = getenv("WZ_SPLITK")) && atoi(env) == 0);
     e->defer_heads = !((env = getenv("WZ_DEFER_HEADS")) && atoi(env) == 0);
     e->fuse_decode = !((env = getenv("WZ_FUSE_DECODE")) && atoi(env) == 0);
+    e->post_self = !((env = getenv("WZ_POST_SELF")) && atoi(env) == 0);
     if ((env = getenv("WZ_LANES")) && atoi(env) >= 1 && atoi(env) <= WZ_SLOTS) e->n_lanes = atoi(env);
 
 #define CK(expr)                                                                                        \
@@ -533,7 +537,7 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     e->pc.score_thr = h.score_threshold;
     e->pc.iou_thr = h.iou_threshold;
     e->pc.scale_y = h.scale_y; e->pc.scale_x = h.scale_x; e->pc.scale_h = h.scale_h; e->pc.scale_w = h.scale_w;
-    e->post_scratch_bytes = (size_t)max_batch * (WZ_HIST_BINS + 3) * 4;
+    e->post_scratch_bytes = (size_t)max_batch * (WZ_HIST_BINS + 4) * 4;   // hist, count, band[2], hint
 
     for (uint32_t i = 0; i < h.n_tensors; ++i)
         if (e->tensors[i].slot < 0 || e->tensors[i].slot >= (int)h.n_slots) {
@@ -583,6 +587,11 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
         pb.hist = (uint32_t*)L.d_post_scratch;
         pb.count = pb.hist + (size_t)max_batch * WZ_HIST_BINS;
         pb.band = pb.count + max_batch;
+        pb.hint = pb.band + 2 * max_batch;
+        {   // first band of the self-scanning NMS kernel: start at score 0.25 until the frame slot has a history
+            std::vector<uint32_t> hint0((size_t)max_batch, 0x3E800000u >> 20);
+            CK(hipMemcpy(pb.hint, hint0.data(), hint0.size() * 4, hipMemcpyHostToDevice));
+        }
         CK(hipMalloc((void**)&pb.cand, (size_t)max_batch * WZ_CAND_CAP * sizeof(uint2)));
         CK(hipMalloc((void**)&pb.det_boxes, (size_t)max_batch * h.max_total * 16));
         CK(hipMalloc((void**)&pb.det_scores, (size_t)max_batch * h.max_total * 4));
