@@ -409,7 +409,7 @@ __device__ __forceinline__ void wz_decode_anchor(const float4_t e, const float4_
 }
 
 __global__ __launch_bounds__(256) void wz_k_splitk_reduce_group(const WzReduceGroup g) {
-    if (g.decode) {   // first kernel of the post-processing chain in this mode: clear its per-frame scratch
+    if (g.decode && !g.list) {   // first kernel of the histogram-based post chain: clear its per-frame scratch
         const int i = blockIdx.x * 256 + threadIdx.x;
         if (i < g.n_frames * WZ_HIST_BINS) g.hist[i] = 0u;
         if (i < g.n_frames) g.count[i] = 0u;
@@ -431,6 +431,24 @@ __global__ __launch_bounds__(256) void wz_k_splitk_reduce_group(const WzReduceGr
     }
     wz_epilogue4(a, m, n4, v);
     const int n_box = a.out_mode == WZ_OUT_HEAD ? a.n_box : (a.out_mode == WZ_OUT_BOX ? a.cout : 0);
+    if (g.list && n4 >= n_box && n4 < a.cout && a.out_mode != WZ_OUT_BOX && a.out_mode != WZ_OUT_ACT) {
+        // class logits of one anchor location, four at a time: the ones that can reach the frame's first score band
+        // are listed for wz_k_nms (which re-derives score, validity and bin exactly as its own scan would)
+        const int hw = a.hout * a.wout;
+        const int b = m / hw, pix = m - b * hw;
+        const int cols = a.cout - n_box, n0 = n4 - n_box;
+        const long long off = a.out_mode == WZ_OUT_HEAD ? a.out2_off : a.out_off;
+        const float lf = g.hint_logit[b];
+        const float4_t bv = *reinterpret_cast<const float4_t*>(a.bias + n4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float x = v[r] + bv[r];   // what the epilogue stored
+            if (n0 + r < cols && x >= lf) {
+                const long long j = off + (long long)pix * cols + n0 + r;   // entry index within the frame's logits
+                atomicOr(&g.cbits[(size_t)b * g.cbits_words + (size_t)(j >> 5)], 1u << (j & 31));   // result unused
+            }
+        }
+    }
     if (g.decode && n4 < n_box) {   // columns n4 .. n4+3 = the encoding of anchor (pixel, n4 / 4)
         const float4_t bv = *reinterpret_cast<const float4_t*>(a.bias + n4);
         float4_t enc;

@@ -691,7 +691,7 @@ __global__ __launch_bounds__(NMS_THREADS) void wz_k_nms(WzPostBuffers b, WzPostC
                                                         const WzFrameDesc* __restrict__ frames,
                                                         const WzCamFilter* __restrict__ cams,
                                                         wz_detection_t* __restrict__ rows, uint8_t* __restrict__ pass,
-                                                        int self_scan) {
+                                                        int self_scan, int listed) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     NmsShared* S = reinterpret_cast<NmsShared*>(smem);
     const int f = blockIdx.x, tid = threadIdx.x;
@@ -702,6 +702,18 @@ __global__ __launch_bounds__(NMS_THREADS) void wz_k_nms(WzPostBuffers b, WzPostC
     int kept = 0;
     if (tid == 0) S->kept = 0;
     if (self_scan) {
+        // the bit map of the listed candidates is requested before anything else: with the hint, the logits and the
+        // validity bytes behind it the first band is a chain of global-memory latencies (~2 us each on a busy chip)
+        constexpr int WPT = 8;                               // words per thread (the launcher checks that this covers the map)
+        uint32_t mw[WPT];
+        {
+            const int words = (k.num_anchors * k.num_classes + 31) >> 5;
+#pragma unroll
+            for (int u = 0; u < WPT; ++u) {
+                const int w = tid + u * NMS_THREADS;
+                mw[u] = (listed && w < words) ? b.cbits[(size_t)f * words + w] : 0u;
+            }
+        }
         NMS_STAMP(1);
         int hi_bin = WZ_HIST_BINS;
         int lo_bin = min((int)b.hint[f], WZ_HIST_BINS - 1);
@@ -710,7 +722,45 @@ __global__ __launch_bounds__(NMS_THREADS) void wz_k_nms(WzPostBuffers b, WzPostC
         int first_lo = lo_bin;
         bool first = true;
         for (;;) {
-            uint32_t cnt = wz_nms_scan_band(S, b, k, f, lo_bin, hi_bin);
+            uint32_t cnt;
+            if (first && listed) {
+                // the grouped head reduce marked every class logit >= wz_logit_floor(hint) of this frame while it still
+                // had it in registers: the first band [hint, 1024) needs no scan of the logits, only of the bit map
+                // (22 KiB per frame; read and cleared here).  Same tests as wz_nms_scan_band.
+                if (tid == 0) S->ncand = 0;
+                __syncthreads();
+                const int C = k.num_classes, n_entries = k.num_anchors * C, words = (n_entries + 31) >> 5;
+                uint32_t* const bits = b.cbits + (size_t)f * words;   // (words <= WPT * NMS_THREADS: checked by the launcher)
+                const float* __restrict__ lg = b.logits + (size_t)f * n_entries;
+#pragma unroll
+                for (int u = 0; u < WPT; ++u) {
+                    const int w = tid + u * NMS_THREADS;
+                    uint32_t m = mw[u];
+                    if (m) bits[w] = 0u;
+                    while (m) {
+                        const int j = w * 32 + __builtin_ctz(m);
+                        m &= m - 1;
+                        const int a = j / C, col = j - a * C;
+                        const float x = lg[j];                      // both loads issued before either is used
+                        const uint8_t ok = b.valid[(size_t)f * k.num_anchors + a];
+                        if (col == 0 || !ok) continue;
+                        const float sc = wz_sigmoid(x);
+                        if (!(sc > k.score_thr)) continue;
+                        const uint32_t key = __float_as_uint(sc);
+                        const int bin = (int)(key >> 20);
+                        if (bin < lo_bin || bin >= hi_bin) continue;
+                        const uint32_t tie = (uint32_t)(col - 1) * (uint32_t)k.num_anchors + (uint32_t)a;
+                        const uint32_t pos = atomicAdd(&S->ncand, 1u);
+                        if (pos < WZ_CAND_CAP)
+                            S->keys[pos] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - tie);
+                    }
+                }
+                __syncthreads();
+                cnt = S->ncand;
+                __syncthreads();
+            } else {
+                cnt = wz_nms_scan_band(S, b, k, f, lo_bin, hi_bin);
+            }
             while (cnt > WZ_CAND_CAP && lo_bin + 1 < hi_bin) {   // too many for the list: raise the band's lower edge
                 lo_bin += (hi_bin - lo_bin + 1) >> 1;
                 cnt = wz_nms_scan_band(S, b, k, f, lo_bin, hi_bin);
@@ -738,6 +788,7 @@ __global__ __launch_bounds__(NMS_THREADS) void wz_k_nms(WzPostBuffers b, WzPostC
             if (first_cnt < WZ_CAND_TARGET) h = max(first_lo - 2, 1);
             else if (first_cnt > 4 * WZ_CAND_TARGET) h = min(first_lo + 1, WZ_HIST_BINS - 1);
             b.hint[f] = (uint32_t)h;
+            b.hint_logit[f] = wz_logit_floor(h);
         }
     } else {
     // Bands of the score histogram, highest first.  Band 0 = bins [thr, 1024) was compacted by
@@ -959,9 +1010,10 @@ void wz_post_init() {
                               (int)sizeof(NmsShared));
 }
 void wz_launch_nms(const WzPostBuffers& b, const WzPostConsts& c, int n, hipStream_t s, const WzFrameDesc* d_frames,
-                   const WzCamFilter* d_cams, wz_detection_t* rows, uint8_t* pass, bool self_scan) {
+                   const WzCamFilter* d_cams, wz_detection_t* rows, uint8_t* pass, bool self_scan, bool listed) {
+    if (((c.num_anchors * c.num_classes + 31) >> 5) > 8 * NMS_THREADS) listed = false;   // bit map larger than one pass: scan instead
     hipLaunchKernelGGL(wz_k_nms, dim3(n), dim3(NMS_THREADS), sizeof(NmsShared), s, b, c, d_frames, d_cams, rows, pass,
-                       self_scan ? 1 : 0);
+                       self_scan ? 1 : 0, (self_scan && listed) ? 1 : 0);
 }
 void wz_launch_rows(const WzPostBuffers& b, const WzFrameDesc* d_frames, const WzCamFilter* d_cams, int n,
                     int max_total, wz_detection_t* rows, uint8_t* pass, hipStream_t s) {

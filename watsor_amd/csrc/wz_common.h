@@ -120,6 +120,11 @@ struct WzReduceGroup {
     // decode != 0: the thread that finishes the four box-encoding columns of an anchor also decodes + clips the box
     // (exactly wz_k_decode's arithmetic) and the launch clears hist / count / band -- wz_k_decode is then not launched
     int32_t decode, n_frames;
+    // list != 0: class logits at or above the frame's hint_logit get their bit set in cbits[f] -- the first band of
+    // wz_k_nms then needs no scan of the logits at all
+    int32_t list, cbits_words;
+    const float* hint_logit;
+    uint32_t* cbits;
     WzPostConsts pc;
     const float* anchors;
     float* boxes;
@@ -176,6 +181,9 @@ struct WzPostBuffers {
     uint32_t* count;          // [n]  (directly behind hist so one memset clears both)
     uint32_t* band;           // [n][2] threshold bin of band 0 and the frame's candidate total (written by wz_k_compact)
     uint32_t* hint;           // [n] self-scan mode of wz_k_nms: the score bin the first band of this frame slot started at last time
+    float* hint_logit;        // [n] wz_logit_floor(hint): what the grouped head reduce compares the finished logits with
+    uint32_t* cbits;          // [n][ceil(A*C/32)] one bit per class logit: set by the grouped head reduce where the logit can
+                              // reach the frame's first band (fire-and-forget atomicOr), read and cleared by wz_k_nms
     uint2* cand;              // [n][WZ_CAND_CAP] (score bits, tie index c*A + a)
     float* det_boxes;         // [n][100][4]
     float* det_scores;        // [n][100]
@@ -190,7 +198,7 @@ void wz_launch_compact(const WzPostBuffers& b, const WzPostConsts& c, int n, hip
 // self_scan: the kernel selects its candidates itself (no wz_k_hist / wz_k_compact in front of it)
 void wz_launch_nms(const WzPostBuffers& b, const WzPostConsts& c, int n, hipStream_t s, const WzFrameDesc* d_frames = nullptr,
                    const WzCamFilter* d_cams = nullptr, wz_detection_t* rows = nullptr, uint8_t* pass = nullptr,
-                   bool self_scan = false);
+                   bool self_scan = false, bool listed = false);
 void wz_launch_rows(const WzPostBuffers& b, const WzFrameDesc* d_frames, const WzCamFilter* d_cams, int n,
                     int max_total, wz_detection_t* rows, uint8_t* pass, hipStream_t s);
 int wz_set_error(int code, const char* fmt, ...);   // sets wz_last_error() of the calling thread, returns code

@@ -71,6 +71,7 @@ struct wz_engine {
     const WzOpDesc* ops = nullptr;
     int max_batch = 0, max_w = 0, max_h = 0;
     bool no_reuse = false, use_graph = true, use_splitk = true;
+    bool list_cands = true;    // WZ_LIST_CANDS=0: the self-scanning NMS kernel always scans
     bool post_self = true;     // WZ_POST_SELF=0: histogram + compaction kernels in front of the NMS kernel
     bool fuse_decode = true;   // WZ_FUSE_DECODE=0: keep wz_k_decode as its own launch
     bool defer_heads = true;   // the SSD heads' split-K reductions run as one launch after the last head (WZ_DEFER_HEADS=0: one each)
@@ -97,6 +98,7 @@ struct wz_engine {
         float* d_logits = nullptr;
         float* d_ws = nullptr;
         bool decode_fused = false;           // set by enqueue_network: the grouped head reduce decoded the boxes
+        bool cands_listed = false;           // ... and listed the candidates of the NMS kernel's first band
         uint8_t* d_frames = nullptr;         // staging for host frames of this lane [max_batch][frame_stride] (lazy)
         WzPostBuffers post;
         void* d_post_scratch = nullptr;      // hist + count (memset per batch)
@@ -157,7 +159,8 @@ static WzMbArgs mb_args(wz_engine* e, const Lane& L, const WzOpDesc& op) {
     return a;
 }
 
-static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t) {
+// with_post: the post-processing chain follows in the same stream (it consumes -- and resets -- the candidate list)
+static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool with_post = true) {
     hipStream_t s = L.stream;
     const bool f32 = e->hdr.precision == 32;
     // The heads write only into the box / logit buffers that the post kernels read at the very end, so their partial
@@ -169,6 +172,7 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t) {
     heads.first[0] = 0;
     heads.decode = 0;
     int box_ops = 0, box_ops_grouped = 0;   // ops that produce box encodings / how many of them went into `heads`
+    int head_ops = 0;                       // ops that write box encodings or class logits
     // ... and the small heads themselves (3x3 ... 1x1 maps: a handful of workgroups each) share one launch as well
     WzConvGroup small, big;
     small.n = big.n = 0;
@@ -259,6 +263,7 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t) {
                 sk = wz_conv_use_lds(a) ? wz_choose_splitk_lds(a.M, a.n_pad, a.kchunks) : wz_choose_splitk(a.M, a.n_pad, a.kchunks);
             const bool makes_boxes = op.out_mode == WZ_OUT_HEAD || op.out_mode == WZ_OUT_BOX;
             if (makes_boxes) ++box_ops;
+            if (op.out_mode != WZ_OUT_ACT) ++head_ops;
             const size_t slab = (((size_t)sk * a.M * a.n_pad * 4) + 255) & ~(size_t)255;
             if (sk > 1 && e->defer_heads && op.out_mode != WZ_OUT_ACT && heads.n < WZ_REDUCE_GROUP_MAX &&
                 slab + (WZ_WS_BYTES >> 1) <= ws_top) {   // keep at least half of the workspace for the other ops
@@ -318,11 +323,19 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t) {
         heads.count = L.post.count;
         heads.band = L.post.band;
     }
+    // ... and, when the NMS kernel selects its own candidates, list the class logits that can reach its first band
+    L.cands_listed = with_post && L.decode_fused && e->post_self && head_ops == heads.n && e->list_cands;
+    heads.list = L.cands_listed ? 1 : 0;
+    if (L.cands_listed) {
+        heads.hint_logit = L.post.hint_logit;
+        heads.cbits = L.post.cbits;
+        heads.cbits_words = (e->pc.num_anchors * e->pc.num_classes + 31) >> 5;
+    }
     if (heads.n > 0) wz_launch_splitk_reduce_group(heads, s);
     if (t) t->mark();
 }
 
-static void enqueue_post(wz_engine* e, Lane& L, bool rows, int n, StageTimer* t, bool decode_done = false) {
+static void enqueue_post(wz_engine* e, Lane& L, bool rows, int n, StageTimer* t, bool decode_done = false, bool listed = false) {
     hipStream_t s = L.stream;
     if (!decode_done) wz_launch_decode(L.post, e->pc, n, s);   // (also clears hist / count / band)
     if (t) t->mark();
@@ -335,9 +348,9 @@ static void enqueue_post(wz_engine* e, Lane& L, bool rows, int n, StageTimer* t,
     // with `rows` the NMS kernel also fills the Detection rows (straight into the lane's pinned, device-mapped host
     // block: no D2H copy node, no separate row kernel); the "post/rows" stage slot stays empty
     if (rows)
-        wz_launch_nms(L.post, e->pc, n, s, L.d_desc, e->d_cams, L.m_rows, L.m_pass, e->post_self);
+        wz_launch_nms(L.post, e->pc, n, s, L.d_desc, e->d_cams, L.m_rows, L.m_pass, e->post_self, listed);
     else
-        wz_launch_nms(L.post, e->pc, n, s, nullptr, nullptr, nullptr, nullptr, e->post_self);
+        wz_launch_nms(L.post, e->pc, n, s, nullptr, nullptr, nullptr, nullptr, e->post_self, listed);
     if (t) t->mark();
     if (rows && t) t->mark();
 }
@@ -351,7 +364,7 @@ static void enqueue_batch(wz_engine* e, Lane& L, int n, StageTimer* t) {
     wz_launch_preprocess(L.d_desc, n, (int)e->hdr.input_size, L.tptr[input_tensor_index(e)], s);
     if (t) t->mark();
     enqueue_network(e, L, n, t);
-    enqueue_post(e, L, true, n, t, L.decode_fused);
+    enqueue_post(e, L, true, n, t, L.decode_fused, L.cands_listed);
 }
 
 static int run_batch(wz_engine* e, int slot, int n) {
@@ -489,6 +502,7 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     e->defer_heads = !((env = getenv("WZ_DEFER_HEADS")) && atoi(env) == 0);
     e->fuse_decode = !((env = getenv("WZ_FUSE_DECODE")) && atoi(env) == 0);
     e->post_self = !((env = getenv("WZ_POST_SELF")) && atoi(env) == 0);
+    e->list_cands = !((env = getenv("WZ_LIST_CANDS")) && atoi(env) == 0);
     if ((env = getenv("WZ_LANES")) && atoi(env) >= 1 && atoi(env) <= WZ_SLOTS) e->n_lanes = atoi(env);
 
 #define CK(expr)                                                                                        \
@@ -537,7 +551,7 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     e->pc.score_thr = h.score_threshold;
     e->pc.iou_thr = h.iou_threshold;
     e->pc.scale_y = h.scale_y; e->pc.scale_x = h.scale_x; e->pc.scale_h = h.scale_h; e->pc.scale_w = h.scale_w;
-    e->post_scratch_bytes = (size_t)max_batch * (WZ_HIST_BINS + 4) * 4;   // hist, count, band[2], hint
+    e->post_scratch_bytes = (size_t)max_batch * (WZ_HIST_BINS + 5 + ((h.num_anchors * h.num_classes + 31) >> 5)) * 4;   // hist, count, band[2], hint, hint_logit, cbits
 
     for (uint32_t i = 0; i < h.n_tensors; ++i)
         if (e->tensors[i].slot < 0 || e->tensors[i].slot >= (int)h.n_slots) {
@@ -589,8 +603,18 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
         pb.band = pb.count + max_batch;
         pb.hint = pb.band + 2 * max_batch;
         {   // first band of the self-scanning NMS kernel: start at score 0.25 until the frame slot has a history
-            std::vector<uint32_t> hint0((size_t)max_batch, 0x3E800000u >> 20);
+            const uint32_t bin0 = 0x3E800000u >> 20;
+            std::vector<uint32_t> hint0((size_t)max_batch, bin0);
             CK(hipMemcpy(pb.hint, hint0.data(), hint0.size() * 4, hipMemcpyHostToDevice));
+            pb.hint_logit = reinterpret_cast<float*>(pb.hint + max_batch);
+            uint32_t sbits = bin0 << 20;
+            float s0;
+            memcpy(&s0, &sbits, 4);
+            const float l0 = logf(s0 / (1.0f - s0));   // wz_logit_floor(bin0), k_post.hip
+            std::vector<float> hl0((size_t)max_batch, l0 - 0.01f - 1e-3f * fabsf(l0));
+            CK(hipMemcpy(pb.hint_logit, hl0.data(), hl0.size() * 4, hipMemcpyHostToDevice));
+            pb.cbits = reinterpret_cast<uint32_t*>(pb.hint_logit + max_batch);
+            CK(hipMemset(pb.cbits, 0, (size_t)max_batch * ((h.num_anchors * h.num_classes + 31) >> 5) * 4));
         }
         CK(hipMalloc((void**)&pb.cand, (size_t)max_batch * WZ_CAND_CAP * sizeof(uint2)));
         CK(hipMalloc((void**)&pb.det_boxes, (size_t)max_batch * h.max_total * 16));
@@ -1033,7 +1057,7 @@ extern "C" int wz_stage_forward(wz_engine_t* e, int n, const uint16_t* in_half, 
     HIPCHK(hipStreamSynchronize(e->stream));
     const int S = (int)e->hdr.input_size;
     HIPCHK(hipMemcpy(e->lanes[0].tptr[input_tensor_index(e)], in_half, (size_t)n * S * S * 4 * 2, hipMemcpyHostToDevice));
-    enqueue_network(e, e->lanes[0], n, nullptr);
+    enqueue_network(e, e->lanes[0], n, nullptr, false);
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipGetLastError());
     if (box_enc) HIPCHK(hipMemcpy(box_enc, e->lanes[0].d_box_enc, (size_t)n * e->hdr.num_anchors * 16, hipMemcpyDeviceToHost));
