@@ -283,7 +283,8 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
                 if (makes_boxes) ++box_ops_grouped;
                 continue;
             }
-            if (sk > 1 && wz_conv_ws_applies(a)) {   // the K split happens inside the workgroups: nothing to reduce
+            if ((sk > 1 || a.M < 128) && wz_conv_ws_applies(a)) {   // the K split happens inside the workgroups: nothing to reduce
+                // (on the 2x2 and 1x1 maps also where one wave per tile would walk all of K alone)
                 a.splitk = 1;
                 a.out = final_out;
                 wz_launch_conv_ws(a, s);
