@@ -311,7 +311,7 @@ int wz_choose_splitk_rs_f32(int M, int n_pad, int kchunks) {
 }
 
 // a.splitk > 1: partials go to a.ws and the reduce kernel is enqueued right behind
-void wz_launch_conv_f32(const WzConvArgs& a0, hipStream_t s) {
+void wz_launch_conv_f32(const WzConvArgs& a0, hipStream_t s, bool reduce) {
     if (wz_conv_f32_use_rs(a0)) {
         WzConvArgs a = a0;
         const int nw = wz_lds_nw(a.M, a.n_pad, a.kchunks);
@@ -330,7 +330,7 @@ void wz_launch_conv_f32(const WzConvArgs& a0, hipStream_t s) {
             else
                 hipLaunchKernelGGL((wz_k_conv_rs_f32<3, 2>), grid, dim3(256), 0, s, a);
         }
-        if (a.splitk > 1) {
+        if (a.splitk > 1 && reduce) {
             const int total = a.M * (a.n_pad >> 2);
             hipLaunchKernelGGL(wz_k_splitk_reduce_f32, dim3((total + 255) / 256), dim3(256), 0, s, a);
         }
@@ -343,7 +343,7 @@ void wz_launch_conv_f32(const WzConvArgs& a0, hipStream_t s) {
         hipLaunchKernelGGL(wz_k_conv_f32<1>, grid, dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL(wz_k_conv_f32<3>, grid, dim3(256), 0, s, a);
-    if (a.splitk > 1) {
+    if (a.splitk > 1 && reduce) {
         const int total = a.M * (a.n_pad >> 2);
         hipLaunchKernelGGL(wz_k_splitk_reduce_f32, dim3((total + 255) / 256), dim3(256), 0, s, a);
     }

@@ -163,7 +163,7 @@ void wz_launch_stem_f32(const half_t* in, const float* w, const float* bias, flo
                         int hout, int wout, int pad_t, int pad_l, hipStream_t s);
 void wz_launch_dw_f32(const float* in, const float* w, const float* bias, float* out, int n, int hin, int win, int c,
                       int hout, int wout, int stride, int pad_t, int pad_l, int act, hipStream_t s);
-void wz_launch_conv_f32(const WzConvArgs& a, hipStream_t s);   // + its split-K reduce when a.splitk > 1
+void wz_launch_conv_f32(const WzConvArgs& a, hipStream_t s, bool reduce = true);   // + its split-K reduce when a.splitk > 1 (unless !reduce)
 int wz_launch_mbconv(const WzMbArgs& a, int n, hipStream_t s, bool prepare);   // -1: no kernel; else #channel groups
 int wz_launch_mbconv_wave(const WzMbArgs& a, int n, hipStream_t s, bool prepare);   // wave-per-tile variant; -2: not applicable
 int wz_launch_mbconv_cs(const WzMbArgs& a, int n, hipStream_t s, bool prepare);     // channels split over waves (small maps); -2: n/a

@@ -248,8 +248,27 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
             }
             a.zeros = e->d_zeros;
             a.dbg = e->d_mbdbg ? e->d_mbdbg + (size_t)i * 16 : nullptr;
+            const bool makes_boxes = op.out_mode == WZ_OUT_HEAD || op.out_mode == WZ_OUT_BOX;
+            if (makes_boxes) ++box_ops;
+            if (op.out_mode != WZ_OUT_ACT) ++head_ops;
             if (f32) {   // a.kc / a.kchunks count 16-channel chunks here
                 int sk = !e->use_splitk ? 1 : wz_conv_f32_use_rs(a) ? wz_choose_splitk_rs_f32(a.M, a.n_pad, a.kchunks) : wz_choose_splitk(a.M, a.n_pad, a.kchunks / 2);
+                const size_t slab32 = (((size_t)sk * a.M * a.n_pad * 4) + 255) & ~(size_t)255;
+                if (sk > 1 && e->defer_heads && op.out_mode != WZ_OUT_ACT && heads.n < WZ_REDUCE_GROUP_MAX &&
+                    slab32 + (WZ_WS_BYTES >> 1) <= ws_top) {
+                    // the heads' outputs are fp32 in both engines and their epilogue is the same: the partial sums are
+                    // parked and reduced (+ decoded, + candidates marked) by the same grouped launch as in the fp16 engine
+                    ws_top -= slab32;
+                    float* const park = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(L.d_ws) + ws_top);
+                    a.splitk = sk;
+                    a.ws = park;
+                    a.out = final_out;
+                    wz_launch_conv_f32(a, s, false);
+                    if (t) { t->mark(); t->mark(); }
+                    wz_reduce_group_add(heads, a, park);
+                    if (makes_boxes) ++box_ops_grouped;
+                    continue;
+                }
                 while (sk > 1 && (size_t)sk * a.M * a.n_pad * 4 > ws_top) --sk;
                 a.splitk = sk;
                 a.ws = L.d_ws;
@@ -261,9 +280,6 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
             int sk = 1;
             if (e->use_splitk)
                 sk = wz_conv_use_lds(a) ? wz_choose_splitk_lds(a.M, a.n_pad, a.kchunks) : wz_choose_splitk(a.M, a.n_pad, a.kchunks);
-            const bool makes_boxes = op.out_mode == WZ_OUT_HEAD || op.out_mode == WZ_OUT_BOX;
-            if (makes_boxes) ++box_ops;
-            if (op.out_mode != WZ_OUT_ACT) ++head_ops;
             const size_t slab = (((size_t)sk * a.M * a.n_pad * 4) + 255) & ~(size_t)255;
             if (sk > 1 && e->defer_heads && op.out_mode != WZ_OUT_ACT && heads.n < WZ_REDUCE_GROUP_MAX &&
                 slab + (WZ_WS_BYTES >> 1) <= ws_top) {   // keep at least half of the workspace for the other ops
