@@ -248,6 +248,86 @@ __global__ __launch_bounds__(256) void wz_k_conv_f32(const WzConvArgs a) {
     }
 }
 
+// Split-K inside the workgroup for the extras chain, fp32 engine (see wz_k_conv_ws in k_conv.hip): the 8 waves of a
+// workgroup share one 32-pixel x 32-channel tile, each walks an eighth of the 16-channel chunks, the accumulators meet
+// in LDS and are summed in wave order.
+template <int KS>
+__global__ __launch_bounds__(512) void wz_k_conv_ws_f32(const WzConvArgs a) {
+    constexpr int U = 2, WAVES = 8;
+    __shared__ float4_t red[WAVES][4][64];   // 32 KiB
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    const int m_base = blockIdx.x * 32;
+    const int nt0 = blockIdx.y * 2;
+    const float* in = reinterpret_cast<const float*>(a.in);
+    const float* wlane = reinterpret_cast<const float*>(a.w) + lane * 4;
+
+    const int hw = a.hout * a.wout;
+    int iy0[2], ix0[2], boff[2];
+    bool mv[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int m = m_base + mt * 16 + r16;
+        mv[mt] = m < a.M;
+        const int mm = mv[mt] ? m : 0;
+        const int b = mm / hw, rem = mm - b * hw;
+        const int oy = rem / a.wout, ox = rem - oy * a.wout;
+        iy0[mt] = oy * a.stride - a.pad_t;
+        ix0[mt] = ox * a.stride - a.pad_l;
+        boff[mt] = b * a.hin;
+    }
+    float4_t acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int per = (a.kchunks + WAVES - 1) / WAVES;
+    const int q0 = wave * per, q1 = min(q0 + per, a.kchunks);
+    if (q0 < q1) {
+        int ql = q0, t = (KS == 1) ? 0 : q0 / a.kc, c = (KS == 1) ? q0 : q0 - t * a.kc;
+        F32Frags<U> fa, fb;
+        wz_f32_load<KS, U>(a, fa, ql, q1, t, c, iy0, ix0, boff, mv, in, wlane, nt0, g);
+        for (int q = q0; q < q1;) {
+            wz_f32_load<KS, U>(a, fb, ql, q1, t, c, iy0, ix0, boff, mv, in, wlane, nt0, g);
+            wz_f32_mfma(fa, acc);
+            q += U;
+            if (q >= q1) break;
+            wz_f32_load<KS, U>(a, fa, ql, q1, t, c, iy0, ix0, boff, mv, in, wlane, nt0, g);
+            wz_f32_mfma(fb, acc);
+            q += U;
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) red[wave][mt * 2 + nt][lane] = acc[mt][nt];
+    __syncthreads();
+    if (wave < 4) {
+        float4_t v = red[0][wave][lane];
+#pragma unroll
+        for (int z = 1; z < WAVES; ++z) {
+            const float4_t p = red[z][wave][lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += p[r];
+        }
+        wz_epilogue4_f32(a, m_base + (wave / 2) * 16 + r16, (nt0 + wave % 2) * 16 + g * 4, v);
+    }
+}
+
+bool wz_conv_ws_f32_applies(const WzConvArgs& a) {
+    static const bool on = [] { const char* e = getenv("WZ_CONV_WS"); return !(e && atoi(e) == 0); }();
+    return on && a.out_mode == WZ_OUT_ACT && a.M <= 1024 && a.kchunks >= 16 && a.n_pad % 32 == 0;
+}
+void wz_launch_conv_ws_f32(const WzConvArgs& a, hipStream_t s) {
+    const dim3 grid((a.M + 31) / 32, a.n_pad / 32);
+    if (a.ksize == 1)
+        hipLaunchKernelGGL(wz_k_conv_ws_f32<1>, grid, dim3(512), 0, s, a);
+    else
+        hipLaunchKernelGGL(wz_k_conv_ws_f32<3>, grid, dim3(512), 0, s, a);
+}
+
 __global__ __launch_bounds__(256) void wz_k_splitk_reduce_f32(const WzConvArgs a) {
     const int tid = blockIdx.x * 256 + threadIdx.x;
     const int n4s = a.n_pad >> 2;

@@ -157,6 +157,8 @@ int wz_choose_splitk_lds(int M, int n_pad, int kchunks);
 int wz_lds_nw(int M, int n_pad, int kchunks);             // 16-channel tiles per wave pair: 2 -> 64-channel tile, 4 -> 128
 bool wz_conv_f32_use_rs(const WzConvArgs& a);            // fp32 engine: the register-staged tile kernel will serve this conv
 int wz_choose_splitk_rs_f32(int M, int n_pad, int kchunks);
+bool wz_conv_ws_f32_applies(const WzConvArgs& a);         // fp32 engine: the extras chain on the wave-split kernel
+void wz_launch_conv_ws_f32(const WzConvArgs& a, hipStream_t s);
 void wz_conv_init();
 // `-p 32` engine (k_f32.hip): fp32 activations and weights, exact-fp32 MFMA
 void wz_launch_stem_f32(const half_t* in, const float* w, const float* bias, float* out, int n, int hin, int win,

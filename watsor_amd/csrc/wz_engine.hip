@@ -269,6 +269,13 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
                     if (makes_boxes) ++box_ops_grouped;
                     continue;
                 }
+                if (wz_conv_ws_f32_applies(a)) {   // the extras chain: K split across the waves of a workgroup, no reduce
+                    a.splitk = 1;
+                    a.out = final_out;
+                    wz_launch_conv_ws_f32(a, s);
+                    if (t) { t->mark(); t->mark(); }
+                    continue;
+                }
                 while (sk > 1 && (size_t)sk * a.M * a.n_pad * 4 > ws_top) --sk;
                 a.splitk = sk;
                 a.ws = L.d_ws;
