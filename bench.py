@@ -409,9 +409,7 @@ def main():
             "config": {"workload": "1 synthetic 640x480 RGB stream per GPU, batch=8 frames, SSD-MobileNet-v2 300x300 "
                                    "(seeded random-init weights), frames resident in HBM, rows copied back to host",
                        "batch": BATCH, "frame": "%dx%d" % (WIDTH, HEIGHT), "parallelism": "replica-per-gpu x%d" % world, "batches_in_flight": lanes,
-                       "detections_per_frame": detections_per_frame,
-                       # stages whose event bracket is not empty = what one batch actually enqueues
-                       "graph_nodes_per_batch": sum(1 for _, ms in stages if ms - empty_bracket_ms(stages) > 5e-4)},   # kernels + the descriptor copy
+                       "detections_per_frame": detections_per_frame},
             "roofline": roof,
         }
         if world == 1:
