@@ -10,8 +10,10 @@
  *
  * Conventions: all functions return 0 on success or a negative WZ_E* code; `wz_last_error()`
  * returns a human readable message for the calling thread's last failure.  One engine = one GPU
- * = one HIP stream; calls on one engine must be serialised by the caller (the reference worker
- * is sequential per detector instance, detector.py:84-112).  Host frames are packed RGB24, HWC,
+ * with up to WZ_SLOTS lanes (a lane = one in-flight batch: its own HIP stream, activation buffers
+ * and captured graph; wz_num_slots() tells how many, 4 unless WZ_LANES says otherwise); calls on
+ * one engine must be serialised by the caller (the reference worker is sequential per detector
+ * instance, detector.py:84-112) -- the lanes overlap on the GPU, not on the host.  Host frames are packed RGB24, HWC,
  * C-contiguous (`Frame.get_numpy_image`, watsor/stream/share.py:68-73); they are read only and
  * not retained past the call.
  */
@@ -152,6 +154,12 @@ int wz_num_classes(wz_engine_t* e);
 int wz_num_tensors(wz_engine_t* e);
 int wz_tensor_info(wz_engine_t* e, int idx, char* name, int namelen, int* h, int* w, int* c);
 int wz_precision(wz_engine_t* e);   /* 16: fp16 storage / fp16 MFMA; 32: fp32 storage / exact-fp32 MFMA (engine built with -p 32) */
+/* bit 0: the tensor is stored as a hi + lo pair of halves per value (2c halves per pixel: c hi, then c lo) --
+ * the tensors between the split-operand blocks of the `-p 16` program (csrc/k_mbconv_hp.hip) */
+int wz_tensor_flags(wz_engine_t* e, int idx);
+/* leading inverted-residual blocks that run with split (hi + lo) matrix operands; 0 = plain fp16 program
+ * (`python -m watsor_amd.engine --plain-fp16`), whose scores miss the 1e-3 tolerance */
+int wz_hp_blocks(wz_engine_t* e);
 int wz_num_ops(wz_engine_t* e);
 /* dims[12] = kind,cin,cout,ksize,stride,hin,win,hout,wout,n_pad,kc,splitk */
 int wz_op_info(wz_engine_t* e, int idx, char* name, int namelen, int* dims);
@@ -175,11 +183,14 @@ int wz_dev_upload(wz_engine_t* e, void* d_dst, const void* h_src, uint64_t bytes
 int wz_dev_download(wz_engine_t* e, void* h_dst, const void* d_src, uint64_t bytes);
 
 /* ---- stage-level entry points for the parity tests (host in, host out, synchronous) */
-/* resize + normalise of one frame -> half[size*size*4] (x,y,z,0 per pixel) */
+/* resize + normalise of one frame -> half[size*size*4] (x,y,z,0 per pixel); when the input tensor is a pair
+ * (wz_tensor_flags) half[size*size*8]: (x,y,z,0) hi then (x,y,z,0) lo per pixel */
 int wz_stage_preprocess(wz_engine_t* e, const uint8_t* rgb, int w, int h, uint16_t* out_half);
-/* network only: half input [n][size][size][4] -> float box encodings [n][A][4], logits [n][A][C] */
+/* network only: half input [n][size][size][4] -> float box encodings [n][A][4], logits [n][A][C]
+ * (a pair input tensor gets these halves as its hi parts and zeros as its lo parts) */
 int wz_stage_forward(wz_engine_t* e, int n, const uint16_t* in_half, float* box_enc, float* logits);
-/* read activation tensor `idx` of frame `frame` left behind by the last forward (half, NHWC).
+/* read activation tensor `idx` of frame `frame` left behind by the last forward (half, NHWC; a pair tensor
+ * comes back as stored, 2c halves per pixel).
  * Only meaningful when the engine was created with WZ_NO_BUFFER_REUSE=1 in the environment. */
 int wz_stage_read_tensor(wz_engine_t* e, int idx, int frame, uint16_t* out_half);
 /* decode + sigmoid + NMS + top-k on caller-provided head outputs:

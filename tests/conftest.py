@@ -44,10 +44,20 @@ def synth_weights():
 
 @pytest.fixture(scope="session")
 def model_dir(synth_weights, tmp_path_factory):
-    """A model directory holding mi355x.bin built from the seeded synthetic weights."""
+    """A model directory holding mi355x.bin built from the seeded synthetic weights: the default `-p 16` program
+    (fused blocks, stem folded in, blocks 0 .. 12 with split matrix operands)."""
     from watsor_amd import engine
     d = tmp_path_factory.mktemp("model")
     engine.save_engine(engine.build_engine(synth_weights), str(d / "mi355x.bin"))
+    return str(d)
+
+
+@pytest.fixture(scope="session")
+def model_dir_plain(synth_weights, tmp_path_factory):
+    """`--plain-fp16`: the same fused program with one fp16 rounding per operand everywhere (no split-operand blocks)."""
+    from watsor_amd import engine
+    d = tmp_path_factory.mktemp("model_plain")
+    engine.save_engine(engine.build_engine(synth_weights, hp_upto=-1), str(d / "mi355x.bin"))
     return str(d)
 
 

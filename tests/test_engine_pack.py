@@ -21,7 +21,13 @@ def fused_blob(synth_weights):
 
 @pytest.fixture(scope="module")
 def default_blob(synth_weights):
-    """the default program: fused blocks, the stem folded into the first one"""
+    """fused blocks, the stem folded into the first one, plain fp16 everywhere (`--plain-fp16`)"""
+    return engine.build_engine(synth_weights, hp_upto=-1)
+
+
+@pytest.fixture(scope="module")
+def hp_blob(synth_weights):
+    """the default `-p 16` program: the same ops, blocks 0 .. 12 with split (hi + lo) matrix operands"""
     return engine.build_engine(synth_weights)
 
 
@@ -30,11 +36,11 @@ def parse(blob):
     hdr = dict(magic=h[0], version=h[1], precision=h[2], size=h[3], classes=h[4], anchors=h[5], n_tensors=h[6],
                n_ops=h[7], max_total=h[8], max_per_class=h[9], score_thr=h[10], iou_thr=h[11], scales=h[12:16],
                tensors_off=h[16], ops_off=h[17], anchors_off=h[18], weights_off=h[19], weights_bytes=h[20],
-               total=h[21], n_slots=h[22])
+               total=h[21], n_slots=h[22], hp_blocks=h[23])
     tensors = []
     for i in range(hdr["n_tensors"]):
-        t = struct.unpack_from("<4i48s", blob, hdr["tensors_off"] + 64 * i)
-        tensors.append(dict(h=t[0], w=t[1], c=t[2], slot=t[3], name=t[4].split(b"\0")[0].decode()))
+        t = struct.unpack_from("<5i44s", blob, hdr["tensors_off"] + 64 * i)
+        tensors.append(dict(h=t[0], w=t[1], c=t[2], slot=t[3], flags=t[4], name=t[5].split(b"\0")[0].decode()))
     ops = []
     keys = ("kind src dst res cin cout ksize stride hin win hout wout pad_t pad_l act out_mode anchor_off "
             "anchors_per_loc n_pad kc").split()
@@ -43,7 +49,7 @@ def parse(blob):
         d = dict(zip(keys, o[:20]))
         d.update(w_off=o[20], b_off=o[21], n_box=o[22], cmid=o[23], cin0=o[24], kc0=o[25], cmid_pad=o[26],
                  nmid_pad=o[27], stem=o[28], stem_pad=o[29], we_off=o[30], be_off=o[31], wd_off=o[32], bd_off=o[33],
-                 name=o[38].split(b"\0")[0].decode())
+                 we_lo_off=o[34], w_lo_off=o[35], flags=o[36], name=o[38].split(b"\0")[0].decode())
         ops.append(d)
     return hdr, tensors, ops
 
@@ -75,7 +81,7 @@ def test_shapes_follow_tf_same_padding(blob):
     assert [o["anchor_off"] for o in heads] == [0, 1083, 1683, 1833, 1887, 1911]
 
 
-@pytest.mark.parametrize("which", ["blob", "fused_blob", "default_blob"])
+@pytest.mark.parametrize("which", ["blob", "fused_blob", "default_blob", "hp_blob"])
 def test_slots_never_alias_live_tensors(which, request):
     hdr, tensors, ops = parse(request.getfixturevalue(which))
     last = {}
@@ -178,6 +184,59 @@ def test_stem_folded_into_the_first_block(default_blob, fused_blob, synth_weight
     np.testing.assert_array_equal(np.frombuffer(default_blob, np.float32, 32, hdr["weights_off"] + o["be_off"]), bf.astype(np.float32))
     for a, b in zip(ops[1:], fops[2:]):                                        # everything behind it is unchanged
         assert (a["kind"], a["name"], a["cin"], a["cout"]) == (b["kind"], b["name"], b["cin"], b["cout"])
+
+
+def test_split_operand_blocks_carry_hi_and_lo_weights(hp_blob, default_blob, synth_weights):
+    """Default `-p 16` program: blocks 0 .. 12 hold every GEMM weight as hi + lo halves whose sum is the folded fp64 weight
+    to ~2^-22 (the expand stage with the 1/6 of the unorm16 chunk buffer folded in), fp32 depthwise weights carrying
+    6/65535, and the tensors between them are pairs."""
+    hdr, tensors, ops = parse(hp_blob)
+    phdr, ptensors, pops = parse(default_blob)
+    assert hdr["hp_blocks"] == arch.HP_LAST_BLOCK + 1 and phdr["hp_blocks"] == 0
+    assert [t["name"] for t in tensors] == [t["name"] for t in ptensors]
+    assert not any(t["flags"] for t in ptensors) and not any(o["flags"] for o in pops)
+    prog = arch.build(hp_upto=arch.HP_LAST_BLOCK)
+    n_hp = 0
+    for o, po, op in zip(ops, pops, prog.ops):
+        assert (o["kind"], o["name"], o["cin"], o["cout"], o["n_pad"], o["kc"]) == (po["kind"], po["name"], po["cin"], po["cout"], po["n_pad"], po["kc"])
+        if not op.hp:
+            assert o["flags"] == 0 and not tensors[o["src"]]["flags"]
+            continue
+        n_hp += 1
+        assert o["flags"] & 1 and tensors[o["src"]]["flags"] == 1
+        assert bool(o["flags"] & 2) == bool(tensors[o["dst"]]["flags"]) == (op.block < arch.HP_LAST_BLOCK)
+        parts = list(op.parts)
+        ex = parts.pop(0) if (op.stem or op.cin0) else None
+        dw, pj = parts
+        # project: hi + lo == folded weight (to 2^-21 of its magnitude), hi == the plain program's fp16 weight
+        wf, bf = engine.fold_batch_norm(synth_weights, pj)
+        hi = unpack_conv(hp_blob, hdr, dict(o, ksize=1)).astype(np.float64)
+        lo = unpack_conv(hp_blob, hdr, dict(o, ksize=1, w_off=o["w_lo_off"])).astype(np.float64)
+        ref = wf.reshape(1, pj.cin, pj.cout)
+        plain = unpack_conv(default_blob, phdr, dict(po, ksize=1)).astype(np.float64)   # (rounded through fp32: a rare ulp apart)
+        assert np.abs(hi - plain).max() <= np.abs(plain).max() * 2.0 ** -10 and (hi != plain).mean() < 1e-3
+        assert np.abs(hi[:, :pj.cin, :pj.cout] + lo[:, :pj.cin, :pj.cout] - ref).max() <= np.abs(ref).max() * 2.0 ** -21
+        assert np.abs(lo).max() <= np.abs(hi).max() * 2.0 ** -10 and lo.any()
+        # expand (or stem): the same with the factor 1/6
+        wf, bf = engine.fold_batch_norm(synth_weights, ex)
+        kin = 27 if op.stem else ex.cin
+        ref = wf.reshape(1, kin, ex.cout) / 6.0
+        d = dict(ksize=1, n_pad=o["nmid_pad"], kc=o["kc0"])
+        hi = unpack_conv(hp_blob, hdr, dict(d, w_off=o["we_off"])).astype(np.float64)
+        lo = unpack_conv(hp_blob, hdr, dict(d, w_off=o["we_lo_off"])).astype(np.float64)
+        assert np.abs(hi[:, :kin, :ex.cout] + lo[:, :kin, :ex.cout] - ref).max() <= np.abs(ref).max() * 2.0 ** -21
+        assert not hi[:, kin:, :].any() and not lo[:, kin:, :].any()
+        be = np.frombuffer(hp_blob, np.float32, o["nmid_pad"], hdr["weights_off"] + o["be_off"])
+        np.testing.assert_allclose(be[:ex.cout], bf / 6.0, rtol=1e-7, atol=0)
+        # depthwise: fp32, scaled by 6 / 65535
+        wf, bf = engine.fold_batch_norm(synth_weights, dw)
+        wd = np.frombuffer(hp_blob, np.float32, 9 * o["cmid_pad"], hdr["weights_off"] + o["wd_off"]).reshape(9, -1)
+        np.testing.assert_allclose(wd[:, :o["cmid"]], wf.reshape(9, -1) * (6.0 / 65535.0), rtol=1e-7, atol=0)
+        assert not wd[:, o["cmid"]:].any()
+    assert n_hp == arch.HP_LAST_BLOCK + 1
+    assert tensors[0]["flags"] == 1                      # the network input is a pair, too
+    with pytest.raises(ValueError):
+        arch.build(fuse_stem=False, hp_upto=3)
 
 
 def test_fold_matches_oracle_fold(synth_weights):

@@ -5,10 +5,13 @@ Tolerances (stated here, measured in profiles/r01_parity.txt):
   * row fill (int truncation) .... bit-exact
   * post-processing on identical fp32 head outputs: same (class, anchor) rows, |score| <= 1e-6,
     |box| <= 2e-6 (GPU expf vs numpy expf differ by <= 2 ulp)
-  * network, `-p 16` engine (fp16 storage of weights and activations, fp32 accumulate) vs the fp32
-    oracle: every sigmoid score within SCORE_TOL = 4e-3 (measured 2.7e-3 on the seeded weights: the
-    ~53-layer random-init network amplifies the 2^-11 roundings; the north-star's 1e-3 is the bar for
-    the `-p 32` engine)
+  * network, default `-p 16` engine (fp16 MFMA everywhere; the stem and blocks 0 .. 12 with split hi + lo
+    operands, csrc/k_mbconv_hp.hip) vs the fp32 oracle: every sigmoid score and every detection row's
+    confidence within SCORE_TOL = 1e-3, the north star's bar ("box scores within 1e-3 of the CPU
+    reference"); tools/err_budget.py predicts 5e-4 for this program
+  * `--plain-fp16` engine (one fp16 rounding per operand everywhere): SCORE_TOL_PLAIN = 4e-3 (measured
+    2.7e-3: the ~53-layer random-init network amplifies the 2^-11 roundings)
+  * `-p 32` engine: 1e-4 on all scores, 1e-3 asserted end to end
 """
 import os
 
@@ -24,8 +27,9 @@ from watsor_amd.synth import synthetic_frame
 
 pytestmark = pytest.mark.gpu
 
-SCORE_TOL = 4e-3        # |sigmoid(logit_gpu) - sigmoid(logit_oracle)| over all 1917*91 entries
-LOGIT_TOL = 0.05        # max abs logit error of the fp16 engine vs the fp32 oracle
+SCORE_TOL = 1e-3        # |sigmoid(logit_gpu) - sigmoid(logit_oracle)| over all 1917*91 entries, default engine
+SCORE_TOL_PLAIN = 4e-3  # the same for the --plain-fp16 engine
+LOGIT_TOL = 0.05        # max abs logit error of the plain fp16 programs vs the fp32 oracle
 BOXENC_TOL = 0.04
 
 
@@ -76,6 +80,22 @@ def test_preprocess_bit_exact(eng, wh):
     ref = pre.preprocess_fp16(f)
     np.testing.assert_array_equal(got[..., :3].view(np.uint16), ref.view(np.uint16))
     assert not got[..., 3].any()
+    # the default program's input tensor is a pair: lo = RN16(v - RN16(v)) of the same fp32 value, bit for bit
+    assert got.shape[-1] == 8
+    lo = (pre.preprocess(f) - ref.astype(np.float32)).astype(np.float16)
+    np.testing.assert_array_equal(got[..., 4:7].view(np.uint16), lo.view(np.uint16))
+    assert not got[..., 7].any()
+
+
+def test_preprocess_plain_program(model_dir_plain):
+    e = make_engine(model_dir_plain, max_batch=1)
+    try:
+        f = synthetic_frame(640, 480, 77)
+        got = e.stage_preprocess(f)
+        assert got.shape[-1] == 4 and e.hp_blocks == 0
+        np.testing.assert_array_equal(got[..., :3].view(np.uint16), pre.preprocess_fp16(f).view(np.uint16))
+    finally:
+        e.close()
 
 
 def test_every_layer_close_to_oracle(eng_keep, head_outputs):
@@ -132,19 +152,54 @@ def test_fused_blocks_equal_unfused_layers(model_dir_stem_separate, model_dir_un
         e_fus.close()
 
 
-def test_stem_fused_program_close_to_oracle(eng_keep_fused, head_outputs):
-    """The default program (stem inside the first block's launch): every tensor it holds vs the fp32 oracle."""
+def test_default_program_close_to_oracle(eng_keep_fused, head_outputs):
+    """The default program (stem inside the first block's launch, blocks 0 .. 12 with split operands): every tensor it
+    holds vs the fp32 oracle.  The pair tensors (outputs of blocks 0 .. 11) carry no fp16 rounding at all: 5e-4 of the
+    tensor's range covers the unorm16 chunk buffer (step 9e-5) and fp32 summation order; block 12's output is one fp16
+    rounding of such a value; everything behind it is plain fp16 as before."""
     x_half, rbe, rlg, T = head_outputs
-    be, lg = eng_keep_fused.stage_forward(x_half)
-    names = [t[0] for t in eng_keep_fused.tensors()]
-    assert "Conv" not in names and "expanded_conv/output" in names
-    for idx, (name, h, w, c) in enumerate(eng_keep_fused.tensors()):
+    e = eng_keep_fused
+    be, lg = e.stage_forward(x_half)
+    names = [t[0] for t in e.tensors()]
+    assert "Conv" not in names and "expanded_conv/output" in names and e.hp_blocks == 13
+    n_pair = 0
+    for idx, (name, h, w, c) in enumerate(e.tensors()):
         if name == "input":
+            assert e.tensor_is_pair(idx)
             continue
-        got = np.stack([eng_keep_fused.stage_read_tensor(idx, f) for f in range(2)]).astype(np.float32)
+        got = np.stack([e.stage_read_tensor(idx, f) for f in range(2)]).astype(np.float32)
         err, scale = np.abs(got - T[name]).max(), np.abs(T[name]).max()
-        assert err <= 0.04 * scale + 0.02, "%s: max abs err %.4f (max|ref| %.3f)" % (name, err, scale)
-    assert np.abs(be - rbe).max() <= BOXENC_TOL and np.abs(lg - rlg).max() <= LOGIT_TOL
+        if e.tensor_is_pair(idx):
+            n_pair += 1
+            assert err <= 5e-4 * scale + 1e-4, "%s (pair): max abs err %.3g (max|ref| %.3f)" % (name, err, scale)
+        elif name == "expanded_conv_12/output":
+            assert err <= 1.5e-3 * scale + 1e-4, "%s: max abs err %.3g (max|ref| %.3f)" % (name, err, scale)
+        else:
+            assert err <= 0.04 * scale + 0.02, "%s: max abs err %.4f (max|ref| %.3f)" % (name, err, scale)
+    assert n_pair == 12
+    from oracle.postprocess import sigmoid
+    assert np.abs(be - rbe).max() <= BOXENC_TOL / 4 and np.abs(lg - rlg).max() <= LOGIT_TOL / 4
+    assert np.abs(sigmoid(lg) - sigmoid(rlg)).max() <= SCORE_TOL
+
+
+def test_plain_fp16_program_close_to_oracle(model_dir_plain, head_outputs):
+    """`--plain-fp16` (stem inside the first block's launch, one fp16 rounding per operand): every tensor vs the fp32 oracle."""
+    from oracle.postprocess import sigmoid
+    x_half, rbe, rlg, T = head_outputs
+    e = _keep_engine(model_dir_plain)
+    try:
+        be, lg = e.stage_forward(x_half)
+        for idx, (name, h, w, c) in enumerate(e.tensors()):
+            if name == "input":
+                continue
+            assert not e.tensor_is_pair(idx)
+            got = np.stack([e.stage_read_tensor(idx, f) for f in range(2)]).astype(np.float32)
+            err, scale = np.abs(got - T[name]).max(), np.abs(T[name]).max()
+            assert err <= 0.04 * scale + 0.02, "%s: max abs err %.4f (max|ref| %.3f)" % (name, err, scale)
+        assert np.abs(be - rbe).max() <= BOXENC_TOL and np.abs(lg - rlg).max() <= LOGIT_TOL
+        assert np.abs(sigmoid(lg) - sigmoid(rlg)).max() <= SCORE_TOL_PLAIN
+    finally:
+        e.close()
 
 
 def test_fused_blocks_with_channel_groups_close_to_unfused(eng_keep, model_dir_stem_separate, head_outputs):
@@ -319,13 +374,17 @@ def test_row_fill_bit_exact(eng, head_outputs, wh):
 
 
 def test_detect_end_to_end_matches_oracle_detector(model_dir, synth_weights, frames_640):
-    """`detect()` through the plugin class on full-resolution frames vs the oracle plugin."""
+    """`detect()` through the plugin class on full-resolution frames vs the oracle plugin: the north star's tolerance
+    (|dscore| <= 1e-3 on every matched detection row) on 9 frames over 640x480 / 1280x720 / 1920x1080, for the engine
+    `bench.py` times."""
     from watsor_amd.detection.hip_gpu import HipObjectDetector
     from watsor_amd.share import DetectionArray
     oracle = odet.OracleObjectDetector(weights=synth_weights)
+    frames = list(frames_640[:3]) + [synthetic_frame(1280, 720, 2000 + i) for i in range(3)] + \
+        [synthetic_frame(1920, 1080, 3000 + i) for i in range(3)]
     with HipObjectDetector(model_dir, 0) as det:
         assert "gfx950" in det.device_name or "MI3" in det.device_name
-        for f in frames_640[:2]:
+        for f in frames:
             rows = DetectionArray()
             ms = det.detect(f.shape, f, rows)
             assert ms > 0
@@ -338,6 +397,8 @@ def test_detect_end_to_end_matches_oracle_detector(model_dir, synth_weights, fra
             n_ref = int((ref["confidence"] > 0.1).sum())
             assert n_ref > 0 and len(missing) <= max(1, n_ref // 20), (n_ref, missing)
             assert max(abs(p[3]) for p in pairs) <= SCORE_TOL
+            every, _ = pu.match_rows(got, ref, min_score=0.0)          # ... and on every row that has a partner at all
+            assert len(every) >= 90 and max(abs(p[3]) for p in every) <= SCORE_TOL
             assert got["label"][0] == ref_rows[0].label
 
 

@@ -1,0 +1,93 @@
+"""Named mixed-precision plans for tools/err_budget.py (which operands of which layers stay plain fp16)."""
+
+
+def _idx(lab):
+    return int(lab[1:3]) if lab[0] == "b" and lab[1:3].isdigit() else None
+
+
+def cut(n, hi=("x", "x", "x"), lo=("h", "h", "h"), tail=None):
+    """blocks 0..n (and the stem) in `hi`, the rest in `lo`; `tail` overrides Conv_1/extras/heads."""
+    def plan(spec, groups):
+        cfg = {}
+        for lab, names in groups.items():
+            i = _idx(lab)
+            if lab == "stem" or (i is not None and i <= n):
+                m = hi
+            elif i is None and tail is not None:
+                m = tail
+            else:
+                m = lo
+            for nm in names:
+                cfg[nm] = m
+        return cfg
+    return plan
+
+
+PLANS = {}
+for n in range(3, 17):
+    PLANS["cut%d" % n] = cut(n)
+    PLANS["cuts%d" % n] = cut(n, hi=("s", "s", "s"))
+    # split weights + split MFMA inputs but fp16... no: outputs carried as hi+lo pairs
+
+
+def ranges(spec_str):
+    """'0-6:xxx,7-12:xhh,13-16:hhh,tail:hhh,stem:xxx' -> plan.  Triple = (weights, MFMA input, stored output)."""
+    table = {}
+    for part in spec_str.split(","):
+        key, trip = part.split(":")
+        trip = tuple(trip)
+        if key in ("tail", "stem", "heads", "conv1", "extras"):
+            table[key] = trip
+        else:
+            lo, _, hi = key.partition("-")
+            for i in range(int(lo), int(hi or lo) + 1):
+                table[i] = trip
+
+    def plan(spec, groups):
+        cfg = {}
+        for lab, names in groups.items():
+            i = _idx(lab)
+            if i is not None:
+                m = table.get((i, lab[4:]), table.get(i, ("h", "h", "h")))
+            elif lab == "stem":
+                m = table.get("stem", ("h", "h", "h"))
+            elif lab.startswith("heads"):
+                m = table.get("heads", table.get("tail", ("h", "h", "h")))
+            elif lab == "Conv_1":
+                m = table.get("conv1", table.get("tail", ("h", "h", "h")))
+            else:
+                m = table.get("extras", table.get("tail", ("h", "h", "h")))
+            for nm in names:
+                cfg[nm] = m
+        return cfg
+    return plan
+
+
+def hp(n, dw_in="u", out_last="h"):
+    """The mixed-precision program of the -p 16 engine: stem + blocks 0..n with split MFMA operands, unorm16 depthwise
+    input, fp32 depthwise weights, hi+lo block outputs (block n's output plain fp16); everything behind in plain fp16."""
+    def plan(spec, groups):
+        cfg = {}
+        for lab, names in groups.items():
+            i = _idx(lab)
+            for nm in names:
+                if lab == "stem":
+                    cfg[nm] = ("s", "s", "x")
+                elif i is not None and i <= n:
+                    kind = lab[4:]
+                    if kind == "exp":
+                        cfg[nm] = ("s", "s", "x")
+                    elif kind == "dep":
+                        cfg[nm] = ("f", dw_in, "x")
+                    else:
+                        cfg[nm] = ("s", "s", out_last if i == n else "s")
+                else:
+                    cfg[nm] = ("h", "h", "h")
+        return cfg
+    return plan
+
+
+for n in (10, 11, 12, 13, 14, 16):
+    PLANS["hp%d" % n] = hp(n)
+    PLANS["hp%dh" % n] = hp(n, dw_in="h")
+    PLANS["hp%dx" % n] = hp(n, dw_in="x")

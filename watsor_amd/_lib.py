@@ -65,6 +65,8 @@ SIGNATURES = {
     "wz_num_classes": (C.c_int, [C.c_void_p]),
     "wz_num_tensors": (C.c_int, [C.c_void_p]),
     "wz_tensor_info": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, c_i32p, c_i32p, c_i32p]),
+    "wz_tensor_flags": (C.c_int, [C.c_void_p, C.c_int]),
+    "wz_hp_blocks": (C.c_int, [C.c_void_p]),
     "wz_num_ops": (C.c_int, [C.c_void_p]),
     "wz_op_info": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, c_i32p]),
     "wz_num_stages": (C.c_int, [C.c_void_p]),

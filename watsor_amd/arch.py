@@ -45,6 +45,7 @@ class Tensor:
     h: int
     w: int
     c: int
+    hp: bool = False           # stored as a pair of fp16 planes per pixel: c "hi" halves then c "lo" halves (x = hi + lo)
 
 
 @dataclass
@@ -79,6 +80,9 @@ class Op:
     parts: Optional[list] = None
     stem: bool = False         # OP_MBCONV whose expand stage is the stem conv (3x3 s2 on the network input, K 27 -> 32)
     stem_pad: Tuple[int, int] = (0, 0)
+    block: int = -1            # OP_MBCONV: index of the inverted-residual block (expanded_conv_<block>)
+    hp: bool = False           # OP_MBCONV on the split-operand kernel (csrc/k_mbconv_hp.hip): both matrix operands as
+                               # hi + lo fp16 pairs, input (and residual) tensor stored as such a pair
 
 
 @dataclass
@@ -117,8 +121,13 @@ def _blk(i: int) -> str:
     return "expanded_conv" if i == 0 else "expanded_conv_%d" % i
 
 
-def build(size: int = INPUT_SIZE, fuse: bool = True, fuse_stem: bool = True) -> Program:
-    """fuse=True: every inverted-residual block is ONE op (OP_MBCONV); block 13 keeps its expand conv as
+HP_LAST_BLOCK = 12   # the blocks in front of the first SSD feature map (the 150x150 ... 19x19 maps)
+
+
+def build(size: int = INPUT_SIZE, fuse: bool = True, fuse_stem: bool = True, hp_upto: int = -1) -> Program:
+    """hp_upto >= 0 (needs fuse and fuse_stem): blocks 0 .. hp_upto run on the split-operand kernel and the tensors
+    between them (the network input included) are hi + lo fp16 pairs; block hp_upto's output is plain fp16 again.
+    fuse=True: every inverted-residual block is ONE op (OP_MBCONV); block 13 keeps its expand conv as
     a separate op because its output is the first SSD feature map.  fuse=False: one op per layer (the
     program the per-layer parity tests walk); both programs compute bit-identical tensors.
     fuse_stem (with fuse): the stem conv becomes the expand stage of the first block -- input image to block
@@ -151,7 +160,7 @@ def build(size: int = INPUT_SIZE, fuse: bool = True, fuse_stem: bool = True) -> 
                     ops.append(block.pop(0))
                 has_expand = t != 1 and not keep_expand
                 ops.append(Op(OP_MBCONV, FE + name, block[0].src, name + "/output", mid, c, 3, stride, ACT_NONE, True,
-                              res=res, cmid=mid, cin0=cin if has_expand else 0, parts=block))
+                              res=res, cmid=mid, cin0=cin if has_expand else 0, parts=block, block=idx))
             else:
                 ops.extend(block)
             cur, cin = name + "/output", c
@@ -173,8 +182,16 @@ def build(size: int = INPUT_SIZE, fuse: bool = True, fuse_stem: bool = True) -> 
         cur, cin = n2, d2
         taps.append(n2)
 
+    if hp_upto >= 0:
+        if not (fuse and fuse_stem) or hp_upto > HP_LAST_BLOCK:
+            raise ValueError("split-operand blocks need the fused program with the stem folded in, and end at block %d"
+                             % HP_LAST_BLOCK)
+        for op in ops:
+            if op.kind == OP_MBCONV and op.block <= hp_upto:
+                op.hp = True
+
     # shape inference
-    p.tensors["input"] = Tensor("input", size, size, 3)
+    p.tensors["input"] = Tensor("input", size, size, 3, hp=hp_upto >= 0)
     for op in ops:
         src = p.tensors[op.src]
         op.hin, op.win = src.h, src.w
@@ -184,7 +201,7 @@ def build(size: int = INPUT_SIZE, fuse: bool = True, fuse_stem: bool = True) -> 
             op.stem_pad = (st, sl)
         op.hout, op.pad_t = tf_same(op.hin, op.k, op.stride)
         op.wout, op.pad_l = tf_same(op.win, op.k, op.stride)
-        p.tensors[op.dst] = Tensor(op.dst, op.hout, op.wout, op.cout)
+        p.tensors[op.dst] = Tensor(op.dst, op.hout, op.wout, op.cout, hp=op.hp and op.block < hp_upto)
 
     # heads: BoxEncodingPredictor and ClassPredictor of a feature map read the same input, so they run
     # as ONE 3x3 conv whose output columns are [a*4 box encodings | a*91 class logits] (biases, no activation)

@@ -1,0 +1,430 @@
+// Inverted-residual block with SPLIT matrix operands: the blocks of the `-p 16` program that decide whether the
+// detector's scores stay within 1e-3 of the fp32 reference (`watsor/detection/tensorflow_cpu.py:79-90` reads fp32
+// scores; north star: "box scores within 1e-3 of the CPU reference").
+//
+// Plain fp16 storage misses that bar by 3x on this network, and tools/err_budget.py shows where the error comes
+// from: the stem and blocks 0 .. 12 (the 150x150 ... 19x19 maps), every operand about equally -- the weights, the
+// block inputs, the expanded tensor that feeds the depthwise conv, and its output that feeds the project conv.
+// Blocks 13 .. 16, Conv_1, the extras and the heads (85 % of the FLOPs) contribute 2e-4 together and stay plain.
+// So these blocks keep fp16 MFMA but carry ~22 significand bits through every operand:
+//
+//   * a value v travels as the pair hi = RN16(v), lo = RN16(v - hi); a product W.x is evaluated as
+//     Wlo.xhi + Whi.xlo + Whi.xhi on v_mfma_f32_16x16x32_f16 (fp32 accumulate; Wlo.xlo ~ 2^-22 is dropped):
+//     3 MFMAs for one -- affordable because these blocks are VALU / LDS bound, not matrix bound;
+//   * weights are split offline (watsor_amd/engine.py), block inputs / outputs / residuals are stored in HBM as
+//     pair tensors (c hi halves, then c lo halves per pixel), the depthwise output is split in registers;
+//   * the expanded tensor is a relu6 output, i.e. in [0, 6]: it goes to LDS as unorm16 of v / 6
+//     (v_cvt_pknorm_u16_f32: clamp + scale + pack in one instruction, absolute step 9e-5 -- 10 to 40 times finer
+//     than fp16 above 0.5, and the same 2 bytes), the 1/6 folded into the expand weights and the 6/65535 into the
+//     depthwise weights, which are fp32 and come straight from L2 into registers;
+//   * depthwise 3x3 in fp32 on v_cvt_f32_u32 (SDWA word select) + v_fma_f32.
+//
+// Two shapes of the same body (the structure of k_mbconv_wave.hip / k_mbconv_cs.hip):
+//   CS = false  one WAVEFRONT per pixel tile, 4 independent waves per workgroup (150x150 ... 38x38 maps);
+//               at stride 1 the lane's two output pixels are vertically adjacent, so the 4 x 3 taps under them
+//               are read once for both (12 LDS reads instead of 18);
+//   CS = true   8 waves on ONE 4x4 tile, the expanded channels dealt out over the waves, partial accumulators
+//               summed through LDS in wave order (19x19 maps).
+#include "wz_common.h"
+
+typedef __attribute__((ext_vector_type(2))) unsigned short wz_us2_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int wz_u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int wz_u32x2_t;
+
+#define HP_CS_WAVES 8
+
+__device__ __forceinline__ void wz_hp_split(const float v[8], half8_t& hi, half8_t& lo) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        hi[r] = (half_t)v[r];
+        lo[r] = (half_t)(v[r] - (float)hi[r]);
+    }
+}
+
+__device__ __forceinline__ void wz_hp_unpack(const wz_u32x4_t t, float x[8]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        x[2 * r] = (float)(t[r] & 0xffffu);
+        x[2 * r + 1] = (float)(t[r] >> 16);
+    }
+}
+
+// MPW: halo m-tiles (16 pixels) per wave, MQW: output m-tiles per wave, KCI: 32-channel K chunks of the expand conv,
+// NTO: 16-column tiles of the project output.  STEM: the "expand" stage is the stem convolution gathered from the
+// 300x300 input pair tensor (8 halves per pixel: r g b 0 hi | r g b 0 lo), as in k_mbconv_wave.hip.
+template <bool CS, bool STEM, int MPW, int MQW, int KCI, int NTO>
+__global__ __launch_bounds__(CS ? HP_CS_WAVES * 64 : 256, 2) void wz_k_mbconv_hp(const WzMbArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wz_hp_smem[];
+    constexpr int NW = CS ? HP_CS_WAVES : 4;
+    constexpr int ES = 40;                               // unorm16 per row of the chunk buffer: 32 channels + 8 of padding
+    constexpr int EBYTES = MPW * 16 * ES * 2;
+    constexpr int RED_BYTES = CS ? NW * MQW * NTO * 1024 : 0;
+    constexpr int REGION = (NW * EBYTES > RED_BYTES) ? NW * EBYTES : RED_BYTES;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    unsigned short* const E = reinterpret_cast<unsigned short*>(wz_hp_smem + wave * EBYTES);
+    float* const bd_l = reinterpret_cast<float*>(wz_hp_smem + REGION);   // [cmid_pad] depthwise bias
+    float* const be_l = bd_l + a.cmid_pad;                               // [cmid_pad] expand bias (already / 6)
+    const float* const wd32 = reinterpret_cast<const float*>(a.wd);      // [9][cmid_pad], already * 6 / 65535
+    // CS: 8 waves share a CU and 256 registers each -- the depthwise weights are staged in LDS once and read where they
+    // are used (broadcast reads); !CS: they come from L2 into registers at the top of a pass (LDS is the busy unit there)
+    float* const wd_l = be_l + a.cmid_pad;                               // CS only: [9][cmid_pad]
+
+    if constexpr (CS)
+        for (int i = threadIdx.x; i < 9 * (a.cmid_pad >> 2); i += NW * 64)
+            *reinterpret_cast<float4_t*>(wd_l + i * 4) = *reinterpret_cast<const float4_t*>(wd32 + (size_t)i * 4);
+    for (int i = threadIdx.x; i < (a.cmid_pad >> 2); i += NW * 64) {
+        *reinterpret_cast<float4_t*>(bd_l + i * 4) = *reinterpret_cast<const float4_t*>(a.bd + i * 4);
+        *reinterpret_cast<float4_t*>(be_l + i * 4) = (i * 4 < a.nmid_pad) ? *reinterpret_cast<const float4_t*>(a.be + i * 4)
+                                                                          : (float4_t){0.f, 0.f, 0.f, 0.f};
+    }
+
+    // ---- the tile of this wave (CS: of this workgroup)
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int wt = CS ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
+    const bool live = wt < tiles * a.nb;                  // wave-uniform; dead waves still take the barrier below
+    const int wtc = live ? wt : 0;
+    const int b = wtc / tiles, t = wtc - b * tiles;
+    const int tyi = t / a.tiles_x;
+    const int oy0 = tyi * a.th, ox0 = (t - tyi * a.tiles_x) * a.tw;
+    const int s = a.stride;
+    const int hw_ = (a.tw - 1) * s + 3, hh_ = (a.th - 1) * s + 3;
+    const int P = hh_ * hw_;
+    const int iy_base = oy0 * s - a.pad_t, ix_base = ox0 * s - a.pad_l;
+    const half8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    int hp0[MQW], opix[MQW];
+#pragma unroll
+    for (int j = 0; j < MQW; ++j) {
+        int qy, qx;
+        if constexpr (MQW == 2) {      // 4 x 8 tile at stride 1: output j of a lane sits right below output j - 1
+            qx = r16 & 7;
+            qy = ((r16 >> 3) << 1) + j;
+        } else {                       // 4 x 4 tile
+            qy = r16 >> 2;
+            qx = r16 & 3;
+        }
+        hp0[j] = qy * s * hw_ + qx * s;
+        const int oy = oy0 + qy, ox = ox0 + qx;
+        opix[j] = (live && oy < a.hout && ox < a.wout) ? (b * a.hout + oy) * a.wout + ox : -1;
+    }
+
+    // ---- halo pixels of this lane: input channels as B fragments, hi and lo
+    half8_t xh[MPW][KCI], xl[MPW][KCI];
+    bool inimg[MPW];
+#pragma unroll
+    for (int i = 0; i < MPW; ++i) {
+        const int p = i * 16 + r16;
+        const int hy = p / hw_, hx = p - hy * hw_;
+        const int iy = iy_base + hy, ix = ix_base + hx;
+        const bool ok = live && p < P && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
+        inimg[i] = ok;
+        if constexpr (STEM) {
+            // k = g*8 + j = (ky*3 + kx)*3 + c: this lane needs taps tb .. tb+3 with tb = (g*8)/3 = {0, 2, 5, 8}
+            const int tb = (g * 8) / 3;
+            half4_t tph[4], tpl[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int tq = tb + q;
+                const int ky = tq / 3, kx = tq - ky * 3;
+                const int sy = iy * 2 - a.spad_t + ky, sx = ix * 2 - a.spad_l + kx;   // stem: stride 2 on the input image
+                const bool in = ok && tq < 9 && sy >= 0 && sy < a.sin_h && sx >= 0 && sx < a.sin_w;
+                const int cy = min(max(sy, 0), a.sin_h - 1), cx = min(max(sx, 0), a.sin_w - 1);
+                const half8_t v = *reinterpret_cast<const half8_t*>(a.in + ((size_t)(b * a.sin_h + cy) * a.sin_w + cx) * 8);
+                tph[q] = in ? (half4_t){v[0], v[1], v[2], v[3]} : (half4_t){0, 0, 0, 0};
+                tpl[q] = in ? (half4_t){v[4], v[5], v[6], v[7]} : (half4_t){0, 0, 0, 0};
+            }
+            half8_t x, y;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                half_t eh[4], el[4];
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) {
+                    const int k = gg * 8 + j;
+                    eh[gg] = k < 27 ? tph[k / 3 - (gg * 8) / 3][k % 3] : (half_t)0.0f;
+                    el[gg] = k < 27 ? tpl[k / 3 - (gg * 8) / 3][k % 3] : (half_t)0.0f;
+                }
+                x[j] = g == 0 ? eh[0] : g == 1 ? eh[1] : g == 2 ? eh[2] : eh[3];
+                y[j] = g == 0 ? el[0] : g == 1 ? el[1] : g == 2 ? el[2] : el[3];
+            }
+            xh[i][0] = x;
+            xl[i][0] = y;
+        } else {
+            const half_t* src = a.in + ((size_t)(b * a.hin + (ok ? iy : 0)) * a.win + (ok ? ix : 0)) * (2 * a.cin0);
+#pragma unroll
+            for (int c = 0; c < KCI; ++c) {
+                const int k0 = c * 32 + g * 8;
+                const bool kok = ok && k0 < a.cin0;
+                xh[i][c] = kok ? *reinterpret_cast<const half8_t*>(src + k0) : zero8;
+                xl[i][c] = kok ? *reinterpret_cast<const half8_t*>(src + a.cin0 + k0) : zero8;
+            }
+        }
+    }
+
+    float4_t acc[MQW][NTO];
+#pragma unroll
+    for (int j = 0; j < MQW; ++j)
+#pragma unroll
+        for (int nt = 0; nt < NTO; ++nt) acc[j][nt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int nk32 = a.cmid_pad >> 5;                     // 32-channel chunks in all
+    const int ntiles_e = a.nmid_pad >> 4;
+    constexpr int STEP = CS ? NW : 1;
+    const int ps0 = CS ? wave : 0;
+    half8_t wah[2][KCI], wal[2][KCI];
+    auto load_wa = [&](int ps) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int tn = min(ps * 2 + nt, ntiles_e - 1);   // beyond the packed tiles: clamped, never used (see `have`)
+            const size_t off = ((size_t)tn * a.kc0 * 64 + lane) * 8;
+#pragma unroll
+            for (int c = 0; c < KCI; ++c) {
+                wah[nt][c] = *reinterpret_cast<const half8_t*>(a.we + off + (size_t)c * 512);
+                wal[nt][c] = *reinterpret_cast<const half8_t*>(a.we_lo + off + (size_t)c * 512);
+            }
+        }
+    };
+    if (ps0 < nk32) load_wa(ps0);
+    __syncthreads();   // staged biases visible; the only workgroup barrier in front of the loop
+    if (!CS && !live) return;
+
+    for (int ps = ps0; ps < nk32; ps += STEP) {
+        const int ce0 = ps * 32;
+        const int coff = ce0 + g * 8;
+        // operands of the later phases, in flight under the expand stage: project fragments, depthwise weights
+        half8_t wph[NTO], wpl[NTO];
+#pragma unroll
+        for (int nt = 0; nt < NTO; ++nt) {
+            const size_t off = ((size_t)(nt * a.kc + ps) * 64 + lane) * 8;
+            wph[nt] = *reinterpret_cast<const half8_t*>(a.wp + off);
+            wpl[nt] = *reinterpret_cast<const half8_t*>(a.wp_lo + off);
+        }
+        float4_t wt0[CS ? 1 : 9], wt1[CS ? 1 : 9];
+        if constexpr (!CS) {
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                wt0[tp] = *reinterpret_cast<const float4_t*>(wd32 + (size_t)tp * a.cmid_pad + coff);
+                wt1[tp] = *reinterpret_cast<const float4_t*>(wd32 + (size_t)tp * a.cmid_pad + coff + 4);
+            }
+        }
+        // ---- expand: E[p][ce] = in-frame ? unorm16(clamp((sum_k X[p][k] We[k][ce] + be[ce]) / 6, 0, 1)) : 0
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const bool have = ce0 + nt * 16 < a.nmid_pad;    // this 16-channel tile exists (wave-uniform)
+            const float4_t bv = *reinterpret_cast<const float4_t*>(be_l + ce0 + nt * 16 + g * 4);
+#pragma unroll
+            for (int i = 0; i < MPW; ++i) {
+                float4_t d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < KCI; ++c) d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wal[nt][c], xh[i][c], d, 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < KCI; ++c) d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wah[nt][c], xl[i][c], d, 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < KCI; ++c) d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wah[nt][c], xh[i][c], d, 0, 0, 0);
+                const bool keep = inimg[i] && have;
+                const wz_us2_t p0 = __builtin_amdgcn_cvt_pknorm_u16(d[0] + bv[0], d[1] + bv[1]);
+                const wz_us2_t p1 = __builtin_amdgcn_cvt_pknorm_u16(d[2] + bv[2], d[3] + bv[3]);
+                wz_u32x2_t o;
+                o[0] = keep ? __builtin_bit_cast(unsigned int, p0) : 0u;
+                o[1] = keep ? __builtin_bit_cast(unsigned int, p1) : 0u;
+                *reinterpret_cast<wz_u32x2_t*>(E + (i * 16 + r16) * ES + nt * 16 + g * 4) = o;
+            }
+        }
+        if (ps + STEP < nk32) load_wa(ps + STEP);   // next pass's expand fragments, in flight under the depthwise stage
+        // the wave's own LDS writes are ordered before its reads by the LDS queue; keep the compiler from moving the reads up
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // ---- depthwise (lane = output pixel x 8 channels), fp32
+        const float4_t b0 = *reinterpret_cast<const float4_t*>(bd_l + coff);
+        const float4_t b1 = *reinterpret_cast<const float4_t*>(bd_l + coff + 4);
+        float dd[MQW][8];
+#pragma unroll
+        for (int j = 0; j < MQW; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { dd[j][r] = b0[r]; dd[j][4 + r] = b1[r]; }
+        if constexpr (MQW == 2) {
+            // rows hp0 .. hp0 + 3 of the halo serve both outputs: row rr is tap row rr of output 0 and rr - 1 of output 1
+            const unsigned short* ep = E + hp0[0] * ES + g * 8;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    float x[8];
+                    wz_hp_unpack(*reinterpret_cast<const wz_u32x4_t*>(ep + (rr * hw_ + kx) * ES), x);
+                    if (rr < 3) {
+                        const int tp = rr * 3 + kx;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            dd[0][r] = fmaf(x[r], wt0[tp][r], dd[0][r]);
+                            dd[0][4 + r] = fmaf(x[4 + r], wt1[tp][r], dd[0][4 + r]);
+                        }
+                    }
+                    if (rr > 0) {
+                        const int tp = (rr - 1) * 3 + kx;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            dd[1][r] = fmaf(x[r], wt0[tp][r], dd[1][r]);
+                            dd[1][4 + r] = fmaf(x[4 + r], wt1[tp][r], dd[1][4 + r]);
+                        }
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int j = 0; j < MQW; ++j) {
+                const unsigned short* ep = E + hp0[j] * ES + g * 8;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        float x[8];
+                        wz_hp_unpack(*reinterpret_cast<const wz_u32x4_t*>(ep + (ky * hw_ + kx) * ES), x);
+                        const int tp = ky * 3 + kx;
+                        const float4_t w0 = CS ? *reinterpret_cast<const float4_t*>(wd_l + tp * a.cmid_pad + coff) : wt0[CS ? 0 : tp];
+                        const float4_t w1 = CS ? *reinterpret_cast<const float4_t*>(wd_l + tp * a.cmid_pad + coff + 4) : wt1[CS ? 0 : tp];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            dd[j][r] = fmaf(x[r], w0[r], dd[j][r]);
+                            dd[j][4 + r] = fmaf(x[4 + r], w1[r], dd[j][4 + r]);
+                        }
+                    }
+            }
+        }
+        // ---- relu6, split, project: acc += Wlo.dhi + Whi.dlo + Whi.dhi
+#pragma unroll
+        for (int j = 0; j < MQW; ++j) {
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = fminf(fmaxf(dd[j][r], 0.0f), 6.0f);
+            half8_t bh, bl;
+            wz_hp_split(v, bh, bl);
+#pragma unroll
+            for (int nt = 0; nt < NTO; ++nt) acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wpl[nt], bh, acc[j][nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NTO; ++nt) acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wph[nt], bl, acc[j][nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NTO; ++nt) acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wph[nt], bh, acc[j][nt], 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // (the next pass's E stores stay behind these reads)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+
+    // ---- epilogue: + bias, + residual (a pair tensor like the input), store as a pair or as one half
+    const int ostride = a.hp_out ? 2 * a.cout : a.cout;
+    auto finish = [&](float4_t v, int op, int n4) {
+        const float4_t bv = *reinterpret_cast<const float4_t*>(a.bp + n4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += bv[r];
+        if (a.res) {
+            const half_t* rp = a.res + (size_t)op * (2 * a.cout) + n4;
+            const half4_t rh = *reinterpret_cast<const half4_t*>(rp);
+            const half4_t rl = *reinterpret_cast<const half4_t*>(rp + a.cout);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (float)rh[r] + (float)rl[r];
+        }
+        half4_t oh, ol;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            oh[r] = (half_t)v[r];
+            ol[r] = (half_t)(v[r] - (float)oh[r]);
+        }
+        half_t* const dst = a.out + (size_t)op * ostride + n4;
+        *reinterpret_cast<half4_t*>(dst) = oh;
+        if (a.hp_out) *reinterpret_cast<half4_t*>(dst + a.cout) = ol;
+    };
+
+    if constexpr (!CS) {
+#pragma unroll
+        for (int j = 0; j < MQW; ++j) {
+            if (opix[j] < 0) continue;
+#pragma unroll
+            for (int nt = 0; nt < NTO; ++nt) {
+                const int n4 = nt * 16 + g * 4;
+                if (n4 >= a.cout) continue;
+                finish(acc[j][nt], opix[j], n4);
+            }
+        }
+    } else {
+        // the 8 waves' accumulators meet in LDS (over the chunk buffers); tile (j, nt) is summed by wave
+        // (j*NTO + nt) % 8 in the order wave 0 .. 7 (deterministic)
+        float* const red = reinterpret_cast<float*>(wz_hp_smem);
+        __syncthreads();   // every wave is done with its chunk buffer
+#pragma unroll
+        for (int j = 0; j < MQW; ++j)
+#pragma unroll
+            for (int nt = 0; nt < NTO; ++nt)
+                *reinterpret_cast<float4_t*>(red + ((size_t)((wave * MQW + j) * NTO + nt) * 64 + lane) * 4) = acc[j][nt];
+        __syncthreads();
+        for (int pr = wave; pr < MQW * NTO; pr += NW) {
+            const int j = pr / NTO, nt = pr - j * NTO;
+            float4_t v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const float4_t pz = *reinterpret_cast<const float4_t*>(red + ((size_t)((w * MQW + j) * NTO + nt) * 64 + lane) * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += pz[r];
+            }
+            int op = -1;
+#pragma unroll
+            for (int jj = 0; jj < MQW; ++jj)
+                if (jj == j) op = opix[jj];
+            const int n4 = nt * 16 + g * 4;
+            if (op < 0 || n4 >= a.cout) continue;
+            finish(v, op, n4);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <bool CS, bool STEM, int MPW, int MQW, int KCI, int NTO>
+static int wz_hp_launch(WzMbArgs a, int n, hipStream_t s, bool prepare) {
+    a.nb = n;
+    constexpr int NW = CS ? HP_CS_WAVES : 4;
+    constexpr int EB = MPW * 16 * 40 * 2;
+    constexpr int RED = CS ? NW * MQW * NTO * 1024 : 0;
+    const size_t region = (size_t)(NW * EB > RED ? NW * EB : RED);
+    const size_t lds = region + (size_t)a.cmid_pad * (CS ? 8 + 36 : 8);
+    auto k = wz_k_mbconv_hp<CS, STEM, MPW, MQW, KCI, NTO>;
+    if (prepare) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return lds <= 160 * 1024 ? 0 : -1;
+    }
+    const int tiles = a.tiles_x * a.tiles_y * n;
+    hipLaunchKernelGGL(k, dim3(CS ? tiles : (tiles + 3) / 4), dim3(NW * 64), lds, s, a);
+    return 1;
+}
+
+// Blocks 0 (with the stem) .. 12 of SSD-MobileNet-v2 300x300.  prepare: 0 = a kernel exists (its attributes are set),
+// -1 = no kernel for this shape; launch: 1.
+int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) {
+    const int nto = a0.n_pad / 16;
+    WzMbArgs a = a0;
+    a.nsplit = 1;
+    if (a.nmid_pad != a.cmid_pad || (a.cmid_pad & 31) || a.kc != (a.cmid_pad >> 5) || !a.we_lo || !a.wp_lo) return -1;
+    if (a.stem || a.wout >= 38) {   // one wavefront per tile
+        if (a.kc0 != 1 || nto != 2) return -1;
+        if (a.stride == 1) { a.th = 4; a.tw = 8; } else { a.th = 4; a.tw = 4; }
+        a.tiles_y = (a.hout + a.th - 1) / a.th;
+        a.tiles_x = (a.wout + a.tw - 1) / a.tw;
+        if (a.stem) return a.stride == 1 ? wz_hp_launch<false, true, 4, 2, 1, 2>(a, n, s, prepare) : -1;
+        if (a.cin0 == 0) return -1;
+        if (a.stride == 1) return wz_hp_launch<false, false, 4, 2, 1, 2>(a, n, s, prepare);   // halo 6 x 10 = 60 pixels
+        return wz_hp_launch<false, false, 6, 1, 1, 2>(a, n, s, prepare);                       // halo 9 x 9 = 81 pixels
+    }
+    if (a.cin0 == 0) return -1;
+    a.th = 4; a.tw = 4;
+    a.tiles_y = (a.hout + a.th - 1) / a.th;
+    a.tiles_x = (a.wout + a.tw - 1) / a.tw;
+    if (a.stride == 2) {
+        if (a.kc0 == 1 && nto == 4) return wz_hp_launch<true, false, 6, 1, 1, 4>(a, n, s, prepare);
+        return -1;
+    }
+#define HP_CASE(K, N) if (a.kc0 == K && nto == N) return wz_hp_launch<true, false, 3, 1, K, N>(a, n, s, prepare)
+    HP_CASE(2, 4);
+    HP_CASE(2, 6);
+    HP_CASE(3, 6);
+#undef HP_CASE
+    return -1;
+}

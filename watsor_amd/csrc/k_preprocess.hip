@@ -12,6 +12,10 @@
 #pragma clang fp contract(off)
 #include "wz_common.h"
 
+// HP: the network input is stored as a hi + lo pair of halves per value (hi = RN16(v), lo = RN16(v - hi), both
+// roundings and the subtraction exact-or-once-rounded fp32 operations): the first blocks of the `-p 16` program take
+// both (k_mbconv_hp.hip), which removes the 2^-11 input rounding from the error budget of the scores.
+template <bool HP>
 __global__ __launch_bounds__(256) void wz_k_preprocess(const WzFrameDesc* __restrict__ frames, int size,
                                                        half_t* __restrict__ out) {
     const WzFrameDesc f = frames[blockIdx.y];
@@ -32,7 +36,7 @@ __global__ __launch_bounds__(256) void wz_k_preprocess(const WzFrameDesc* __rest
 
     const uint8_t* r0 = f.rgb + (size_t)y_lo * f.w * 3;
     const uint8_t* r1 = f.rgb + (size_t)y_hi * f.w * 3;
-    half_t v[4];
+    half_t v[4], vl[4];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float tl = (float)r0[x_lo * 3 + c], tr = (float)r0[x_hi * 3 + c];
@@ -42,13 +46,22 @@ __global__ __launch_bounds__(256) void wz_k_preprocess(const WzFrameDesc* __rest
         const float px = top + (bot - top) * ly;
         const float nv = (2.0f / 255.0f) * px - 1.0f;
         v[c] = (half_t)nv;   // round-to-nearest-even
+        vl[c] = (half_t)(nv - (float)v[c]);
     }
-    v[3] = (half_t)0.0f;
-    half4_t o = {v[0], v[1], v[2], v[3]};
-    *reinterpret_cast<half4_t*>(out + ((size_t)blockIdx.y * size * size + pix) * 4) = o;
+    v[3] = vl[3] = (half_t)0.0f;
+    if constexpr (HP) {
+        const half8_t o = {v[0], v[1], v[2], v[3], vl[0], vl[1], vl[2], vl[3]};
+        *reinterpret_cast<half8_t*>(out + ((size_t)blockIdx.y * size * size + pix) * 8) = o;
+    } else {
+        const half4_t o = {v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<half4_t*>(out + ((size_t)blockIdx.y * size * size + pix) * 4) = o;
+    }
 }
 
-void wz_launch_preprocess(const WzFrameDesc* d_frames, int n, int size, half_t* out, hipStream_t s) {
+void wz_launch_preprocess(const WzFrameDesc* d_frames, int n, int size, half_t* out, hipStream_t s, bool hp) {
     dim3 grid((size * size + 255) / 256, n);
-    hipLaunchKernelGGL(wz_k_preprocess, grid, dim3(256), 0, s, d_frames, size, out);
+    if (hp)
+        hipLaunchKernelGGL(wz_k_preprocess<true>, grid, dim3(256), 0, s, d_frames, size, out);
+    else
+        hipLaunchKernelGGL(wz_k_preprocess<false>, grid, dim3(256), 0, s, d_frames, size, out);
 }

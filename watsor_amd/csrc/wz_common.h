@@ -83,6 +83,10 @@ struct WzMbArgs {
     int32_t M;             // n * hout * wout
     unsigned long long* dbg;   // diagnostics: 16 timestamps (first / last workgroup), or nullptr
     int32_t th, tw, tiles_y, tiles_x, nsplit, cpg, stage, ebufs, nb;   // filled in by the launcher (nb = frames)
+    // split-operand blocks (k_mbconv_hp.hip): `in` / `res` are hi + lo pair tensors, `wd` points at float[9][cmid_pad]
+    const half_t* we_lo;   // "lo" halves of the expand weights (we = "hi")
+    const half_t* wp_lo;   // "lo" halves of the project weights
+    int32_t hp, hp_out;    // hp: this block runs on the split-operand kernel; hp_out: `out` is a hi + lo pair tensor
 };
 
 // Per-camera filter state resident in HBM (see wz_set_camera_filter).
@@ -103,7 +107,8 @@ struct WzPostConsts {
 };
 
 // ---- launchers (each enqueues exactly one kernel on `s`) ------------------------------------
-void wz_launch_preprocess(const WzFrameDesc* d_frames, int n, int size, half_t* out, hipStream_t s);
+// hp: the input tensor is a hi + lo pair (8 halves per pixel: r g b 0 | r g b 0)
+void wz_launch_preprocess(const WzFrameDesc* d_frames, int n, int size, half_t* out, hipStream_t s, bool hp = false);
 void wz_launch_stem(const half_t* in, const float* w, const float* bias, half_t* out, int n, int hin, int win,
                     int hout, int wout, int pad_t, int pad_l, hipStream_t s);
 void wz_launch_dw(const half_t* in, const half_t* w, const float* bias, half_t* out, int n, int hin, int win,
@@ -169,6 +174,7 @@ void wz_launch_conv_f32(const WzConvArgs& a, hipStream_t s, bool reduce = true);
 int wz_launch_mbconv(const WzMbArgs& a, int n, hipStream_t s, bool prepare);   // -1: no kernel; else #channel groups
 int wz_launch_mbconv_wave(const WzMbArgs& a, int n, hipStream_t s, bool prepare);   // wave-per-tile variant; -2: not applicable
 int wz_launch_mbconv_cs(const WzMbArgs& a, int n, hipStream_t s, bool prepare);     // channels split over waves (small maps); -2: n/a
+int wz_launch_mbconv_hp(const WzMbArgs& a, int n, hipStream_t s, bool prepare);     // split-operand blocks; -1: no kernel for this shape
 
 #define WZ_HIST_BINS 1024
 #define WZ_CAND_CAP 4096

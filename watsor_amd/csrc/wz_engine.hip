@@ -127,6 +127,14 @@ struct wz_engine {
 };
 
 static int input_tensor_index(wz_engine* e) { return e->ops[0].src; }
+static bool tensor_is_pair(wz_engine* e, int idx) { return (e->tensors[idx].flags & WZ_TENSOR_HP) != 0; }
+static bool input_is_pair(wz_engine* e) { return tensor_is_pair(e, input_tensor_index(e)); }
+// bytes of one frame of tensor idx (pair tensors hold two halves per value; the input tensor is fp16 in both engines)
+static size_t tensor_frame_bytes(wz_engine* e, int idx) {
+    const WzTensorDesc& t = e->tensors[idx];
+    const size_t es = idx == input_tensor_index(e) ? 2 : e->hdr.precision / 8;
+    return (size_t)t.h * t.w * t.c * es * (tensor_is_pair(e, idx) ? 2 : 1);
+}
 typedef wz_engine::Lane Lane;
 
 // ------------------------------------------------------------------------------------------------
@@ -137,8 +145,8 @@ static WzMbArgs mb_args(wz_engine* e, const Lane& L, const WzOpDesc& op) {
     WzMbArgs a;
     memset(&a, 0, sizeof(a));
     a.in = L.tptr.empty() ? nullptr : L.tptr[op.src];
-    a.we = op.cin0 > 0 ? (const half_t*)(wbase + op.we_off) : nullptr;
-    a.be = op.cin0 > 0 ? (const float*)(wbase + op.be_off) : nullptr;
+    a.we = (op.cin0 > 0 || op.stem) ? (const half_t*)(wbase + op.we_off) : nullptr;
+    a.be = (op.cin0 > 0 || op.stem) ? (const float*)(wbase + op.be_off) : nullptr;
     a.wd = (const half_t*)(wbase + op.wd_off);
     a.bd = (const float*)(wbase + op.bd_off);
     a.wp = (const half_t*)(wbase + op.w_off);
@@ -150,6 +158,12 @@ static WzMbArgs mb_args(wz_engine* e, const Lane& L, const WzOpDesc& op) {
     a.cmid = op.cmid; a.cmid_pad = op.cmid_pad; a.kc = op.kc;
     a.cout = op.cout; a.n_pad = op.n_pad;
     a.stride = op.stride; a.pad_t = op.pad_t; a.pad_l = op.pad_l;
+    a.hp = (op.flags & WZ_OPF_HP) ? 1 : 0;
+    a.hp_out = (op.flags & WZ_OPF_HP_OUT) ? 1 : 0;
+    if (a.hp) {
+        a.we_lo = (const half_t*)(wbase + op.we_lo_off);
+        a.wp_lo = (const half_t*)(wbase + op.w_lo_off);
+    }
     a.stem = op.stem;
     if (op.stem) {
         const WzTensorDesc& in = e->tensors[op.src];
@@ -200,7 +214,8 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
             a.ws = e->use_splitk ? L.d_ws : nullptr;
             a.ws_bytes = ws_top;
             a.dbg = e->d_mbdbg ? e->d_mbdbg + (size_t)i * 16 : nullptr;
-            int groups = wz_launch_mbconv_wave(a, n, s, false);   // large maps: one wavefront per pixel tile
+            int groups = a.hp ? wz_launch_mbconv_hp(a, n, s, false)   // split-operand blocks (the `-p 16` program's first 13)
+                              : wz_launch_mbconv_wave(a, n, s, false);   // large maps: one wavefront per pixel tile
             if (groups == -2 && e->use_splitk) groups = wz_launch_mbconv_cs(a, n, s, false);   // small maps: channels over waves
             if (groups == -2) groups = wz_launch_mbconv(a, n, s, false);
             if (e->d_mbdbg) e->mb_groups[i] = groups;
@@ -385,7 +400,7 @@ static void enqueue_batch(wz_engine* e, Lane& L, int n, StageTimer* t) {
     if (t) t->mark();   // "(empty)": two event records with nothing between them = the bracket's own cost
     (void)hipMemcpyAsync(L.d_desc, L.h_desc, sizeof(WzFrameDesc) * n, hipMemcpyHostToDevice, s);
     if (t) t->mark();
-    wz_launch_preprocess(L.d_desc, n, (int)e->hdr.input_size, L.tptr[input_tensor_index(e)], s);
+    wz_launch_preprocess(L.d_desc, n, (int)e->hdr.input_size, L.tptr[input_tensor_index(e)], s, input_is_pair(e));
     if (t) t->mark();
     enqueue_network(e, L, n, t);
     enqueue_post(e, L, true, n, t, L.decode_fused, L.cands_listed);
@@ -483,7 +498,19 @@ static int load_blob(wz_engine* e, const char* path) {
             return wz_fail(WZ_EFORMAT, "%s: fused blocks exist for the fp16 engine only", path);
         if (h.precision == 32 && ((op.kind == WZ_OP_CONV && op.cin % 4 != 0) || (op.kind == WZ_OP_DW && op.cin % 4 != 0)))
             return wz_fail(WZ_EFORMAT, "%s: op %u (%s) is malformed", path, i, op.name);
-        if (op.kind == WZ_OP_MBCONV && op.stem) {
+        if (op.kind == WZ_OP_MBCONV && (op.flags & WZ_OPF_HP)) {
+            if (!(e->tensors[op.src].flags & WZ_TENSOR_HP) || (op.res >= 0 && op.res != op.src) ||
+                ((op.flags & WZ_OPF_HP_OUT) != 0) != ((e->tensors[op.dst].flags & WZ_TENSOR_HP) != 0) ||
+                op.we_lo_off <= 0 || (uint64_t)op.we_lo_off >= h.weights_bytes || op.w_lo_off <= 0 ||
+                (uint64_t)op.w_lo_off >= h.weights_bytes || (op.stem && e->tensors[op.src].c != 4))
+                return wz_fail(WZ_EFORMAT, "%s: op %u (%s): malformed split-operand block", path, i, op.name);
+            wz_engine::Lane none;
+            if (wz_launch_mbconv_hp(mb_args(e, none, op), 1, nullptr, true) != 0)
+                return wz_fail(WZ_EFORMAT, "%s: op %u (%s): no split-operand kernel for this shape", path, i, op.name);
+        } else if ((e->tensors[op.src].flags & WZ_TENSOR_HP) || (op.dst >= 0 && (e->tensors[op.dst].flags & WZ_TENSOR_HP)) ||
+                   (op.res >= 0 && (e->tensors[op.res].flags & WZ_TENSOR_HP))) {
+            return wz_fail(WZ_EFORMAT, "%s: op %u (%s) touches a pair tensor but is not a split-operand block", path, i, op.name);
+        } else if (op.kind == WZ_OP_MBCONV && op.stem) {
             if (e->tensors[op.src].c != 4 || op.cin0 != 32 || op.kc0 != 1 || (e->tensors[op.src].h + 1) / 2 != op.hin ||
                 (e->tensors[op.src].w + 1) / 2 != op.win)
                 return wz_fail(WZ_EFORMAT, "%s: op %u (%s): malformed stem fusion", path, i, op.name);
@@ -548,6 +575,10 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     for (uint32_t i = 0; i < e->hdr.n_ops; ++i)   // kernel attributes of the fused-block kernels, on THIS device
         if (e->ops[i].kind == WZ_OP_MBCONV) {
             wz_engine::Lane none;
+            if (e->ops[i].flags & WZ_OPF_HP) {
+                (void)wz_launch_mbconv_hp(mb_args(e, none, e->ops[i]), max_batch, nullptr, true);
+                continue;
+            }
             if (!e->ops[i].stem) (void)wz_launch_mbconv(mb_args(e, none, e->ops[i]), max_batch, nullptr, true);
             (void)wz_launch_mbconv_wave(mb_args(e, none, e->ops[i]), max_batch, nullptr, true);
             (void)wz_launch_mbconv_cs(mb_args(e, none, e->ops[i]), max_batch, nullptr, true);
@@ -593,7 +624,8 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
             for (uint32_t i = 0; i < h.n_tensors; ++i) {
                 const WzTensorDesc& t = e->tensors[i];
                 void* p = nullptr;
-                CK(hipMalloc(&p, (size_t)max_batch * t.h * t.w * t.c * (h.precision / 8) + 256));
+                (void)t;
+                CK(hipMalloc(&p, (size_t)max_batch * tensor_frame_bytes(e, i) + 256));
                 L.bufs.push_back(p);
                 L.tptr[i] = (half_t*)p;
             }
@@ -601,7 +633,7 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
             std::vector<size_t> slot_bytes(h.n_slots, 0);
             for (uint32_t i = 0; i < h.n_tensors; ++i) {
                 const WzTensorDesc& t = e->tensors[i];
-                const size_t b = (size_t)max_batch * t.h * t.w * t.c * (h.precision / 8) + 256;
+                const size_t b = (size_t)max_batch * tensor_frame_bytes(e, i) + 256;
                 if (b > slot_bytes[t.slot]) slot_bytes[t.slot] = b;
             }
             for (uint32_t sidx = 0; sidx < h.n_slots; ++sidx) {
@@ -959,6 +991,13 @@ extern "C" int wz_tensor_info(wz_engine_t* e, int idx, char* name, int namelen, 
     return WZ_OK;
 }
 
+extern "C" int wz_tensor_flags(wz_engine_t* e, int idx) {
+    if (!e || idx < 0 || idx >= (int)e->hdr.n_tensors) return wz_fail(WZ_EINVAL, "tensor index %d", idx);
+    return e->tensors[idx].flags;
+}
+
+extern "C" int wz_hp_blocks(wz_engine_t* e) { return e ? (int)e->hdr.hp_blocks : 0; }
+
 extern "C" int wz_op_info(wz_engine_t* e, int idx, char* name, int namelen, int* dims) {
     if (!e || idx < 0 || idx >= (int)e->hdr.n_ops) return wz_fail(WZ_EINVAL, "op index %d", idx);
     const WzOpDesc& o = e->ops[idx];
@@ -1068,9 +1107,10 @@ extern "C" int wz_stage_preprocess(wz_engine_t* e, const uint8_t* rgb, int w, in
     if (rc != WZ_OK) return rc;
     HIPCHK(hipMemcpyAsync(e->lanes[0].d_desc, e->lanes[0].h_desc, sizeof(WzFrameDesc), hipMemcpyHostToDevice, e->stream));
     const int S = (int)e->hdr.input_size;
-    wz_launch_preprocess(e->lanes[0].d_desc, 1, S, e->lanes[0].tptr[input_tensor_index(e)], e->stream);
+    wz_launch_preprocess(e->lanes[0].d_desc, 1, S, e->lanes[0].tptr[input_tensor_index(e)], e->stream, input_is_pair(e));
     HIPCHK(hipStreamSynchronize(e->stream));
-    HIPCHK(hipMemcpy(out_half, e->lanes[0].tptr[input_tensor_index(e)], (size_t)S * S * 4 * 2, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(out_half, e->lanes[0].tptr[input_tensor_index(e)], tensor_frame_bytes(e, input_tensor_index(e)),
+                     hipMemcpyDeviceToHost));
     return WZ_OK;
 }
 
@@ -1080,7 +1120,13 @@ extern "C" int wz_stage_forward(wz_engine_t* e, int n, const uint16_t* in_half, 
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
     const int S = (int)e->hdr.input_size;
-    HIPCHK(hipMemcpy(e->lanes[0].tptr[input_tensor_index(e)], in_half, (size_t)n * S * S * 4 * 2, hipMemcpyHostToDevice));
+    if (input_is_pair(e)) {   // the given halves are the "hi" parts, the "lo" parts are zero (the input is exactly these halves)
+        std::vector<uint16_t> pair((size_t)n * S * S * 8, 0);
+        for (size_t px = 0; px < (size_t)n * S * S; ++px) memcpy(&pair[px * 8], in_half + px * 4, 8);
+        HIPCHK(hipMemcpy(e->lanes[0].tptr[input_tensor_index(e)], pair.data(), pair.size() * 2, hipMemcpyHostToDevice));
+    } else {
+        HIPCHK(hipMemcpy(e->lanes[0].tptr[input_tensor_index(e)], in_half, (size_t)n * S * S * 4 * 2, hipMemcpyHostToDevice));
+    }
     enqueue_network(e, e->lanes[0], n, nullptr, false);
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipGetLastError());
@@ -1095,9 +1141,7 @@ extern "C" int wz_stage_read_tensor(wz_engine_t* e, int idx, int frame, uint16_t
         return wz_fail(WZ_EINVAL, "wz_stage_read_tensor: bad argument");
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
-    const WzTensorDesc& t = e->tensors[idx];
-    const size_t es = idx == input_tensor_index(e) ? 2 : e->hdr.precision / 8;   // the input tensor is fp16 in both engines
-    const size_t per = (size_t)t.h * t.w * t.c * es;
+    const size_t per = tensor_frame_bytes(e, idx);   // a pair tensor: 2c halves per pixel, hi then lo
     HIPCHK(hipMemcpy(out_half, (const uint8_t*)e->lanes[0].tptr[idx] + per * frame, per, hipMemcpyDeviceToHost));
     return WZ_OK;
 }

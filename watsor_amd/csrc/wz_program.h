@@ -8,11 +8,13 @@
 #include <stdint.h>
 
 #define WZ_MAGIC 0x35335A57u /* "WZ35" */
-#define WZ_FORMAT_VERSION 6u
+#define WZ_FORMAT_VERSION 7u
 
 enum WzOpKind { WZ_OP_STEM = 1, WZ_OP_DW = 2, WZ_OP_CONV = 3, WZ_OP_MBCONV = 4 };
 enum WzOutMode { WZ_OUT_ACT = 0, WZ_OUT_BOX = 1, WZ_OUT_CLS = 2, WZ_OUT_HEAD = 3 };
 enum WzAct { WZ_ACT_NONE = 0, WZ_ACT_RELU6 = 1 };
+enum WzTensorFlags { WZ_TENSOR_HP = 1 };
+enum WzOpFlags { WZ_OPF_HP = 1, WZ_OPF_HP_OUT = 2 };   // split-operand block (k_mbconv_hp.hip) / its output tensor is a hi + lo pair
 
 #pragma pack(push, 1)
 struct WzBlobHeader {  // 160 bytes
@@ -25,13 +27,15 @@ struct WzBlobHeader {  // 160 bytes
     float scale_y, scale_x, scale_h, scale_w;   // box coder scale factors (10,10,5,5)
     uint64_t tensors_off, ops_off, anchors_off, weights_off, weights_bytes, total_bytes;
     uint32_t n_slots;         // activation buffer slots after liveness packing
-    uint32_t reserved[11];
+    uint32_t hp_blocks;       // leading inverted-residual blocks on the split-operand kernel (0 = plain fp16 program)
+    uint32_t reserved[10];
 };
 
 struct WzTensorDesc {  // 64 bytes
     int32_t h, w, c;          // per frame, NHWC; c is the stored channel count (input: 4)
     int32_t slot;             // buffer slot (tensors with disjoint lifetimes share one)
-    char name[48];
+    int32_t flags;            // WZ_TENSOR_HP: a pixel holds c "hi" halves followed by c "lo" halves (value = hi + lo)
+    char name[44];
 };
 
 struct WzOpDesc {  // 256 bytes
@@ -56,7 +60,12 @@ struct WzOpDesc {  // 256 bytes
     int32_t stem_pad;                       // stem padding, pad_t << 16 | pad_l
     int64_t we_off, be_off;                 // expand weights (WZ_OP_CONV layout, 1 tap) / float bias[nmid_pad]
     int64_t wd_off, bd_off;                 // depthwise: half w[9][cmid_pad] / float bias[cmid_pad]
-    int64_t reserved2[4];
+    // WZ_OPF_HP: we_off / w_off hold the "hi" fragments, these the "lo" ones (same layout); the expand weights and bias
+    // carry a factor 1/6 and the depthwise weights are float w[9][cmid_pad] carrying 6/65535 (the expanded tensor lives
+    // in LDS as unorm16 of relu6(x)/6)
+    int64_t we_lo_off, w_lo_off;
+    int64_t flags;                          // WzOpFlags
+    int64_t reserved2[1];
     char name[64];
 };
 #pragma pack(pop)
@@ -68,3 +77,4 @@ struct WzOpDesc {  // 256 bytes
 //               W[k = chunk*32 + (l>>4)*8 + j][n = t*16 + (l&15)], zero beyond cin / cout
 //               (exactly the A-operand fragment of v_mfma_f32_16x16x32_f16), float bias[n_pad]
 //  WZ_OP_MBCONV: expand + project in the WZ_OP_CONV layout, depthwise as WZ_OP_DW with rows padded to cmid_pad
+//               (WZ_OPF_HP: every GEMM weight twice, hi and lo halves; depthwise weights fp32)

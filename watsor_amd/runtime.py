@@ -42,6 +42,7 @@ class HipEngine:
         self.num_anchors = self._lib.wz_num_anchors(self._h)
         self.num_classes = self._lib.wz_num_classes(self._h)
         self.num_slots = self._lib.wz_num_slots(self._h)
+        self.hp_blocks = self._lib.wz_hp_blocks(self._h)   # leading blocks with split (hi + lo) matrix operands
         self._dev_allocs: List[int] = []
 
     # -- lifecycle ------------------------------------------------------------------------------
@@ -239,10 +240,14 @@ class HipEngine:
         return list(zip(self.stage_names(), [float(x) for x in ms]))
 
     # -- stage-level entry points (parity tests) --------------------------------------------------
+    def tensor_is_pair(self, idx: int) -> bool:
+        return bool(self._lib.wz_tensor_flags(self._h, idx) & 1)
+
     def stage_preprocess(self, frame: np.ndarray) -> np.ndarray:
+        """(S,S,4) float16; for a pair input tensor (S,S,8): hi (r,g,b,0) then lo (r,g,b,0)."""
         frame = np.ascontiguousarray(frame, np.uint8)
         S = self.input_size
-        out = np.empty((S, S, 4), np.float16)
+        out = np.empty((S, S, 8 if self.tensor_is_pair(0) else 4), np.float16)
         _lib.check(self._lib.wz_stage_preprocess(self._h, C.c_void_p(frame.ctypes.data), frame.shape[1],
                                                  frame.shape[0], C.c_void_p(out.ctypes.data)))
         return out
@@ -258,9 +263,13 @@ class HipEngine:
         return be, lg
 
     def stage_read_tensor(self, idx: int, frame: int = 0) -> np.ndarray:
+        """(h,w,c) array as stored; a pair tensor comes back as float32 hi + lo."""
         name, h, w, c = self.tensors()[idx]
-        out = np.empty((h, w, c), np.float16 if (self.precision == 16 or name == "input") else np.float32)
+        pair = self.tensor_is_pair(idx)
+        out = np.empty((h, w, 2 * c if pair else c), np.float16 if (self.precision == 16 or name == "input") else np.float32)
         _lib.check(self._lib.wz_stage_read_tensor(self._h, idx, frame, C.c_void_p(out.ctypes.data)))
+        if pair:
+            return out[..., :c].astype(np.float32) + out[..., c:].astype(np.float32)
         return out
 
     def stage_postprocess(self, box_enc: np.ndarray, logits: np.ndarray):
