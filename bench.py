@@ -9,11 +9,19 @@ Detection rows per frame, D2H of the rows included) over one batch of synthetic 
 already resident in HBM.  Workload at N=1 = BASELINE.json configs[1]: one synthetic 640x480 RGB
 stream, batch = 8 frames, 1 x MI355X.  For N > 1 every rank is an independent replica with its own
 camera (cameras are the shard; no data-path collective -- SURVEY.md 8e), value = frames of all ranks
-/ max-over-ranks time, scaling "weak".
+/ max-over-ranks time, scaling "weak".  `--gpus N` without a launcher (WORLD_SIZE unset) starts the N
+ranks itself, one process per device ordinal -- the reference's scheme (`watsor/detection/detector.py:34-50`).
+
+The timed region of exactly K steps (barrier + device synchronise on both sides, max over ranks) is
+repeated for >= 25 rounds; `value` / `ms_per_step` are the MEDIAN round, min / max beside them (one
+K = 20 region lasts ~4 ms: a single sample of it is noise).
 
 Rank 0 prints ONE JSON line (contract in the task description) extended with
-  "p50_ms"      : median per-step latency of synchronous steps (the other half of BASELINE's metric)
+  "p50_ms"      : median latency of synchronous batch-8 steps, frames in HBM
+  "parity"      : the north star's criterion checked LIVE on the engine that was timed: max |score - oracle score|
+                  over the detection rows of 8 of the benchmark's frames (bar: 1e-3)
   "roofline"    : dominant kernel of the step, timed live with HIP events on the engine's own stream
+  "legs"        : the other BASELINE configs as per-GPU shares (frames/s + p50), host-frame and plugin paths
   "cpu_baseline": the oracle (CPU restatement of the reference's TF detector) on this host's cores
 """
 from __future__ import annotations
@@ -21,6 +29,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,23 +42,30 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0    # dense fp16/bf16 MFMA
 WIDTH, HEIGHT, BATCH = 640, 480, 8
+SCORE_TOLERANCE = 1e-3       # BASELINE.json north_star: "box scores within 1e-3 of the CPU reference"
+MIN_ROUNDS, MAX_ROUNDS, ROUNDS_BUDGET_S = 25, 400, 1.0
+PROFILE_INNER = 8            # launches per bracket in the stage profile (wz_profile_stages)
 
 
-def kernel_class(op):
+# --------------------------------------------------------------------------------------------------
+# roofline
+# --------------------------------------------------------------------------------------------------
+def kernel_class(op, hp):
     from watsor_amd import arch
     if op["kind"] == arch.OP_STEM:
         return "wz_k_stem"
     if op["kind"] == arch.OP_DW:
         return "wz_k_dw"
     if op["kind"] == arch.OP_MBCONV:
-        return "wz_k_mbconv"
+        return "wz_k_mbconv_hp" if hp else "wz_k_mbconv"
     return "wz_k_conv<%d>" % op["ksize"]
 
 
 def algorithmic_cost(op, n):
-    """(flops, bytes) of one launch per the per-layer rule of SURVEY.md 8(d): every tensor once.
+    """(flops, bytes) of one launch per the per-layer rule of SURVEY.md 8(d): fp16, every tensor once.
     A fused inverted-residual block is priced as the layers it computes (expand, depthwise, project), i.e.
-    the bytes a layer-by-layer execution moves; `fused_min_bytes` below is what the fused launch has to move."""
+    the bytes a layer-by-layer fp16 execution moves -- also for the split-operand blocks, whose extra bytes
+    (pair tensors, hi + lo weights) and 3x MFMA work are the price of the tolerance, not algorithmic work."""
     from watsor_amd import arch
     M = n * op["hout"] * op["wout"]
     if op["kind"] == arch.OP_MBCONV:
@@ -76,56 +93,72 @@ def algorithmic_cost(op, n):
     return 2.0 * M * N * K, 2.0 * (n * op["hin"] * op["win"] * op["cin"] + K * N) + out_bytes * M * N
 
 
+def fused_min_bytes(op, n, hp, hp_out):
+    """What a fused block launch has to move, as laid out in HBM: block input + weights + output, once each
+    (pair tensors 4 bytes per value, split weights twice, fp32 depthwise weights)."""
+    cin, cmid, cout = op["cin"], op["cmid"], op["cout"]
+    es_in = 4.0 if hp else 2.0
+    es_out = 4.0 if hp_out else 2.0
+    es_w = 4.0 if hp else 2.0
+    inp = n * (2 * op["hin"]) * (2 * op["win"]) * 4 if cin == 3 else n * op["hin"] * op["win"] * cin
+    wts = (27 * 32 if cin == 3 else (cin * cmid if cin != cmid else 0)) + cmid * cout
+    return es_in * inp + es_w * wts + (4.0 if hp else 2.0) * 9 * cmid + es_out * n * op["hout"] * op["wout"] * cout
+
+
 def empty_bracket_ms(stages):
     """Cost of an event bracket with no kernel in it: the median of the brackets that are empty ("(empty)" and the
-    unused split-K slots), i.e. of those within 1 us of the shortest one (back-to-back empty brackets read ~0.5 us
-    shorter than isolated ones, so the minimum itself would inflate every other stage)."""
+    unused split-K slots), i.e. of those within 1 us of the shortest one."""
     cands = sorted([ms for name, ms in stages if name == "(empty)" or name.endswith("#splitk_reduce")])
     near = [ms for ms in cands if ms <= cands[0] + 1e-3]
     return near[len(near) // 2]
 
 
-def roofline_from_stages(stages, ops, n, frame_bytes, size):
-    """Aggregate event-bracketed stage times by kernel; return (roofline dict of the dominant kernel, table)."""
+def aggregate_stages(stages, ops, n, frame_bytes, size, hp_blocks, inner):
+    """Event-bracketed stage times -> per-kernel-class totals.  A network stage's bracket holds `inner` back-to-back
+    launches (wz_profile_stages): (bracket - empty bracket) / inner = one launch including its in-stream boundary."""
     from watsor_amd import arch
     by_name = {o["name"]: o for o in ops}
-    # A hipEventRecord pair with nothing in between reads ~5 us on this stack (the record itself is a
-    # barrier packet).  Brackets of unused split-K slots are exactly that: calibrate on them and
-    # subtract, so a stage time is the kernel's own duration as rocprofv3's kernel trace reports it.
+    mb_index = {o["name"]: i for i, o in enumerate([o for o in ops if o["kind"] == arch.OP_MBCONV])}
     overhead = empty_bracket_ms(stages)
     agg = {}
+
+    def slot(k):
+        return agg.setdefault(k, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, min_bytes=0.0))
+
     for name, ms in stages:
-        ms = max(ms - overhead, 0.0)
+        post = name.startswith("post/") or name in ("(empty)", "h2d_descriptors")
+        ms = max(ms - overhead, 0.0) / (1 if post else inner)
         if name.endswith("#splitk_reduce"):
             k, fl, by = "wz_k_splitk_reduce", 0.0, 0.0
             if ms < 5e-4:
                 continue
+            mb = None
         elif name in ("heads#small_convs", "heads#big_convs"):   # the SSD heads' shared launches: their flops / bytes are
-            k, fl, by = "wz_k_conv<3>", 0.0, 0.0            # counted in their own (empty) op slots below
+            k, fl, by, mb = "wz_k_conv<3>", 0.0, 0.0, None       # counted in their own (empty) op slots below
             if ms < 5e-4:
                 continue
         elif name in by_name:
             o = by_name[name]
-            k = kernel_class(o)
+            mb = mb_index.get(name)
+            k = kernel_class(o, mb is not None and mb < hp_blocks)
             fl, by = algorithmic_cost(o, n)
             if ms < 5e-4 and o["kind"] == arch.OP_CONV:     # deferred into the shared launch: work yes, launch no
-                a = agg.setdefault(k, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, min_bytes=0.0))
+                a = slot(k)
                 a["flops"] += fl; a["bytes"] += by; a["min_bytes"] += by
                 continue
         elif name == "preprocess":
-            k, fl, by = "wz_k_preprocess", 0.0, float(n * (frame_bytes + size * size * 4 * 2))
+            k, fl, mb = "wz_k_preprocess", 0.0, None
+            by = float(n * (frame_bytes + size * size * 4 * 2 * (2 if hp_blocks else 1)))
         elif name.startswith("post/"):
-            k, fl, by = "wz_k_" + name.split("/")[1], 0.0, 0.0
+            k, fl, by, mb = "wz_k_" + name.split("/")[1], 0.0, 0.0, None
+            if ms < 5e-4:
+                continue
         else:
             continue
-        a = agg.setdefault(k, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, min_bytes=0.0))
+        a = slot(k)
         a["ms"] += ms; a["flops"] += fl; a["bytes"] += by; a["launches"] += 1
-        if name in by_name and by_name[name]["kind"] == arch.OP_MBCONV:   # block input + weights + output, once each
-            o = by_name[name]
-            cin, cmid, cout = o["cin"], o["cmid"], o["cout"]
-            inp = n * (2 * o["hin"]) * (2 * o["win"]) * 4 if cin == 3 else n * o["hin"] * o["win"] * cin
-            a["min_bytes"] += 2.0 * (inp + (cin * cmid if cin != cmid else 0) + 9 * cmid +
-                                     cmid * cout + n * o["hout"] * o["wout"] * cout)
+        if mb is not None:
+            a["min_bytes"] += fused_min_bytes(by_name[name], n, mb < hp_blocks, mb < hp_blocks - 1)
         else:
             a["min_bytes"] += by
     table = []
@@ -140,23 +173,38 @@ def roofline_from_stages(stages, ops, n, frame_bytes, size):
                           bytes_per_launch=a["bytes"] / a["launches"], flops_per_launch=a["flops"] / a["launches"],
                           min_bytes_per_launch=a["min_bytes"] / a["launches"],
                           min_gbs=a["min_bytes"] / t / 1e9 if t > 0 else 0.0))
+    return table, overhead
+
+
+def roofline_object(table, overhead, single_table, inner):
+    """The JSON `roofline` object for the dominant kernel class of the step."""
     dom = table[0]
     if dom["bound"] == "hbm":
         ach, peak, unit = dom["gbs"], HBM_PEAK_GBS, "GB/s"
     else:
         ach, peak, unit = dom["tflops"], MFMA_PEAK_TFLOPS, "TFLOP/s"
-    roof = dict(kernel=dom["kernel"], event_overhead_us=round(overhead * 1e3, 3), bound=dom["bound"], achieved=round(ach, 3), peak=peak, unit=unit,
-                frac=round(ach / peak, 5), traffic=pmc_traffic(dom["kernel"]), avg_launch_us=round(dom["avg_us"], 3),
-                launches_per_step=dom["launches"], time_frac_of_roofline=round(dom["t_roof_frac"], 5),
-                algorithmic_bytes_per_launch=dom["bytes_per_launch"], algorithmic_flops_per_launch=dom["flops_per_launch"],
+    traffic = pmc_traffic(dom["kernel"])
+    roof = dict(kernel=dom["kernel"], bound=dom["bound"], achieved=round(ach, 3), peak=peak, unit=unit,
+                frac=round(ach / peak, 5), traffic=traffic,
+                avg_launch_us=round(dom["avg_us"], 3), launches_per_step=dom["launches"],
+                duration_method="HIP events on the lane's stream around %d back-to-back launches of each kernel "
+                                "(wz_profile_stages), empty bracket %.2f us subtracted, / %d: a launch incl. its in-stream "
+                                "boundary" % (inner, overhead * 1e3, inner),
+                algorithmic_bytes_per_launch=round(dom["bytes_per_launch"]),
+                algorithmic_flops_per_launch=round(dom["flops_per_launch"]),
                 # what the launch has to move when intermediate tensors stay on chip (= algorithmic for unfused kernels)
-                fused_min_bytes_per_launch=dom["min_bytes_per_launch"],
-                frac_of_peak_on_fused_min_bytes=round(dom["min_gbs"] / HBM_PEAK_GBS, 5))
+                fused_min_bytes_per_launch=round(dom["min_bytes_per_launch"]),
+                frac_fused_min=round(dom["min_gbs"] / HBM_PEAK_GBS, 5))
+    if traffic:      # bytes the memory-side counters saw per launch (committed rocprofv3 --pmc passes) at this run's duration
+        roof["frac_counter_traffic"] = round(traffic["bytes"] / (dom["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
+    single = {r["kernel"]: r for r in single_table}.get(dom["kernel"])
+    if single:       # the same kernel with ONE launch per bracket (the cost of the event pair estimated, not amortised)
+        roof["avg_launch_us_single_bracket"] = round(single["avg_us"], 3)
     rp = rocprof_avg_us(dom["kernel"])
-    if rp:   # the same fraction at the duration the committed rocprofv3 trace reports for this kernel
+    if rp:           # ... and at the duration the committed rocprofv3 kernel trace of this command reports
         roof["avg_launch_us_rocprof"] = rp
         roof["frac_at_rocprof_duration"] = round(roof["frac"] * dom["avg_us"] / rp, 5)
-    return roof, table
+    return roof
 
 
 def pmc_traffic(kernel):
@@ -170,23 +218,172 @@ def pmc_traffic(kernel):
             return None
         return dict(bytes=round(t["fetch_bytes_corrected"] + t["write_bytes"]), fetch_bytes_raw=round(t["fetch_bytes_raw"]),
                     fetch_bytes_corrected=round(t["fetch_bytes_corrected"]), write_bytes=round(t["write_bytes"]),
-                    source="profiles/pmc_traffic.json (rocprofv3 --pmc, mean per launch)")
+                    source="profiles/pmc_traffic.json (rocprofv3 --pmc of this command, mean per launch; committed, not of this run)")
     except (OSError, ValueError, KeyError):
         return None
 
 
 def rocprof_avg_us(kernel):
     """Average per-dispatch duration of `kernel` in the committed rocprofv3 kernel trace of this command
-    (profiles/rocprof_kernel_avg.json).  rocprofv3 counts dispatch + teardown into a duration, the HIP-event
-    bracket minus the empty-bracket calibration does not: the two differ by 2-3 us per launch."""
+    (profiles/rocprof_kernel_avg.json)."""
     try:
         return json.load(open(os.path.join(ROOT, "profiles", "rocprof_kernel_avg.json"))).get(kernel, {}).get("avg_us")
     except (OSError, ValueError):
         return None
 
 
+# --------------------------------------------------------------------------------------------------
+# legs
+# --------------------------------------------------------------------------------------------------
+def throughput(eng, submit, n_frames_per_step, steps=120, warm=12):
+    """frames/s of `steps` asynchronous steps over the engine's lanes + p50 of synchronous ones."""
+    lanes = eng.num_slots
+    for s in range(warm):
+        submit(s % lanes, s)
+    eng.sync()
+    t0 = time.perf_counter()
+    for s in range(steps):
+        submit(s % lanes, s)
+    eng.sync()
+    dt = time.perf_counter() - t0
+    lat = []
+    for s in range(min(steps, 60)):
+        t1 = time.perf_counter()
+        submit(0, s)
+        eng.wait(0)
+        lat.append((time.perf_counter() - t1) * 1e3)
+    return dict(value=round(steps * n_frames_per_step / dt, 1), unit="frames/s", ms_per_step=round(dt / steps * 1e3, 4),
+                p50_ms=round(float(np.median(lat)), 4), frames_per_step=n_frames_per_step, steps=steps)
+
+
+def sample_detect_config(nz):
+    """Thresholds of the reference's sample camera (`config/config.yaml:69-79`); zones limited to those the mask has."""
+    return [{"person": {"area": 20, "confidence": 60, "zones": []}},
+            {"car": {"area": 10, "confidence": 50, "zones": [z for z in (1, 3, 5) if z <= nz]}},
+            {"truck": {"area": 10, "confidence": 50, "zones": []}}]
+
+
+def config_legs(engine_path, device, rank):
+    """Per-GPU shares of BASELINE.json configs[2..4] (frames resident in HBM, filters on where the config has them)
+    plus the north star's 300x300 sweep point."""
+    from watsor_amd.filter.hip_filter import HipCameraFilter
+    from watsor_amd.runtime import HipEngine, zones_from_alpha
+    from watsor_amd.synth import synthetic_frame, synthetic_zone_mask
+    legs = {}
+    eng = HipEngine(engine_path, device, 16, 1920, 1080)
+    try:
+        # north star sweep point: synthetic 300x300 frames, batch 8
+        f300 = [eng.upload(synthetic_frame(300, 300, 500 + i)) for i in range(8)]
+        r = throughput(eng, lambda lane, s: eng.submit_device(lane, f300, [300] * 8, [300] * 8), 8)
+        r["workload"] = "synthetic 300x300 frames in HBM, batch 8"
+        legs["frame_300x300_b8"] = r
+        # configs[2]: 8 x 1280x720 streams, one camera per GPU -> this GPU's share: ONE camera; its frames arrive one at a
+        # time (BalancedQueue holds one queued frame per camera, watsor/stream/sync.py:156-166), so batch = 1 per lane
+        f720 = [eng.upload(synthetic_frame(1280, 720, 600 + i)) for i in range(4)]
+        r = throughput(eng, lambda lane, s: eng.submit_device(lane, [f720[s % 4]], [1280], [720]), 1, steps=300, warm=20)
+        r["workload"] = "configs[2] share: 1 camera 1280x720, batch 1 on each of %d lanes, frames in HBM" % eng.num_slots
+        legs["config3_1x720p_b1"] = r
+        # configs[3]: 32 x 1920x1080 cameras with per-camera alpha zone masks, 4 cameras per GPU: one frame of each per step
+        filters = []
+        masks = [synthetic_zone_mask(1920, 1080, 100 + c, 2 + c % 5) for c in range(8)]
+        for c in range(4):
+            nz = zones_from_alpha(masks[c])[0].shape[0]
+            filters.append(HipCameraFilter(eng, c, {"width": 1920, "height": 1080, "detect": sample_detect_config(nz)}, alpha=masks[c]))
+        f1080 = [eng.upload(synthetic_frame(1920, 1080, 700 + c)) for c in range(8)]
+        r = throughput(eng, lambda lane, s: eng.submit_device(lane, f1080[:4], [1920] * 4, [1080] * 4, cams=[0, 1, 2, 3]), 4)
+        r["workload"] = "configs[3] share: 4 cameras 1920x1080, each with its alpha zone mask + sample-config thresholds (filters on), batch 4, frames in HBM"
+        legs["config4_4x1080p_masks_b4"] = r
+        # configs[4]: 128 mixed cameras (640x480 / 1920x1080) with masks + confidence / area filters: 16 per GPU, saturation
+        small_masks = [synthetic_zone_mask(640, 480, 300 + c, 2 + c % 5) for c in range(8)]
+        fsmall = [eng.upload(synthetic_frame(640, 480, 800 + c)) for c in range(8)]
+        for c in range(4, 8):
+            nz = zones_from_alpha(masks[c])[0].shape[0]
+            filters.append(HipCameraFilter(eng, c, {"width": 1920, "height": 1080, "detect": sample_detect_config(nz)}, alpha=masks[c]))
+        for c in range(8):
+            nz = zones_from_alpha(small_masks[c])[0].shape[0]
+            filters.append(HipCameraFilter(eng, 8 + c, {"width": 640, "height": 480, "detect": sample_detect_config(nz)}, alpha=small_masks[c]))
+        mix_frames, mix_w, mix_h, mix_c = [], [], [], []
+        for c in range(8):                         # alternating resolutions, as the config says
+            mix_frames += [fsmall[c], f1080[c]]
+            mix_w += [640, 1920]
+            mix_h += [480, 1080]
+            mix_c += [8 + c, c]
+        r = throughput(eng, lambda lane, s: eng.submit_device(lane, mix_frames, mix_w, mix_h, cams=mix_c), 16, steps=80, warm=8)
+        r["workload"] = ("configs[4] share: 16 cameras alternating 640x480 / 1920x1080, masks + confidence / area thresholds "
+                         "(config.yaml:69-79), batch 16 = one frame of each camera, frames in HBM, saturation")
+        legs["config5_16_mixed_filters_b16"] = r
+        for f in filters:
+            f.close()
+    finally:
+        eng.close()
+    return legs
+
+
+def host_legs(engine_path, model_dir, device, host_frames):
+    """The reference's actual boundary: frames handed over as HOST memory (`detector.py:104-107`)."""
+    from watsor_amd.detection.hip_gpu import HipObjectDetector
+    from watsor_amd.runtime import HipEngine, ROW_DTYPE
+    legs = {}
+    eng = HipEngine(engine_path, device, BATCH, WIDTH, HEIGHT)
+    try:
+        arena = np.ascontiguousarray(np.stack(host_frames[:2 * BATCH]))     # one "FrameBuffer arena", page-locked once
+        eng.host_register(arena)
+        try:
+            views = [[arena[b * BATCH + i] for i in range(BATCH)] for b in range(2)]
+            r = throughput(eng, lambda lane, s: eng.submit_host(lane, views[s % 2]), BATCH)
+            r["workload"] = "640x480 frames in page-locked host memory (wz_host_register + wz_submit_host), batch 8: H2D inside the step"
+            legs["host_frames_pinned_b8"] = r
+        finally:
+            eng.sync()
+            eng.host_unregister(arena)
+    finally:
+        eng.close()
+    # the plugin call the reference worker makes: one frame from (pageable) host memory, synchronous -- the time
+    # `ObjectDetector._next_frame` feeds into `inference_time` (detector.py:107-109)
+    with HipObjectDetector(model_dir, device, max_batch=1, max_width=WIDTH, max_height=HEIGHT) as det:
+        rows = np.zeros(100, ROW_DTYPE)
+        f = host_frames[0]
+        for _ in range(20):
+            det.detect(f.shape, f, rows)
+        ms, wall = [], []
+        for i in range(300):
+            f = host_frames[i % len(host_frames)]
+            t1 = time.perf_counter()
+            ms.append(det.detect(f.shape, f, rows))
+            wall.append((time.perf_counter() - t1) * 1e3)
+        legs["plugin_detect_b1"] = dict(p50_ms=round(float(np.median(ms)), 4), p99_ms=round(float(np.percentile(ms, 99)), 4),
+                                        p50_ms_python_wall=round(float(np.median(wall)), 4),
+                                        value=round(1000.0 / float(np.mean(wall)), 1), unit="frames/s",
+                                        workload="HipObjectDetector.detect() of one 640x480 frame in pageable host memory, synchronous "
+                                                 "(what the reference's inference_time measures, detector.py:107-109)")
+    return legs
+
+
+def parity_leg(eng, host_frames, d_frames, weights):
+    """North star criterion (1), live, on the engine that was just timed: scores of its detection rows vs the oracle's
+    on 8 of the benchmark's own frames."""
+    from oracle.compare import match_rows
+    from oracle.detect import OracleObjectDetector, rows_as_array
+    n = BATCH
+    eng.submit_device(0, d_frames[:n], [WIDTH] * n, [HEIGHT] * n)
+    eng.wait(0)
+    got = eng.slot_rows(0, n).copy()
+    det = OracleObjectDetector(weights=weights)
+    worst, matched, total = 0.0, 0, 0
+    for i in range(n):
+        b, c, s, _, _ = det.raw(host_frames[i])
+        ref = rows_as_array(host_frames[i].shape, b, c, s)
+        pairs, _ = match_rows(got[i], ref, min_score=0.0)
+        matched += len(pairs)
+        total += int((ref["confidence"] > 0).sum())
+        worst = max([worst] + [abs(p[3]) for p in pairs])
+    return dict(max_dscore=round(worst, 6), frames=n, rows_compared=matched, rows_reference=total,
+                tolerance=SCORE_TOLERANCE, within_tolerance=bool(worst <= SCORE_TOLERANCE and matched >= 0.9 * total),
+                against="oracle (CPU restatement of the reference's TF detector, fp32), same frames, rows matched by label and IoU >= 0.9")
+
+
 def fp32_engine_leg(weights, frames, rank):
-    """Throughput of the `-p 32` engine (the one that meets the 1e-3 score tolerance) on the same workload."""
+    """Throughput of the `-p 32` engine (fp32 storage, exact-fp32 MFMA) on the same workload, for reference."""
     from watsor_amd import engine as builder
     from watsor_amd.runtime import HipEngine
     d = "/tmp/wz_bench32_%d_%d" % (os.getpid(), rank)
@@ -196,28 +393,43 @@ def fp32_engine_leg(weights, frames, rank):
     eng = HipEngine(path, int(os.environ.get("LOCAL_RANK", "0")), BATCH, WIDTH, HEIGHT)
     try:
         dfr = [eng.upload(f) for f in frames[:BATCH]]
-        ws, hs = [WIDTH] * BATCH, [HEIGHT] * BATCH
-        for s in range(2 * eng.num_slots):
-            eng.submit_device(s % eng.num_slots, dfr, ws, hs)
-        eng.sync()
-        n = 60
-        t0 = time.perf_counter()
-        for s in range(n):
-            eng.submit_device(s % eng.num_slots, dfr, ws, hs)
-        eng.sync()
-        dt = time.perf_counter() - t0
+        r = throughput(eng, lambda lane, s: eng.submit_device(lane, dfr, [WIDTH] * BATCH, [HEIGHT] * BATCH), BATCH, steps=60, warm=8)
     finally:
         eng.close()
         os.remove(path)
         os.rmdir(d)
-    return dict(value=round(n * BATCH / dt, 2), unit="frames/s", ms_per_step=round(dt / n * 1e3, 4), dtype="f32",
-                note="same workload on the -p 32 engine (fp32 storage, exact-fp32 MFMA): scores within 1e-3 of the CPU "
-                     "detector (measured 1e-5); the headline value is the -p 16 engine (fp16, measured 2.9e-3)")
+    r.update(dtype="f32", workload="the headline workload on the -p 32 engine (scores within 1e-5 of the CPU detector)")
+    return r
+
+
+def plain_fp16_leg(weights, frames, rank):
+    """The same workload on the `--plain-fp16` program (no split operands): faster, but 3x outside the score tolerance."""
+    from watsor_amd import engine as builder
+    from watsor_amd.runtime import HipEngine
+    d = "/tmp/wz_bench16p_%d_%d" % (os.getpid(), rank)
+    os.makedirs(d, exist_ok=True)
+    path = os.path.join(d, "mi355x.bin")
+    builder.save_engine(builder.build_engine(weights, hp_upto=-1), path)
+    eng = HipEngine(path, int(os.environ.get("LOCAL_RANK", "0")), BATCH, WIDTH, HEIGHT)
+    try:
+        dfr = [eng.upload(f) for f in frames[:BATCH]]
+        r = throughput(eng, lambda lane, s: eng.submit_device(lane, dfr, [WIDTH] * BATCH, [HEIGHT] * BATCH), BATCH)
+        par = parity_leg(eng, frames, dfr, weights)
+    finally:
+        eng.close()
+        os.remove(path)
+        os.rmdir(d)
+    r.update(dtype="f16", max_dscore=par["max_dscore"], within_tolerance=par["within_tolerance"],
+             workload="the headline workload on the --plain-fp16 program: NOT parity-qualified, shown for the cost of the tolerance")
+    return r
 
 
 def cpu_baseline(weights, frames, budget_s=12.0):
-    """Oracle detector (kind 'port') on this host's cores over a bounded sample of the same frames."""
+    """Oracle detector (kind 'port') on this host's cores over a bounded sample of the same frames, with the split
+    between the network (torch-CPU convolutions) and the post-processing (numpy + pure-Python class-by-class NMS)."""
     import torch
+    from oracle import postprocess as post
+    from oracle import preprocess as pre
     from oracle.detect import OracleObjectDetector
     from watsor_amd.share import DetectionArray
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -238,10 +450,26 @@ def cpu_baseline(weights, frames, budget_s=12.0):
         if time.perf_counter() - t0 >= budget_s and done >= 4:
             break
     dt = time.perf_counter() - t0
+    # where the time goes (4 frames, outside the sample above)
+    t_pre = t_net = t_post = 0.0
+    anchors = post.anchors_center_size(post.generate_anchors(300))
+    for f in frames[:4]:
+        t1 = time.perf_counter()
+        x = pre.preprocess(f, 300)[None]
+        t2 = time.perf_counter()
+        be, cl, _ = det._net.forward(x)
+        t3 = time.perf_counter()
+        post.postprocess(be[0], cl[0], anchors)
+        t4 = time.perf_counter()
+        t_pre += t2 - t1; t_net += t3 - t2; t_post += t4 - t3
     return dict(value=round(done / dt, 3), unit="frames/s", cores=cores, kind="port",
                 p50_ms=round(float(np.median(lat)), 2),
-                sample="%d synthetic %dx%d frames, oracle (torch-CPU fp32 restatement of the reference TF detector), "
-                       "%.1f s" % (done, WIDTH, HEIGHT, dt))
+                split_ms=dict(resize_normalise=round(t_pre / 4 * 1e3, 2), network=round(t_net / 4 * 1e3, 2),
+                              postprocess=round(t_post / 4 * 1e3, 2)),
+                network_only_frames_per_s=round(4.0 / t_net, 2),
+                sample="%d synthetic %dx%d frames, oracle (torch-CPU fp32 restatement of the reference TF detector; its "
+                       "post-processing is a literal class-by-class NMS in Python), %.1f s" % (done, WIDTH, HEIGHT, dt),
+                published_reference="README.md:455 quotes ~24 FPS for the TF CPU detector (v1 model) on a desktop CPU")
 
 
 class _StubEngine:
@@ -284,27 +512,55 @@ def note(msg):
         print("[bench %7.2fs] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
 
 
+def spawn_ranks(n, argv):
+    """`--gpus N` without a launcher: one process per device ordinal 0 .. N-1 (the reference starts one detector
+    process per device, `watsor/detection/detector.py:34-50`); gloo rendezvous on 127.0.0.1 for the barrier and the
+    max-over-ranks; rank 0's JSON line is this process's output."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out = procs[0].communicate()[0].decode()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = p.wait() or rc
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--rounds", type=int, default=0, help="timed regions of --steps steps (0: >= 25, until 1 s of them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the -p 32 engine leg (profiling runs: one engine's kernels only)")
+    ap.add_argument("--no-legs", action="store_true", help="skip the other BASELINE configs / host-frame / plugin legs")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the -p 32 and --plain-fp16 engine legs (profiling runs: one engine's kernels only)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the live score check against the oracle")
     ap.add_argument("--table", default=None, help="write the per-kernel roofline table (JSON) here")
     ap.add_argument("--dry-run", action="store_true",
                     help="harness self-test without a GPU: a stub engine that sleeps 2 ms per step (used by the "
-                         "world_size-2 gloo test; its output is marked invalid)")
+                         "world_size-2 tests; its output is marked invalid)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
 
-    # libwatsor_hip.so owns the GPU side (its own HIP stream, events, graphs): load it FIRST so it binds
+    # libwatsor_hip.so owns the GPU side (its own HIP streams, events, graphs): load it FIRST so it binds
     # to /opt/rocm's HIP runtime, and never initialise torch's bundled copy of that runtime in this
     # process.  torch is used for its CPU side only: the rendezvous/barrier/max-over-ranks (gloo -- the
-    # path has no data-path collective) and the oracle's conv2d in the cpu_baseline leg.
+    # path has no data-path collective, SURVEY.md 8e) and the oracle's conv2d in the parity / cpu_baseline legs.
     from watsor_amd import engine as builder
     from watsor_amd.synth import synthetic_frame, synthetic_weights
     if args.dry_run:
@@ -330,7 +586,7 @@ def main():
         open(engine_path, "wb").close()
     else:
         weights = synthetic_weights(1234)
-        builder.save_engine(builder.build_engine(weights), engine_path)
+        builder.save_engine(builder.build_engine(weights), engine_path)     # the default -p 16 program
 
     note("engine file built")
     eng = HipEngine(engine_path, local_rank, BATCH, WIDTH, HEIGHT)
@@ -350,8 +606,8 @@ def main():
         eng.submit_device(step % lanes, d_frames[b * BATCH:(b + 1) * BATCH], ws, hs)
 
     def barrier():
-        # barrier + device synchronize on both sides of the timed region (eng.sync() = hipStreamSynchronize
-        # of the only stream this process ever enqueues GPU work on)
+        # barrier + device synchronize on both sides of a timed region (eng.sync() = hipStreamSynchronize of every
+        # stream this process ever enqueues GPU work on)
         eng.sync()
         if dist is not None:
             dist.barrier()
@@ -361,62 +617,103 @@ def main():
         submit(s)
     barrier()
     note("warm-up done")
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        submit(s)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    note("timed region done: %.3f s" % elapsed)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    rounds = []
+    spent = 0.0
+    while True:
+        barrier()
+        t0 = time.perf_counter()
+        for s in range(args.steps):
+            submit(s)
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        rounds.append(el)
+        spent += el
+        if args.rounds > 0:
+            more = len(rounds) < args.rounds
+        else:
+            more = len(rounds) < (3 if args.dry_run else MIN_ROUNDS) or (not args.dry_run and spent < ROUNDS_BUDGET_S and len(rounds) < MAX_ROUNDS)
+        if dist is not None:      # every rank runs the same number of rounds: rank 0 decides
+            flag = torch.tensor([1 if more else 0])
+            dist.broadcast(flag, 0)
+            more = bool(flag.item())
+        if not more:
+            break
+    elapsed = float(np.median(rounds))
+    note("timed: %d rounds of %d steps, median %.4f s (min %.4f, max %.4f)" % (len(rounds), args.steps, elapsed, min(rounds), max(rounds)))
 
-    # per-step latency (synchronous steps), outside the timed region
+    # per-step latency (synchronous steps), outside the timed regions
     lat = []
-    for s in range(min(args.steps, 50)):
+    for s in range(min(max(args.steps, 50), 100)):
         t1 = time.perf_counter()
         submit(s)
         eng.wait(s % lanes)
         lat.append((time.perf_counter() - t1) * 1e3)
-    rows = eng.slot_rows((min(args.steps, 50) - 1) % lanes, BATCH)
+    rows = eng.slot_rows((len(lat) - 1) % lanes, BATCH)
     detections_per_frame = float((rows["confidence"] > 0).sum()) / BATCH
 
     out = None
+    frames_per_round = args.steps * BATCH * world
     if rank == 0 and args.dry_run:
         out = {"metric": "DRY RUN (stub engine, no GPU) -- invalid as a measurement",
-               "value": round(args.steps * BATCH * world / elapsed, 2), "unit": "frames/s", "n_gpus": world,
+               "value": round(frames_per_round / elapsed, 2), "unit": "frames/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none",
+               "rounds": len(rounds), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none",
                "data": "synthetic", "config": {"workload": "dry-run"},
                "camera_seeds": [1234 + r * 1000 for r in range(world)]}
     elif rank == 0:
         note("latency loop done")
-        stages = eng.profile_device(d_frames[:BATCH], ws, hs, reps=20)
-        note("stage profile done")
-        roof, table = roofline_from_stages(stages, eng.ops(), BATCH, WIDTH * HEIGHT * 3, eng.input_size)
+        parity = None
+        if not args.no_parity:
+            parity = parity_leg(eng, host_frames, d_frames, weights)
+            note("parity: max |dscore| %.6f over %d rows" % (parity["max_dscore"], parity["rows_compared"]))
+        ops = eng.ops()
+        stages = eng.profile_device(d_frames[:BATCH], ws, hs, reps=10, inner=PROFILE_INNER)
+        single = eng.profile_device(d_frames[:BATCH], ws, hs, reps=10, inner=1)
+        note("stage profiles done")
+        table, overhead = aggregate_stages(stages, ops, BATCH, WIDTH * HEIGHT * 3, eng.input_size, eng.hp_blocks, PROFILE_INNER)
+        single_table, _ = aggregate_stages(single, ops, BATCH, WIDTH * HEIGHT * 3, eng.input_size, eng.hp_blocks, 1)
+        roof = roofline_object(table, overhead, single_table, PROFILE_INNER)
         if args.table:
-            json.dump(dict(stages=stages, kernels=table), open(args.table, "w"), indent=1)
-        frames_total = args.steps * BATCH * world
+            json.dump(dict(stages=stages, stages_single_bracket=single, inner=PROFILE_INNER, kernels=table,
+                           kernels_single_bracket=single_table), open(args.table, "w"), indent=1)
+        graph_nodes = sum(1 for (name, ms), (_, ms1) in zip(stages, single)
+                          if ms1 - overhead > 5e-4 and name not in ("(empty)",))
         out = {
             "metric": "detected frames/sec (whole node) + p50 per-frame latency, SSD-MobileNet 300x300",
-            "value": round(frames_total / elapsed, 2), "unit": "frames/s",
+            "value": round(frames_per_round / elapsed, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "rounds": len(rounds),
+            "value_min": round(frames_per_round / max(rounds), 2), "value_max": round(frames_per_round / min(rounds), 2),
             "p50_ms": round(float(np.median(lat)), 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": "1 synthetic 640x480 RGB stream per GPU, batch=8 frames, SSD-MobileNet-v2 300x300 "
                                    "(seeded random-init weights), frames resident in HBM, rows copied back to host",
+                       "engine": "-p 16 (fp16 MFMA; stem + blocks 0..%d with split hi+lo operands, the rest plain fp16)" % (eng.hp_blocks - 1)
+                                 if eng.hp_blocks else "-p 16 --plain-fp16",
                        "batch": BATCH, "frame": "%dx%d" % (WIDTH, HEIGHT), "parallelism": "replica-per-gpu x%d" % world, "batches_in_flight": lanes,
-                       "detections_per_frame": detections_per_frame},
+                       "graph_nodes_per_batch": graph_nodes, "detections_per_frame": detections_per_frame},
+            "parity": parity,
             "roofline": roof,
         }
         if world == 1:
             eng.close()
+        if world == 1 and not args.no_legs:
+            legs = {}
+            legs.update(host_legs(engine_path, model_dir, local_rank, host_frames))
+            note("host-frame legs done")
+            legs.update(config_legs(engine_path, local_rank, rank))
+            note("config legs done")
+            out["legs"] = legs
         if world == 1 and not args.no_fp32_leg:
+            out["plain_fp16_engine"] = plain_fp16_leg(weights, host_frames, rank)
             out["fp32_engine"] = fp32_engine_leg(weights, host_frames, rank)
-            note("fp32 engine leg done")
+            note("other-precision legs done")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(weights, host_frames[:BATCH])
             note("cpu baseline done")

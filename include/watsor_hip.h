@@ -169,6 +169,12 @@ int wz_stage_name(wz_engine_t* e, int stage, char* name, int namelen);
  * (events on the engine's own stream); stage_ms[stage] = mean milliseconds of that launch. */
 int wz_profile_device(wz_engine_t* e, int n, const uint8_t* const* d_rgb, const int* w, const int* h,
                       int reps, float* stage_ms);
+/* The same with every kernel of the pre-processing and the network enqueued `inner` times back to back inside its
+ * bracket (they are pure functions of their inputs): stage_ms[stage] = mean milliseconds of the whole bracket, so
+ * (stage_ms - empty bracket) / inner is a launch INCLUDING its in-stream boundary, with the cost of the event pair
+ * amortised rather than estimated.  The post-processing stages run once. */
+int wz_profile_stages(wz_engine_t* e, int n, const uint8_t* const* d_rgb, const int* w, const int* h,
+                      int reps, int inner, float* stage_ms);
 
 /* diagnostics: 16 words per frame written by the NMS kernel of lane 0 (phase timestamps at 100 MHz, counts) */
 int wz_debug_nms(wz_engine_t* e, int n, uint64_t* out);

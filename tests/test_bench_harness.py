@@ -32,3 +32,16 @@ def test_two_ranks_over_gloo():
     assert out["camera_seeds"] == [1234, 2234]        # every rank serves its own camera (cameras are the shard)
     single = run([sys.executable, "bench.py", "--gpus", "1", "--steps", "40", "--warmup", "4", "--dry-run"])
     assert 1.5 < out["value"] / single["value"] < 2.5   # whole-job aggregate = frames of all ranks / max time
+
+
+def test_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` WITHOUT a launcher: bench.py starts one process per device ordinal (the reference's
+    one-detector-process-per-device scheme, watsor/detection/detector.py:34-50) and still prints ONE line, n_gpus = 2."""
+    env_keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")
+    saved = {k: os.environ.pop(k) for k in env_keys if k in os.environ}
+    try:
+        out = run([sys.executable, "bench.py", "--gpus", "2", "--steps", "40", "--warmup", "4", "--dry-run"])
+    finally:
+        os.environ.update(saved)
+    assert out["n_gpus"] == 2 and out["camera_seeds"] == [1234, 2234] and out["rounds"] >= 3
+    assert 3000 < out["value"] < 16200                # two replicas of the single-process figure

@@ -12,7 +12,7 @@ from watsor_amd.coco import COCO_CLASSES
 from watsor_amd.filter.hip_filter import HipCameraFilter
 from watsor_amd.runtime import ROW_DTYPE
 from watsor_amd.share import BoundingBox, Detection
-from watsor_amd.synth import synthetic_frame
+from watsor_amd.synth import synthetic_frame, synthetic_zone_mask as blob_mask
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
@@ -132,26 +132,6 @@ def test_filters_inside_detect_batch(eng):
     with pytest.raises(ValueError):                                  # camera filter was set for 640x480
         eng.detect_batch([synthetic_frame(1280, 720, 1)], rows[:1], cams=[5])
     flt.close()
-
-
-def blob_mask(width, height, seed, n_blobs):
-    """RGBA-style alpha plane in the spirit of BASELINE configs[3]: a few filled blobs (>= 8 px thick, alpha 255)
-    on a translucent background (alpha 204), with an anti-aliased rim (alpha 230) that is NOT part of a zone."""
-    rng = np.random.default_rng(seed)
-    alpha = np.full((height, width), 204, np.uint8)
-    yy, xx = np.mgrid[0:height, 0:width]
-    for _ in range(n_blobs):
-        cx, cy = int(rng.integers(width // 8, 7 * width // 8)), int(rng.integers(height // 8, 7 * height // 8))
-        rx, ry = int(rng.integers(max(8, width // 24), width // 7)), int(rng.integers(max(8, height // 24), height // 7))
-        if rng.random() < 0.5:
-            inner = (np.abs(xx - cx) <= rx) & (np.abs(yy - cy) <= ry)
-            rim = (np.abs(xx - cx) <= rx + 2) & (np.abs(yy - cy) <= ry + 2)
-        else:
-            d = ((xx - cx) / float(rx)) ** 2 + ((yy - cy) / float(ry)) ** 2
-            inner, rim = d <= 1.0, d <= 1.08
-        alpha[rim & (alpha != 255)] = 230
-        alpha[inner] = 255
-    return alpha
 
 
 def test_many_cameras_with_masks_and_thresholds_mixed_resolutions(model_dir):

@@ -55,8 +55,10 @@ def traffic_json(agg, path):
         c = k.split("<")[0]
         if c.startswith("_Z"):
             c = "wz_k_stem" if "stem" in c else "wz_k_preprocess" if "preprocess" in c else c
-        if c.startswith("wz_k_mbconv"):
-            c = "wz_k_mbconv"                     # both fused-block kernels serve the same op class
+        if c.startswith("wz_k_mbconv_hp"):
+            c = "wz_k_mbconv_hp"                  # the split-operand blocks (0 .. 12 of the default -p 16 program)
+        elif c.startswith("wz_k_mbconv"):
+            c = "wz_k_mbconv"                     # the plain fused-block kernels serve one op class
         if c == "wz_k_conv_lds" or c == "wz_k_conv":
             c = "wz_k_conv<%s>" % k.split("<")[1].split(",")[0].split(">")[0]
         if "FETCH_SIZE" in counters:

@@ -39,7 +39,9 @@ def main(path, out=None, js=None):
             k = name.replace("void ", "").split("(")[0].split("<")[0]
             if k.startswith("_Z"):
                 k = "wz_k_stem" if "stem" in k else "wz_k_preprocess" if "preprocess" in k else k
-            if k.startswith("wz_k_mbconv"):
+            if k.startswith("wz_k_mbconv_hp"):
+                k = "wz_k_mbconv_hp"
+            elif k.startswith("wz_k_mbconv"):
                 k = "wz_k_mbconv"
             if k in ("wz_k_conv_lds", "wz_k_conv"):
                 k = "wz_k_conv<%s>" % name.split("<")[1].split(",")[0].split(">")[0]

@@ -72,6 +72,7 @@ SIGNATURES = {
     "wz_num_stages": (C.c_int, [C.c_void_p]),
     "wz_stage_name": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int]),
     "wz_profile_device": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), c_i32p, c_i32p, C.c_int, c_f32p]),
+    "wz_profile_stages": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), c_i32p, c_i32p, C.c_int, C.c_int, c_f32p]),
     "wz_debug_nms": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "wz_debug_mbconv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "wz_dev_alloc": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void wz_k_stem(const half_t* __restrict__ in, 
 void wz_launch_stem(const half_t* in, const float* w, const float* bias, half_t* out, int n, int hin, int win,
                     int hout, int wout, int pad_t, int pad_l, hipStream_t s) {
     const int total = n * hout * wout * 4;
-    hipLaunchKernelGGL(wz_k_stem, dim3((total + 255) / 256), dim3(256), 0, s, in, w, bias, out, total, hin, win,
+    WZ_LAUNCH(wz_k_stem, dim3((total + 255) / 256), dim3(256), 0, s, in, w, bias, out, total, hin, win,
                        hout, wout, pad_t, pad_l);
 }
 
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void wz_k_dw(const half_t* __restrict__ in, co
 void wz_launch_dw(const half_t* in, const half_t* w, const float* bias, half_t* out, int n, int hin, int win,
                   int c, int hout, int wout, int stride, int pad_t, int pad_l, int act, hipStream_t s) {
     const int total = n * hout * wout * (c >> 3);
-    hipLaunchKernelGGL(wz_k_dw, dim3((total + 255) / 256), dim3(256), 0, s, in, w, bias, out, total, hin, win, c,
+    WZ_LAUNCH(wz_k_dw, dim3((total + 255) / 256), dim3(256), 0, s, in, w, bias, out, total, hin, win, c,
                        hout, wout, stride, pad_t, pad_l, act);
 }
 
@@ -763,9 +763,9 @@ static void wz_launch_conv_cfg(const WzConvArgs& a, hipStream_t s) {
     const int mtiles = (a.M + MT * 16 - 1) / (MT * 16);
     dim3 grid((mtiles + 3) / 4, a.n_pad / (NT * 16), a.splitk);
     if (a.ksize == 1)
-        hipLaunchKernelGGL((wz_k_conv<1, MT, NT, U>), grid, dim3(256), 0, s, a);
+        WZ_LAUNCH((wz_k_conv<1, MT, NT, U>), grid, dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL((wz_k_conv<3, MT, NT, U>), grid, dim3(256), 0, s, a);
+        WZ_LAUNCH((wz_k_conv<3, MT, NT, U>), grid, dim3(256), 0, s, a);
 }
 
 static int wz_lds_nbuf() { return 2; }
@@ -798,11 +798,11 @@ template <int KS, int NW>
 static void wz_launch_conv_lds(const WzConvArgs& a, dim3 grid, hipStream_t s) {
     static const int rs = wz_env_int("WZ_LDS_RS", 1);
     if (rs && wz_lds_spec())
-        hipLaunchKernelGGL((wz_k_conv_rs<KS, NW, true>), grid, dim3(512), 0, s, a);
+        WZ_LAUNCH((wz_k_conv_rs<KS, NW, true>), grid, dim3(512), 0, s, a);
     else if (rs)
-        hipLaunchKernelGGL((wz_k_conv_rs<KS, NW, false>), grid, dim3(256), 0, s, a);
+        WZ_LAUNCH((wz_k_conv_rs<KS, NW, false>), grid, dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL((wz_k_conv_lds<KS, NW, 2, false>), grid, dim3(256), 2 * WZ_LDS_BUF(NW), s, a);
+        WZ_LAUNCH((wz_k_conv_lds<KS, NW, 2, false>), grid, dim3(256), 2 * WZ_LDS_BUF(NW), s, a);
 }
 
 void wz_launch_conv(const WzConvArgs& a0, hipStream_t s) {
@@ -842,9 +842,9 @@ bool wz_conv_ws_applies(const WzConvArgs& a) {
 void wz_launch_conv_ws(const WzConvArgs& a, hipStream_t s) {
     const dim3 grid((a.M + 31) / 32, a.n_pad / 32);
     if (a.ksize == 1)
-        hipLaunchKernelGGL(wz_k_conv_ws<1>, grid, dim3(512), 0, s, a);
+        WZ_LAUNCH(wz_k_conv_ws<1>, grid, dim3(512), 0, s, a);
     else
-        hipLaunchKernelGGL(wz_k_conv_ws<3>, grid, dim3(512), 0, s, a);
+        WZ_LAUNCH(wz_k_conv_ws<3>, grid, dim3(512), 0, s, a);
 }
 
 // the 3x3 convolutions wz_launch_conv would give to wz_k_conv<3, 2, 2, 4>
@@ -860,7 +860,7 @@ void wz_conv_group_add(WzConvGroup& g, const WzConvArgs& a) {
     g.first[i + 1] = g.first[i] + g.gx[i] * g.gy[i] * a.splitk;
 }
 void wz_launch_conv_group(const WzConvGroup& g, hipStream_t s) {
-    hipLaunchKernelGGL(wz_k_conv_group, dim3(g.first[g.n]), dim3(256), 0, s, g);
+    WZ_LAUNCH(wz_k_conv_group, dim3(g.first[g.n]), dim3(256), 0, s, g);
 }
 
 // the convolutions wz_launch_conv would give to wz_k_conv_rs<3, 4>
@@ -881,7 +881,7 @@ void wz_conv_rs_group_add(WzConvGroup& g, const WzConvArgs& a0) {
     g.first[i + 1] = g.first[i] + ((a.grid_m * a.grid_n * a.splitk + 7) & ~7);   // entries start on an XCD boundary
 }
 void wz_launch_conv_rs_group(const WzConvGroup& g, hipStream_t s) {
-    hipLaunchKernelGGL(wz_k_conv_rs_group, dim3(g.first[g.n]), dim3(256), 0, s, g);
+    WZ_LAUNCH(wz_k_conv_rs_group, dim3(g.first[g.n]), dim3(256), 0, s, g);
 }
 
 void wz_reduce_group_add(WzReduceGroup& g, const WzConvArgs& a, const float* ws) {
@@ -891,10 +891,10 @@ void wz_reduce_group_add(WzReduceGroup& g, const WzConvArgs& a, const float* ws)
     g.first[i + 1] = g.first[i] + (a.M * (a.n_pad >> 2) + 255) / 256;
 }
 void wz_launch_splitk_reduce_group(const WzReduceGroup& g, hipStream_t s) {
-    hipLaunchKernelGGL(wz_k_splitk_reduce_group, dim3(g.first[g.n]), dim3(256), 0, s, g);
+    WZ_LAUNCH(wz_k_splitk_reduce_group, dim3(g.first[g.n]), dim3(256), 0, s, g);
 }
 
 void wz_launch_splitk_reduce(const WzConvArgs& a, const float* ws, hipStream_t s) {
     const int total = a.M * (a.n_pad >> 2);
-    hipLaunchKernelGGL(wz_k_splitk_reduce, dim3((total + 255) / 256), dim3(256), 0, s, a, ws);
+    WZ_LAUNCH(wz_k_splitk_reduce, dim3((total + 255) / 256), dim3(256), 0, s, a, ws);
 }

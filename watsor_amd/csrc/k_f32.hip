@@ -323,9 +323,9 @@ bool wz_conv_ws_f32_applies(const WzConvArgs& a) {
 void wz_launch_conv_ws_f32(const WzConvArgs& a, hipStream_t s) {
     const dim3 grid((a.M + 31) / 32, a.n_pad / 32);
     if (a.ksize == 1)
-        hipLaunchKernelGGL(wz_k_conv_ws_f32<1>, grid, dim3(512), 0, s, a);
+        WZ_LAUNCH(wz_k_conv_ws_f32<1>, grid, dim3(512), 0, s, a);
     else
-        hipLaunchKernelGGL(wz_k_conv_ws_f32<3>, grid, dim3(512), 0, s, a);
+        WZ_LAUNCH(wz_k_conv_ws_f32<3>, grid, dim3(512), 0, s, a);
 }
 
 __global__ __launch_bounds__(256) void wz_k_splitk_reduce_f32(const WzConvArgs a) {
@@ -345,14 +345,14 @@ __global__ __launch_bounds__(256) void wz_k_splitk_reduce_f32(const WzConvArgs a
 void wz_launch_stem_f32(const half_t* in, const float* w, const float* bias, float* out, int n, int hin, int win,
                         int hout, int wout, int pad_t, int pad_l, hipStream_t s) {
     const int total = n * hout * wout * 4;
-    hipLaunchKernelGGL(wz_k_stem_f32, dim3((total + 255) / 256), dim3(256), 0, s, in, w, bias, out, total, hin, win,
+    WZ_LAUNCH(wz_k_stem_f32, dim3((total + 255) / 256), dim3(256), 0, s, in, w, bias, out, total, hin, win,
                        hout, wout, pad_t, pad_l);
 }
 
 void wz_launch_dw_f32(const float* in, const float* w, const float* bias, float* out, int n, int hin, int win, int c,
                       int hout, int wout, int stride, int pad_t, int pad_l, int act, hipStream_t s) {
     const int total = n * hout * wout * (c >> 2);
-    hipLaunchKernelGGL(wz_k_dw_f32, dim3((total + 255) / 256), dim3(256), 0, s, in, w, bias, out, total, hin, win, c,
+    WZ_LAUNCH(wz_k_dw_f32, dim3((total + 255) / 256), dim3(256), 0, s, in, w, bias, out, total, hin, win, c,
                        hout, wout, stride, pad_t, pad_l, act);
 }
 
@@ -401,18 +401,18 @@ void wz_launch_conv_f32(const WzConvArgs& a0, hipStream_t s, bool reduce) {
         const dim3 grid(a.grid_m * a.grid_n * a.splitk);
         if (nw == 4) {
             if (a.ksize == 1)
-                hipLaunchKernelGGL((wz_k_conv_rs_f32<1, 4>), grid, dim3(256), 0, s, a);
+                WZ_LAUNCH((wz_k_conv_rs_f32<1, 4>), grid, dim3(256), 0, s, a);
             else
-                hipLaunchKernelGGL((wz_k_conv_rs_f32<3, 4>), grid, dim3(256), 0, s, a);
+                WZ_LAUNCH((wz_k_conv_rs_f32<3, 4>), grid, dim3(256), 0, s, a);
         } else {
             if (a.ksize == 1)
-                hipLaunchKernelGGL((wz_k_conv_rs_f32<1, 2>), grid, dim3(256), 0, s, a);
+                WZ_LAUNCH((wz_k_conv_rs_f32<1, 2>), grid, dim3(256), 0, s, a);
             else
-                hipLaunchKernelGGL((wz_k_conv_rs_f32<3, 2>), grid, dim3(256), 0, s, a);
+                WZ_LAUNCH((wz_k_conv_rs_f32<3, 2>), grid, dim3(256), 0, s, a);
         }
         if (a.splitk > 1 && reduce) {
             const int total = a.M * (a.n_pad >> 2);
-            hipLaunchKernelGGL(wz_k_splitk_reduce_f32, dim3((total + 255) / 256), dim3(256), 0, s, a);
+            WZ_LAUNCH(wz_k_splitk_reduce_f32, dim3((total + 255) / 256), dim3(256), 0, s, a);
         }
         return;
     }
@@ -420,11 +420,11 @@ void wz_launch_conv_f32(const WzConvArgs& a0, hipStream_t s, bool reduce) {
     const int mtiles = (a.M + 31) / 32;
     dim3 grid((mtiles + 3) / 4, a.n_pad / 32, a.splitk);
     if (a.ksize == 1)
-        hipLaunchKernelGGL(wz_k_conv_f32<1>, grid, dim3(256), 0, s, a);
+        WZ_LAUNCH(wz_k_conv_f32<1>, grid, dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL(wz_k_conv_f32<3>, grid, dim3(256), 0, s, a);
+        WZ_LAUNCH(wz_k_conv_f32<3>, grid, dim3(256), 0, s, a);
     if (a.splitk > 1 && reduce) {
         const int total = a.M * (a.n_pad >> 2);
-        hipLaunchKernelGGL(wz_k_splitk_reduce_f32, dim3((total + 255) / 256), dim3(256), 0, s, a);
+        WZ_LAUNCH(wz_k_splitk_reduce_f32, dim3((total + 255) / 256), dim3(256), 0, s, a);
     }
 }

@@ -405,7 +405,7 @@ static int wz_mb_launch(WzMbArgs a, const MbCfg& c, int n, hipStream_t s, bool p
                                       160 * 1024);
         return lds <= 160 * 1024 ? 0 : -1;
     }
-    hipLaunchKernelGGL(k, dim3(a.tiles_x * a.tiles_y * n, c.nsplit), dim3(256), lds, s, a);
+    WZ_LAUNCH(k, dim3(a.tiles_x * a.tiles_y * n, c.nsplit), dim3(256), lds, s, a);
     return c.nsplit;
 }
 

@@ -262,7 +262,7 @@ static int wz_cs_launch(WzMbArgs a, int n, hipStream_t s, bool prepare) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return lds <= 160 * 1024 ? 0 : -1;
     }
-    hipLaunchKernelGGL(k, dim3(a.tiles_x * a.tiles_y * n), dim3(CS_WAVES * 64), lds, s, a);
+    WZ_LAUNCH(k, dim3(a.tiles_x * a.tiles_y * n), dim3(CS_WAVES * 64), lds, s, a);
     return 1;
 }
 

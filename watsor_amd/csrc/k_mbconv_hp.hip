@@ -52,10 +52,10 @@ __device__ __forceinline__ void wz_hp_unpack(const wz_u32x4_t t, float x[8]) {
 // MPW: halo m-tiles (16 pixels) per wave, MQW: output m-tiles per wave, KCI: 32-channel K chunks of the expand conv,
 // NTO: 16-column tiles of the project output.  STEM: the "expand" stage is the stem convolution gathered from the
 // 300x300 input pair tensor (8 halves per pixel: r g b 0 hi | r g b 0 lo), as in k_mbconv_wave.hip.
-template <bool CS, bool STEM, int MPW, int MQW, int KCI, int NTO>
-__global__ __launch_bounds__(CS ? HP_CS_WAVES * 64 : 256, 2) void wz_k_mbconv_hp(const WzMbArgs a) {
+// NW: wavefronts per workgroup (CS: they share one tile and deal its 32-channel chunks out among themselves).
+template <int NW, bool CS, bool STEM, int MPW, int MQW, int KCI, int NTO>
+__global__ __launch_bounds__(NW * 64, 2) void wz_k_mbconv_hp(const WzMbArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wz_hp_smem[];
-    constexpr int NW = CS ? HP_CS_WAVES : 4;
     constexpr int ES = 40;                               // unorm16 per row of the chunk buffer: 32 channels + 8 of padding
     constexpr int EBYTES = MPW * 16 * ES * 2;
     constexpr int RED_BYTES = CS ? NW * MQW * NTO * 1024 : 0;
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(CS ? HP_CS_WAVES * 64 : 256, 2) void wz_k_mbconv_hp
             wph[nt] = *reinterpret_cast<const half8_t*>(a.wp + off);
             wpl[nt] = *reinterpret_cast<const half8_t*>(a.wp_lo + off);
         }
-        float4_t wt0[CS ? 1 : 9], wt1[CS ? 1 : 9];
+        float4_t wt0[9], wt1[9];   // (CS: unused, the weights are read from LDS where they are needed)
         if constexpr (!CS) {
 #pragma unroll
             for (int tp = 0; tp < 9; ++tp) {
@@ -207,23 +207,37 @@ __global__ __launch_bounds__(CS ? HP_CS_WAVES * 64 : 256, 2) void wz_k_mbconv_hp
                 wt1[tp] = *reinterpret_cast<const float4_t*>(wd32 + (size_t)tp * a.cmid_pad + coff + 4);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);   // (the loads above stay above: they have the whole expand stage to land)
         // ---- expand: E[p][ce] = in-frame ? unorm16(clamp((sum_k X[p][k] We[k][ce] + be[ce]) / 6, 0, 1)) : 0
+        // per 16-channel tile the MPW pixel tiles are MPW independent accumulator chains: the three terms are issued term by
+        // term across them, so that no MFMA waits for the one in front of it
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const bool have = ce0 + nt * 16 < a.nmid_pad;    // this 16-channel tile exists (wave-uniform)
             const float4_t bv = *reinterpret_cast<const float4_t*>(be_l + ce0 + nt * 16 + g * 4);
+            float4_t d[MPW];
 #pragma unroll
             for (int i = 0; i < MPW; ++i) {
-                float4_t d = {0.f, 0.f, 0.f, 0.f};
+                d[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int c = 0; c < KCI; ++c) d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wal[nt][c], xh[i][c], d, 0, 0, 0);
+                for (int c = 0; c < KCI; ++c) d[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wal[nt][c], xh[i][c], d[i], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // (left alone, the scheduler re-serialises the chains to save registers)
 #pragma unroll
-                for (int c = 0; c < KCI; ++c) d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wah[nt][c], xl[i][c], d, 0, 0, 0);
+            for (int i = 0; i < MPW; ++i)
 #pragma unroll
-                for (int c = 0; c < KCI; ++c) d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wah[nt][c], xh[i][c], d, 0, 0, 0);
+                for (int c = 0; c < KCI; ++c) d[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wah[nt][c], xl[i][c], d[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MPW; ++i)
+#pragma unroll
+                for (int c = 0; c < KCI; ++c) d[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wah[nt][c], xh[i][c], d[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MPW; ++i) {
                 const bool keep = inimg[i] && have;
-                const wz_us2_t p0 = __builtin_amdgcn_cvt_pknorm_u16(d[0] + bv[0], d[1] + bv[1]);
-                const wz_us2_t p1 = __builtin_amdgcn_cvt_pknorm_u16(d[2] + bv[2], d[3] + bv[3]);
+                const wz_us2_t p0 = __builtin_amdgcn_cvt_pknorm_u16(d[i][0] + bv[0], d[i][1] + bv[1]);
+                const wz_us2_t p1 = __builtin_amdgcn_cvt_pknorm_u16(d[i][2] + bv[2], d[i][3] + bv[3]);
                 wz_u32x2_t o;
                 o[0] = keep ? __builtin_bit_cast(unsigned int, p0) : 0u;
                 o[1] = keep ? __builtin_bit_cast(unsigned int, p1) : 0u;
@@ -244,29 +258,44 @@ __global__ __launch_bounds__(CS ? HP_CS_WAVES * 64 : 256, 2) void wz_k_mbconv_hp
         for (int j = 0; j < MQW; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { dd[j][r] = b0[r]; dd[j][4 + r] = b1[r]; }
+        auto W0 = [&](int tp) -> float4_t {
+            if constexpr (CS) return *reinterpret_cast<const float4_t*>(wd_l + tp * a.cmid_pad + coff);
+            else return wt0[tp];
+        };
+        auto W1 = [&](int tp) -> float4_t {
+            if constexpr (CS) return *reinterpret_cast<const float4_t*>(wd_l + tp * a.cmid_pad + coff + 4);
+            else return wt1[tp];
+        };
         if constexpr (MQW == 2) {
-            // rows hp0 .. hp0 + 3 of the halo serve both outputs: row rr is tap row rr of output 0 and rr - 1 of output 1
+            // rows hp0 .. hp0 + 3 of the halo serve both outputs: row rr is tap row rr of output 0 and rr - 1 of output 1.
+            // All 12 taps are requested before the first one is used: one LDS latency instead of twelve.
             const unsigned short* ep = E + hp0[0] * ES + g * 8;
+            wz_u32x4_t tq[12];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) tq[rr * 3 + kx] = *reinterpret_cast<const wz_u32x4_t*>(ep + (rr * hw_ + kx) * ES);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     float x[8];
-                    wz_hp_unpack(*reinterpret_cast<const wz_u32x4_t*>(ep + (rr * hw_ + kx) * ES), x);
+                    wz_hp_unpack(tq[rr * 3 + kx], x);
                     if (rr < 3) {
-                        const int tp = rr * 3 + kx;
+                        const float4_t w0 = W0(rr * 3 + kx), w1 = W1(rr * 3 + kx);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            dd[0][r] = fmaf(x[r], wt0[tp][r], dd[0][r]);
-                            dd[0][4 + r] = fmaf(x[4 + r], wt1[tp][r], dd[0][4 + r]);
+                            dd[0][r] = fmaf(x[r], w0[r], dd[0][r]);
+                            dd[0][4 + r] = fmaf(x[4 + r], w1[r], dd[0][4 + r]);
                         }
                     }
                     if (rr > 0) {
-                        const int tp = (rr - 1) * 3 + kx;
+                        const float4_t w0 = W0((rr - 1) * 3 + kx), w1 = W1((rr - 1) * 3 + kx);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            dd[1][r] = fmaf(x[r], wt0[tp][r], dd[1][r]);
-                            dd[1][4 + r] = fmaf(x[4 + r], wt1[tp][r], dd[1][4 + r]);
+                            dd[1][r] = fmaf(x[r], w0[r], dd[1][r]);
+                            dd[1][4 + r] = fmaf(x[4 + r], w1[r], dd[1][4 + r]);
                         }
                     }
                 }
@@ -274,21 +303,28 @@ __global__ __launch_bounds__(CS ? HP_CS_WAVES * 64 : 256, 2) void wz_k_mbconv_hp
 #pragma unroll
             for (int j = 0; j < MQW; ++j) {
                 const unsigned short* ep = E + hp0[j] * ES + g * 8;
+                // the taps are requested ahead of their use, all nine at once where the registers allow it
+                constexpr int ROWS = KCI >= 3 ? 1 : 3;          // tap rows per request group
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
+                for (int k0 = 0; k0 < 3; k0 += ROWS) {
+                    wz_u32x4_t tq[ROWS * 3];
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
+                    for (int t = 0; t < ROWS * 3; ++t)
+                        tq[t] = *reinterpret_cast<const wz_u32x4_t*>(ep + ((k0 + t / 3) * hw_ + t % 3) * ES);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < ROWS * 3; ++t) {
+                        const int tp = k0 * 3 + t;
                         float x[8];
-                        wz_hp_unpack(*reinterpret_cast<const wz_u32x4_t*>(ep + (ky * hw_ + kx) * ES), x);
-                        const int tp = ky * 3 + kx;
-                        const float4_t w0 = CS ? *reinterpret_cast<const float4_t*>(wd_l + tp * a.cmid_pad + coff) : wt0[CS ? 0 : tp];
-                        const float4_t w1 = CS ? *reinterpret_cast<const float4_t*>(wd_l + tp * a.cmid_pad + coff + 4) : wt1[CS ? 0 : tp];
+                        wz_hp_unpack(tq[t], x);
+                        const float4_t w0 = W0(tp), w1 = W1(tp);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             dd[j][r] = fmaf(x[r], w0[r], dd[j][r]);
                             dd[j][4 + r] = fmaf(x[4 + r], w1[r], dd[j][4 + r]);
                         }
                     }
+                }
             }
         }
         // ---- relu6, split, project: acc += Wlo.dhi + Whi.dlo + Whi.dhi
@@ -378,50 +414,75 @@ __global__ __launch_bounds__(CS ? HP_CS_WAVES * 64 : 256, 2) void wz_k_mbconv_hp
 }
 
 // ---------------------------------------------------------------------------------------------
-template <bool CS, bool STEM, int MPW, int MQW, int KCI, int NTO>
+static int wz_hp_env(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return (e && atoi(e) > 0) ? atoi(e) : dflt;
+}
+
+template <int NW, bool CS, bool STEM, int MPW, int MQW, int KCI, int NTO>
 static int wz_hp_launch(WzMbArgs a, int n, hipStream_t s, bool prepare) {
     a.nb = n;
-    constexpr int NW = CS ? HP_CS_WAVES : 4;
+    if (MQW == 2) { a.th = 4; a.tw = 8; } else { a.th = 4; a.tw = 4; }
+    a.tiles_y = (a.hout + a.th - 1) / a.th;
+    a.tiles_x = (a.wout + a.tw - 1) / a.tw;
     constexpr int EB = MPW * 16 * 40 * 2;
     constexpr int RED = CS ? NW * MQW * NTO * 1024 : 0;
     const size_t region = (size_t)(NW * EB > RED ? NW * EB : RED);
     const size_t lds = region + (size_t)a.cmid_pad * (CS ? 8 + 36 : 8);
-    auto k = wz_k_mbconv_hp<CS, STEM, MPW, MQW, KCI, NTO>;
+    auto k = wz_k_mbconv_hp<NW, CS, STEM, MPW, MQW, KCI, NTO>;
     if (prepare) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return lds <= 160 * 1024 ? 0 : -1;
     }
     const int tiles = a.tiles_x * a.tiles_y * n;
-    hipLaunchKernelGGL(k, dim3(CS ? tiles : (tiles + 3) / 4), dim3(NW * 64), lds, s, a);
+    WZ_LAUNCH(k, dim3(CS ? tiles : (tiles + 3) / 4), dim3(NW * 64), lds, s, a);
     return 1;
 }
 
 // Blocks 0 (with the stem) .. 12 of SSD-MobileNet-v2 300x300.  prepare: 0 = a kernel exists (its attributes are set),
 // -1 = no kernel for this shape; launch: 1.
+//   maps wider than WZ_HP_CS_MAX_W (default 19): one wavefront per tile, every wave walks all chunks;
+//   19x19: 8 waves per 4x4 tile, 2 - 3 chunks per wave;
+//   WZ_HP_CS_MAX_W=38 / 75 puts the 38x38 / 75x75 maps on workgroups of 5 / 6 waves per tile with ONE chunk per wave as
+//     well.  Measured (profiles/r02c_*): the 38x38 stride-1 blocks get faster alone (13.6 -> 11.0 us: 100 tiles x 8 frames of
+//     waves walking 6 chunks each leave most of the GPU idle) but every wave repeats the halo load and the accumulators
+//     take a trip through LDS, and with four lanes in flight CU x time is what counts: 37.2 k frames/s against 40.2 k
+//     with one wave per tile (75x75 on it as well: 35.0 k).
 int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) {
+    static const int cs_max_w = wz_hp_env("WZ_HP_CS_MAX_W", 19);
     const int nto = a0.n_pad / 16;
     WzMbArgs a = a0;
     a.nsplit = 1;
     if (a.nmid_pad != a.cmid_pad || (a.cmid_pad & 31) || a.kc != (a.cmid_pad >> 5) || !a.we_lo || !a.wp_lo) return -1;
-    if (a.stem || a.wout >= 38) {   // one wavefront per tile
-        if (a.kc0 != 1 || nto != 2) return -1;
-        if (a.stride == 1) { a.th = 4; a.tw = 8; } else { a.th = 4; a.tw = 4; }
-        a.tiles_y = (a.hout + a.th - 1) / a.th;
-        a.tiles_x = (a.wout + a.tw - 1) / a.tw;
-        if (a.stem) return a.stride == 1 ? wz_hp_launch<false, true, 4, 2, 1, 2>(a, n, s, prepare) : -1;
-        if (a.cin0 == 0) return -1;
-        if (a.stride == 1) return wz_hp_launch<false, false, 4, 2, 1, 2>(a, n, s, prepare);   // halo 6 x 10 = 60 pixels
-        return wz_hp_launch<false, false, 6, 1, 1, 2>(a, n, s, prepare);                       // halo 9 x 9 = 81 pixels
-    }
+    const int nk32 = a.cmid_pad >> 5;
+    if (a.stem) return (a.kc0 == 1 && nto == 2 && a.stride == 1) ? wz_hp_launch<4, false, true, 4, 2, 1, 2>(a, n, s, prepare) : -1;
     if (a.cin0 == 0) return -1;
-    a.th = 4; a.tw = 4;
-    a.tiles_y = (a.hout + a.th - 1) / a.th;
-    a.tiles_x = (a.wout + a.tw - 1) / a.tw;
+    if (a.wout > 19 && a.kc0 == 1 && nto == 2) {
+        const bool cs = (prepare || a.wout <= cs_max_w) && nk32 >= 4 && nk32 <= 6;
+        if (a.stride == 1) {        // 4 x 8 tiles, halo 6 x 10 = 60 pixels
+            if (prepare) {
+                (void)wz_hp_launch<5, true, false, 4, 2, 1, 2>(a, n, s, true);
+                (void)wz_hp_launch<6, true, false, 4, 2, 1, 2>(a, n, s, true);
+                return wz_hp_launch<4, false, false, 4, 2, 1, 2>(a, n, s, true);
+            }
+            if (cs && nk32 <= 5) return wz_hp_launch<5, true, false, 4, 2, 1, 2>(a, n, s, false);
+            if (cs) return wz_hp_launch<6, true, false, 4, 2, 1, 2>(a, n, s, false);
+            return wz_hp_launch<4, false, false, 4, 2, 1, 2>(a, n, s, false);
+        }
+        // stride 2: 4 x 4 tiles, halo 9 x 9 = 81 pixels
+        if (prepare) {
+            (void)wz_hp_launch<5, true, false, 6, 1, 1, 2>(a, n, s, true);
+            return wz_hp_launch<4, false, false, 6, 1, 1, 2>(a, n, s, true);
+        }
+        if (cs && nk32 <= 5) return wz_hp_launch<5, true, false, 6, 1, 1, 2>(a, n, s, false);
+        return wz_hp_launch<4, false, false, 6, 1, 1, 2>(a, n, s, false);
+    }
+    if (a.wout > 19) return -1;
     if (a.stride == 2) {
-        if (a.kc0 == 1 && nto == 4) return wz_hp_launch<true, false, 6, 1, 1, 4>(a, n, s, prepare);
+        if (a.kc0 == 1 && nto == 4) return wz_hp_launch<HP_CS_WAVES, true, false, 6, 1, 1, 4>(a, n, s, prepare);
         return -1;
     }
-#define HP_CASE(K, N) if (a.kc0 == K && nto == N) return wz_hp_launch<true, false, 3, 1, K, N>(a, n, s, prepare)
+#define HP_CASE(K, N) if (a.kc0 == K && nto == N) return wz_hp_launch<HP_CS_WAVES, true, false, 3, 1, K, N>(a, n, s, prepare)
     HP_CASE(2, 4);
     HP_CASE(2, 6);
     HP_CASE(3, 6);

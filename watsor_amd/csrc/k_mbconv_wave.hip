@@ -260,7 +260,7 @@ static int wz_mbw_launch(WzMbArgs a, int n, hipStream_t s, bool prepare) {
         return lds <= 160 * 1024 ? 0 : -1;
     }
     const int waves = a.tiles_x * a.tiles_y * n;
-    hipLaunchKernelGGL(k, dim3((waves + 3) / 4), dim3(256), lds, s, a);
+    WZ_LAUNCH(k, dim3((waves + 3) / 4), dim3(256), lds, s, a);
     return 1;
 }
 

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void wz_k_preprocess(const WzFrameDesc* __rest
 void wz_launch_preprocess(const WzFrameDesc* d_frames, int n, int size, half_t* out, hipStream_t s, bool hp) {
     dim3 grid((size * size + 255) / 256, n);
     if (hp)
-        hipLaunchKernelGGL(wz_k_preprocess<true>, grid, dim3(256), 0, s, d_frames, size, out);
+        WZ_LAUNCH(wz_k_preprocess<true>, grid, dim3(256), 0, s, d_frames, size, out);
     else
-        hipLaunchKernelGGL(wz_k_preprocess<false>, grid, dim3(256), 0, s, d_frames, size, out);
+        WZ_LAUNCH(wz_k_preprocess<false>, grid, dim3(256), 0, s, d_frames, size, out);
 }

@@ -107,6 +107,11 @@ struct WzPostConsts {
 };
 
 // ---- launchers (each enqueues exactly one kernel on `s`) ------------------------------------
+// ... except under wz_profile_stages(), which has the network's launchers enqueue every kernel `wz_launch_repeat` times
+// back to back (all of them are pure functions of their inputs): the bracket around a stage then holds N launches and
+// their N - 1 in-stream boundaries, and the one-off cost of the event pair is amortised instead of estimated.
+extern thread_local int wz_launch_repeat;
+#define WZ_LAUNCH(...) do { for (int _wz_r = 0; _wz_r < wz_launch_repeat; ++_wz_r) hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 // hp: the input tensor is a hi + lo pair (8 halves per pixel: r g b 0 | r g b 0)
 void wz_launch_preprocess(const WzFrameDesc* d_frames, int n, int size, half_t* out, hipStream_t s, bool hp = false);
 void wz_launch_stem(const half_t* in, const float* w, const float* bias, half_t* out, int n, int hin, int win,

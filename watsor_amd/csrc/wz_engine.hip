@@ -22,6 +22,7 @@
 // when the HIP runtime initialises, i.e. at the first HIP call, which cannot precede this constructor.
 __attribute__((constructor)) static void wz_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
+thread_local int wz_launch_repeat = 1;
 static thread_local char g_err[512] = "";
 static int wz_fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -395,14 +396,17 @@ static void enqueue_post(wz_engine* e, Lane& L, bool rows, int n, StageTimer* t,
 }
 
 // everything between "descriptors are in h_desc[slot]" and "rows are in h_rows[slot]"
-static void enqueue_batch(wz_engine* e, Lane& L, int n, StageTimer* t) {
+// inner > 1 (profiling only): every kernel of the pre-processing and the network is enqueued `inner` times back to back
+static void enqueue_batch(wz_engine* e, Lane& L, int n, StageTimer* t, int inner = 1) {
     hipStream_t s = L.stream;
     if (t) t->mark();   // "(empty)": two event records with nothing between them = the bracket's own cost
     (void)hipMemcpyAsync(L.d_desc, L.h_desc, sizeof(WzFrameDesc) * n, hipMemcpyHostToDevice, s);
     if (t) t->mark();
+    wz_launch_repeat = inner;
     wz_launch_preprocess(L.d_desc, n, (int)e->hdr.input_size, L.tptr[input_tensor_index(e)], s, input_is_pair(e));
     if (t) t->mark();
     enqueue_network(e, L, n, t);
+    wz_launch_repeat = 1;
     enqueue_post(e, L, true, n, t, L.decode_fused, L.cands_listed);
 }
 
@@ -1038,7 +1042,12 @@ extern "C" int wz_stage_name(wz_engine_t* e, int stage, char* name, int namelen)
 
 extern "C" int wz_profile_device(wz_engine_t* e, int n, const uint8_t* const* d_rgb, const int* w, const int* h,
                                  int reps, float* stage_ms) {
-    if (!e || !stage_ms || reps < 1) return wz_fail(WZ_EINVAL, "wz_profile_device: bad argument");
+    return wz_profile_stages(e, n, d_rgb, w, h, reps, 1, stage_ms);
+}
+
+extern "C" int wz_profile_stages(wz_engine_t* e, int n, const uint8_t* const* d_rgb, const int* w, const int* h,
+                                 int reps, int inner, float* stage_ms) {
+    if (!e || !stage_ms || reps < 1 || inner < 1 || inner > 64) return wz_fail(WZ_EINVAL, "wz_profile_stages: bad argument");
     HIPCHK(hipSetDevice(e->device));
     { int _rc = sync_all(e); if (_rc != WZ_OK) return _rc; }
     int rc = fill_desc(e, 0, n, d_rgb, w, h, nullptr);
@@ -1050,7 +1059,7 @@ extern "C" int wz_profile_device(wz_engine_t* e, int n, const uint8_t* const* d_
     for (int r = 0; r < reps + 1; ++r) {   // first repetition is an untimed warm-up
         t.used = 0;
         t.mark();
-        enqueue_batch(e, e->lanes[0], n, &t);
+        enqueue_batch(e, e->lanes[0], n, &t, inner);
         HIPCHK(hipStreamSynchronize(e->stream));
         if (t.used != ns + 1) return wz_fail(WZ_EINVAL, "profile: %zu marks for %zu stages", t.used, ns);
         if (r == 0) continue;

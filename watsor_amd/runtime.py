@@ -231,12 +231,14 @@ class HipEngine:
             out.append(name.value.decode())
         return out
 
-    def profile_device(self, d_frames: Sequence[int], widths: Sequence[int], heights: Sequence[int], reps: int = 10):
+    def profile_device(self, d_frames: Sequence[int], widths: Sequence[int], heights: Sequence[int], reps: int = 10,
+                       inner: int = 1):
+        """[(stage name, ms of its event bracket)]; inner > 1: every network kernel `inner` times back to back in its bracket."""
         n = len(d_frames)
         ns = self._lib.wz_num_stages(self._h)
         ms = (C.c_float * ns)()
-        _lib.check(self._lib.wz_profile_device(self._h, n, (C.c_void_p * n)(*d_frames), (C.c_int32 * n)(*widths),
-                                               (C.c_int32 * n)(*heights), reps, ms))
+        _lib.check(self._lib.wz_profile_stages(self._h, n, (C.c_void_p * n)(*d_frames), (C.c_int32 * n)(*widths),
+                                               (C.c_int32 * n)(*heights), reps, inner, ms))
         return list(zip(self.stage_names(), [float(x) for x in ms]))
 
     # -- stage-level entry points (parity tests) --------------------------------------------------

@@ -90,3 +90,24 @@ def synthetic_frame(width: int, height: int, seed: int, n_shapes: int = 4) -> np
             m = ((xx - cx) / float(rw)) ** 2 + ((yy - cy) / float(rh)) ** 2 <= 1.0
         img[m] = color
     return np.ascontiguousarray(np.clip(np.rint(img), 0, 255).astype(np.uint8))   # packed RGB24, row-major
+
+
+def synthetic_zone_mask(width: int, height: int, seed: int, n_blobs: int) -> np.ndarray:
+    """Alpha plane (H,W uint8) of a camera's zone mask in the spirit of BASELINE configs[3] and the reference's
+    `config/porch.png`: a few filled blobs (>= 8 px thick, alpha 255 = zone, `watsor/filter/mask.py:77-88`) on a
+    translucent background (alpha 204), with an anti-aliased rim (alpha 230) that is NOT part of a zone."""
+    rng = np.random.default_rng(seed)
+    alpha = np.full((height, width), 204, np.uint8)
+    yy, xx = np.mgrid[0:height, 0:width]
+    for _ in range(n_blobs):
+        cx, cy = int(rng.integers(width // 8, 7 * width // 8)), int(rng.integers(height // 8, 7 * height // 8))
+        rx, ry = int(rng.integers(max(8, width // 24), width // 7)), int(rng.integers(max(8, height // 24), height // 7))
+        if rng.random() < 0.5:
+            inner = (np.abs(xx - cx) <= rx) & (np.abs(yy - cy) <= ry)
+            rim = (np.abs(xx - cx) <= rx + 2) & (np.abs(yy - cy) <= ry + 2)
+        else:
+            d = ((xx - cx) / float(rx)) ** 2 + ((yy - cy) / float(ry)) ** 2
+            inner, rim = d <= 1.0, d <= 1.08
+        alpha[rim & (alpha != 255)] = 230
+        alpha[inner] = 255
+    return alpha
