@@ -1,0 +1,115 @@
+"""The HIP plugin under the worker logic in a SPAWNED process (`watsor/main.py:474` sets the spawn start method;
+`watsor/detection/detector.py:84-112` is the worker): HIP context created after spawn, frames and `Detection[100]` rows
+in `multiprocessing.sharedctypes` memory created by the parent, that memory page-locked in the child
+(`wz_host_register`), batches submitted asynchronously on two lanes -- and the rows the parent then reads are
+bit-for-bit the rows of an in-process call on the same frames.  No Watsor needed (stand-ins: tests/shm_standins.py)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import shm_standins as shm
+from conftest import make_engine
+from watsor_amd.coco import COCO_CLASSES
+from watsor_amd.runtime import ROW_DTYPE
+from watsor_amd.synth import synthetic_frame, synthetic_zone_mask
+
+pytestmark = pytest.mark.gpu
+
+
+def rows_of(frame):
+    return np.frombuffer(frame.header.get_obj().detections, dtype=ROW_DTYPE).copy()
+
+
+def fill(frame, img):
+    np.copyto(np.frombuffer(frame.image.get_obj(), np.uint8), img.reshape(-1))
+
+
+def run_child(ctx, *args, **kw):
+    import gpu_worker_child
+    rq = ctx.Queue()
+    p = ctx.Process(target=gpu_worker_child.run_worker, args=args + (rq,), kwargs=kw)
+    p.start()
+    status, a, b, c = rq.get(timeout=240)
+    p.join(60)
+    assert status == "ok", a
+    assert p.exitcode == 0
+    return a, b, c
+
+
+@pytest.mark.parametrize("asynchronous", [True, False])
+def test_plugin_in_a_spawned_worker_writes_the_same_rows(model_dir, asynchronous):
+    ctx = shm.spawn_context()
+    cams = {"cam%d" % c: shm.FrameBuffer(ctx, 3, *((640, 480) if c % 2 == 0 else (1280, 720))) for c in range(5)}
+    images = {}
+    batches = []
+    for rnd in range(3):                                   # three rounds: one frame of every camera per round
+        batch = []
+        for c, (name, fb) in enumerate(sorted(cams.items())):
+            img = synthetic_frame(fb.frames[0].header.width, fb.frames[0].header.height, 900 + 10 * rnd + c)
+            fill(fb.frames[rnd], img)
+            images[(name, rnd)] = img
+            batch.append(shm.Payload(name, rnd))
+        batches.append(batch)
+    fps, inference_time = shm.Gauge(ctx), shm.Gauge(ctx)
+    name, opts, pinned = run_child(ctx, model_dir, cams, batches, fps, inference_time, None, False, asynchronous=asynchronous)
+    assert "gfx950" in name or "MI3" in name
+    assert opts == {"max_width": 1280, "max_height": 720}          # derived from the frame buffers, not from env defaults
+    assert pinned == 15                                             # every Frame.image of every camera was page-locked
+    # the parent reads the rows out of shared memory and compares with an in-process engine
+    e = make_engine(model_dir, max_batch=8, max_width=1280, max_height=720)
+    try:
+        for (cam, rnd), img in images.items():
+            got = rows_of(cams[cam].frames[rnd])
+            ref = np.zeros(100, ROW_DTYPE)
+            e.detect_batch([img], [ref])
+            assert got.tobytes() == ref.tobytes(), (cam, rnd)
+            assert got["label"][0] >= 1 and got["confidence"][0] > 0
+    finally:
+        e.close()
+    for fb in cams.values():                                        # exactly one latch step per dequeued payload
+        assert [f.latch.steps.value for f in fb.frames] == [1, 1, 1]
+    assert fps.count.value == 15 and inference_time.count.value == 15
+    # inference_time is the per-frame share of a batch, not the batch time once per frame
+    assert 0 < inference_time.total.value / 15 < 50
+
+
+def test_spawned_worker_runs_the_camera_filters(model_dir):
+    """`hip_cameras` / `hip_drop`: the camera's Confidence / Area / Mask filters are registered in the worker process and
+    frames are tagged with their camera id -- rows failing the filters arrive as all-zero rows, the others carry zones."""
+    ctx = shm.spawn_context()
+    cams = {"porch": shm.FrameBuffer(ctx, 2, 640, 480), "yard": shm.FrameBuffer(ctx, 2, 640, 480)}
+    alpha = synthetic_zone_mask(640, 480, 5, 4)
+    import os
+    import tempfile
+    from PIL import Image
+    d = tempfile.mkdtemp()
+    rgba = np.zeros((480, 640, 4), np.uint8)
+    rgba[..., 3] = alpha
+    Image.fromarray(rgba, "RGBA").save(os.path.join(d, "porch.png"))
+    cfg = {"width": 640, "height": 480, "mask": os.path.join(d, "porch.png"),
+           "detect": [{n: {"area": 2, "confidence": 20, "zones": []}} for n in dict.fromkeys(COCO_CLASSES[1:])]}
+    img = synthetic_frame(640, 480, 4242)
+    for fb in cams.values():
+        fill(fb.frames[0], img)
+    batches = [[shm.Payload("porch", 0), shm.Payload("yard", 0)]]
+    run_child(ctx, model_dir, cams, batches, shm.Gauge(ctx), shm.Gauge(ctx), {"porch": cfg}, True)
+    porch, yard = rows_of(cams["porch"].frames[0]), rows_of(cams["yard"].frames[0])
+    assert (yard["label"] >= 1).all() and not yard["zones"].any()               # no filter configured: raw rows
+    dropped = porch["label"] == 0
+    assert dropped.any() and not dropped.all()
+    assert porch[dropped].tobytes() == bytes(72 * int(dropped.sum()))           # failing rows: all-zero records
+    kept = ~dropped
+    assert porch[kept].tobytes() != yard[kept].tobytes() or porch["zones"][kept].any()
+    assert (porch["confidence"][kept] >= 0.2).all() and (porch["zones"][kept] > 0).any()
+    # same verdict as the in-process filter on the raw rows
+    from watsor_amd.filter.hip_filter import HipCameraFilter
+    e = make_engine(model_dir, max_batch=2, max_width=640, max_height=480)
+    try:
+        flt = HipCameraFilter(e, 0, cfg)
+        raw = yard.copy()
+        ok = flt.filter_rows(raw).astype(bool)
+        np.testing.assert_array_equal(ok, kept)
+        np.testing.assert_array_equal(raw["zones"][kept], porch["zones"][kept])
+    finally:
+        e.close()

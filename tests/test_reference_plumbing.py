@@ -231,3 +231,14 @@ def test_factory_defers_to_reference_when_no_engine_file(reference_on_path, tmp_
     from watsor_amd.detection import detector as d
     with pytest.raises(AssertionError, match="Failed to create an object detector"):
         d.create_object_detectors(Thread, Event(), Queue(), Queue(), {}, str(tmp_path))   # no TF here either
+
+
+def test_worker_class_survives_the_spawn_start_method(reference_on_path):
+    """`watsor/main.py:474` selects 'spawn': the detector object is pickled into the child, so its class must be reachable
+    by name (it is derived from the reference's `ObjectDetector` on first use)."""
+    import pickle
+    from watsor.detection.detector import ObjectDetector
+    from watsor_amd.detection import detector as d
+    cls = d.BatchedObjectDetector
+    assert issubclass(cls, ObjectDetector) and issubclass(cls, d.BatchedWorkerMixin)
+    assert pickle.loads(pickle.dumps(cls)) is cls

@@ -1,0 +1,147 @@
+"""`BatchedWorkerMixin` (watsor_amd/detection/detector.py) on the CPU with a scripted detector: batching, camera ids,
+asynchronous submit / retire over the lanes, one latch step per payload, per-frame inference time, fall-backs."""
+import queue
+
+import numpy as np
+
+import shm_standins as shm
+from watsor_amd.detection.detector import BatchedWorkerMixin, hip_detector_options
+
+
+class ScriptedDetector:
+    max_batch = 4
+    num_lanes = 3
+
+    def __init__(self, reject_width=None):
+        self.log = []
+        self.busy = {}
+        self.reject_width = reject_width
+        self.max_in_flight = 0
+
+    def bind_cameras(self, frame_buffers, camera_configs=None, drop=False, logger=None):
+        self.log.append(("bind", sorted(frame_buffers), camera_configs, drop))
+        return {n: i for i, n in enumerate(sorted(frame_buffers))}
+
+    def _check(self, images):
+        if self.reject_width is not None and any(im.shape[1] == self.reject_width for im in images):
+            raise ValueError("frame too large")
+
+    def _fill(self, im, det, cam):
+        det[0].label = 1 + int(im.reshape(-1)[0])
+        det[0].bounding_box.x_min = -1 if cam is None else cam
+
+    def submit_host(self, lane, images, cameras=None):
+        self._check(images)
+        assert lane not in self.busy, "lane reused before it was collected"
+        self.busy[lane] = (list(images), cameras)
+        self.max_in_flight = max(self.max_in_flight, len(self.busy))
+        self.log.append(("submit", lane, len(images)))
+
+    def collect(self, lane, detections):
+        images, cameras = self.busy.pop(lane)
+        for i, (im, d) in enumerate(zip(images, detections)):
+            self._fill(im, d, cameras[i] if cameras else None)
+        self.log.append(("collect", lane, len(images)))
+
+    def detect_batch(self, shapes, images, detections, cameras=None):
+        self._check(images)
+        for i, (im, d) in enumerate(zip(images, detections)):
+            self._fill(im, d, cameras[i] if cameras else None)
+        self.log.append(("sync", len(images)))
+        return 4.0 * len(images)
+
+    def detect(self, shape, image, detections):
+        self._fill(image, detections, None)
+        return 1.0
+
+
+class Worker(BatchedWorkerMixin):
+    _logger = None
+    idle = 0
+
+    def _no_frame(self, *a, **k):
+        self.idle += 1
+
+
+def setup(n_cams=3, wide=None):
+    ctx = shm.spawn_context()
+    cams = {"cam%d" % c: shm.FrameBuffer(ctx, 4, 96 if c == wide else 64, 48) for c in range(n_cams)}
+    for c, fb in enumerate(sorted(cams)):
+        for i, f in enumerate(cams[fb].frames):
+            np.frombuffer(f.image.get_obj(), np.uint8)[:] = 10 * c + i
+    return ctx, cams
+
+
+def drive(w, det, cams, batches, **kwargs):
+    ctx = shm.spawn_context()
+    q = queue.Queue()
+    fps, it = shm.Gauge(ctx), shm.Gauge(ctx)
+    for b in batches:
+        for p in b:
+            q.put(p)
+        while not q.empty():
+            w._process(q, None, cams, fps, it, det, **kwargs)
+    w.drain(fps, it)
+    return fps, it
+
+
+def first_row(frame):
+    d = frame.header.get_obj().detections[0]
+    return d.label, d.bounding_box.x_min
+
+
+def test_async_batches_over_two_lanes():
+    _, cams = setup()
+    det, w = ScriptedDetector(), Worker()
+    batches = [[shm.Payload("cam%d" % c, i) for c in range(3)] for i in range(4)]
+    fps, it = drive(w, det, cams, batches, hip_lanes=2, hip_cameras={"cam1": {"x": 1}}, hip_drop=True)
+    assert det.log[0] == ("bind", ["cam0", "cam1", "cam2"], {"cam1": {"x": 1}}, True)
+    assert [e for e in det.log if e[0] == "submit"] == [("submit", i % 2, 3) for i in range(4)]
+    assert det.max_in_flight <= 2 and not det.busy
+    for c in range(3):
+        for i in range(4):
+            f = cams["cam%d" % c].frames[i]
+            assert first_row(f) == (1 + 10 * c + i, c)              # right frame, tagged with its camera id
+            assert f.latch.steps.value == 1
+    assert fps.count.value == 12 and it.count.value == 12
+
+
+def test_sync_path_reports_per_frame_time_and_camera_ids():
+    _, cams = setup()
+    det, w = ScriptedDetector(), Worker()
+    fps, it = drive(w, det, cams, [[shm.Payload("cam0", 0), shm.Payload("cam2", 1)]], hip_async=False)
+    assert ("sync", 2) in det.log and first_row(cams["cam2"].frames[1]) == (22, 2)
+    assert it.count.value == 2 and abs(it.total.value - 8.0) < 1e-9   # 8 ms for the batch -> 4 ms per frame, twice
+    assert w.idle == 0
+
+
+def test_rejected_batch_is_retried_frame_by_frame_and_every_payload_is_released():
+    _, cams = setup(wide=1)
+    det, w = ScriptedDetector(reject_width=96), Worker()
+    batch = [shm.Payload("cam0", 0), shm.Payload("cam1", 0), shm.Payload("cam2", 0), shm.Payload("nobody", 7)]
+    fps, it = drive(w, det, cams, [batch], hip_lanes=2)
+    assert first_row(cams["cam0"].frames[0]) == (1, 0) and first_row(cams["cam2"].frames[0]) == (21, 2)
+    assert first_row(cams["cam1"].frames[0]) == (0, 0)                # the oversized camera's frame: skipped, not fatal
+    assert [cams["cam%d" % c].frames[0].latch.steps.value for c in range(3)] == [1, 1, 1]
+    assert fps.count.value == 2
+
+
+def test_options_follow_the_frame_buffers():
+    _, cams = setup(wide=2)
+    assert hip_detector_options(cams, {}) == {"max_width": 96, "max_height": 48}
+    assert hip_detector_options(cams, {"hip_options": {"max_width": 4096, "max_batch": 16}}) == \
+        {"max_width": 4096, "max_height": 48, "max_batch": 16}
+    assert hip_detector_options({}, {}) == {}
+
+
+def test_plain_plugin_without_batch_or_async_api():
+    class Plain:
+        def detect(self, shape, image, detections):
+            detections[0].label = 5
+            return 2.0
+
+    _, cams = setup()
+    w = Worker()
+    fps, it = drive(w, Plain(), cams, [[shm.Payload("cam0", 0)], [shm.Payload("cam1", 1)]])
+    assert first_row(cams["cam0"].frames[0])[0] == 5 and first_row(cams["cam1"].frames[1])[0] == 5
+    assert fps.count.value == 2 and abs(it.total.value - 4.0) < 1e-9

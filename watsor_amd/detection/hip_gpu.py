@@ -31,16 +31,22 @@ ENGINE_FILE = "mi355x.bin"       # the analogue of gpu.trt (watsor/detection/det
 class HipObjectDetector:
     """Performs object detection on AMD Instinct MI355X GPUs (hand-written HIP kernels)."""
 
-    def __init__(self, model_path, device: int = 0, max_batch: Optional[int] = None,
+    def __init__(self, model_path, device: int = 0, options: Optional[dict] = None, max_batch: Optional[int] = None,
                  max_width: Optional[int] = None, max_height: Optional[int] = None):
+        """`options` (third positional argument, what `create_object_detectors` passes in `detector_args`):
+        dict(max_batch=, max_width=, max_height=) -- the factory derives the frame size from the cameras' frame buffers;
+        the keyword forms and the WATSOR_HIP_MAX_* environment variables are the fallbacks."""
         engine_path = os.path.join(model_path, ENGINE_FILE)
         if not os.path.isfile(engine_path):
             raise FileNotFoundError(engine_path)
-        max_batch = max_batch or int(os.environ.get("WATSOR_HIP_MAX_BATCH", "8"))
-        max_width = max_width or int(os.environ.get("WATSOR_HIP_MAX_WIDTH", "1920"))
-        max_height = max_height or int(os.environ.get("WATSOR_HIP_MAX_HEIGHT", "1080"))
+        options = options or {}
+        max_batch = max_batch or options.get("max_batch") or int(os.environ.get("WATSOR_HIP_MAX_BATCH", "8"))
+        max_width = max_width or options.get("max_width") or int(os.environ.get("WATSOR_HIP_MAX_WIDTH", "1920"))
+        max_height = max_height or options.get("max_height") or int(os.environ.get("WATSOR_HIP_MAX_HEIGHT", "1080"))
         self.__engine = HipEngine(engine_path, device, max_batch, max_width, max_height)
         self.__device = device
+        self.__filters = []
+        self.__pinned = []
 
     @property
     def engine(self) -> HipEngine:
@@ -58,7 +64,53 @@ class HipObjectDetector:
         return self
 
     def __exit__(self, exc_type, exc_value, traceback):
-        self.__engine.close()
+        try:
+            self.__engine.sync()
+            for addr in self.__pinned:
+                try:
+                    self.__engine.host_unregister_address(addr)
+                except (RuntimeError, ValueError):
+                    pass
+        finally:
+            self.__pinned = []
+            self.__engine.close()
+
+    # -- what `BatchedObjectDetector` uses inside the worker process ----------------------------------------------------
+    @property
+    def num_lanes(self) -> int:
+        return self.__engine.num_slots
+
+    def bind_cameras(self, frame_buffers, camera_configs=None, drop: bool = False, logger=None):
+        """Called once in the worker process.  Gives every camera (key of `frame_buffers`) an id, registers the GPU
+        filters of the cameras whose (normalised) configuration is given -- `HipCameraFilter`, i.e. the reference's
+        ConfidenceFilter / AreaFilter / MaskFilter constructors (`watsor/filter/{confidence,area,mask}.py`) -- and
+        page-locks every `Frame.image` array (`watsor/stream/share.py:35-41`) so that `submit_host` moves pixels by DMA.
+        Returns {camera name: id}."""
+        from ..filter.hip_filter import HipCameraFilter
+        ids = {name: i for i, name in enumerate(sorted(frame_buffers, key=str))}
+        for name, cfg in (camera_configs or {}).items():
+            if name in ids:
+                self.__filters.append(HipCameraFilter(self.__engine, ids[name], cfg, drop=drop))
+        import ctypes
+        for fb in frame_buffers.values():
+            for frame in fb.frames:
+                obj = frame.image.get_obj() if hasattr(frame.image, "get_obj") else frame.image
+                addr, size = ctypes.addressof(obj), ctypes.sizeof(obj)
+                try:
+                    self.__engine.host_register_address(addr, size)
+                    self.__pinned.append(addr)
+                except (RuntimeError, ValueError) as e:      # still correct, just not DMA speed
+                    if logger is not None:
+                        logger.warning("frame memory at 0x%x could not be page-locked: %s" % (addr, e))
+        return ids
+
+    def submit_host(self, lane: int, images: Sequence[np.ndarray], cameras: Optional[Sequence[int]] = None) -> None:
+        """Asynchronous `detect_batch`: the frames (views of shared memory, unchanged until `collect`) are enqueued on `lane`."""
+        self.__engine.submit_host(lane, images, cameras)
+
+    def collect(self, lane: int, detections: Sequence) -> None:
+        """Waits for `lane` and writes its rows into the given `Detection[100]` arrays (the frame headers)."""
+        self.__engine.collect(lane, detections)
 
     def detect(self, image_shape, image_np, detections: List[Detection]):
         return self.__engine.detect_batch([image_np.reshape(image_shape)], [detections])

@@ -137,6 +137,13 @@ class HipEngine:
     def host_unregister(self, arr: np.ndarray) -> None:
         _lib.check(self._lib.wz_host_unregister(self._h, C.c_void_p(arr.ctypes.data)))
 
+    def host_register_address(self, address: int, nbytes: int) -> None:
+        """The same for raw memory, e.g. a `multiprocessing.sharedctypes` array shared with other processes."""
+        _lib.check(self._lib.wz_host_register(self._h, C.c_void_p(address), nbytes))
+
+    def host_unregister_address(self, address: int) -> None:
+        _lib.check(self._lib.wz_host_unregister(self._h, C.c_void_p(address)))
+
     def collect(self, slot: int, out_rows: Sequence, out_pass: Optional[Sequence[np.ndarray]] = None) -> None:
         n = len(out_rows)
         outs = (C.c_void_p * n)(*[self._addr(r) for r in out_rows])
