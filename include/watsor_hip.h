@@ -106,6 +106,9 @@ int wz_num_slots(wz_engine_t* e);   /* lanes actually created (WZ_SLOTS unless W
  *                NULL = every label sees every zone
  *   zone_fill    [n_zones][height][width] bytes: 1 on the lattice points of zone z's polygon
  *                (8-connected alpha==255 component with holes filled, ordered as mask.py:78-88)
+ * n_zones == 0 with zone_fill != NULL: a mask IS configured but holds no zone -- every row then fails the mask test,
+ * as the reference's MaskFilter with an empty polygon list does (mask.py:44-59); n_zones == 0 with zone_fill == NULL:
+ * no mask.  On failure the camera keeps the filter it had.
  */
 int wz_set_camera_filter(wz_engine_t* e, int cam, int width, int height, const double* conf_thr,
                          const double* area_thr, int n_zones, const uint8_t* zone_allow,

@@ -1,0 +1,78 @@
+"""Golden vectors of the REAL reference detector -- the route from "parity unpinned" to "pinned" (DESIGN.md section 3).
+
+The reference's CPU plugin is `sess.run` on `frozen_inference_graph.pb` of ssd_mobilenet_v2_coco_2018_03_29
+(`watsor/detection/tensorflow_cpu.py:50-62,94-121`, README.md:446-451).  Neither TensorFlow nor that file exists in the
+build container, so the oracle's resize rule, extras / heads, anchors and NMS are restated from the published graph
+semantics only.  Run this script anywhere both exist:
+
+    python tests/golden/make_tf_golden.py --pb /path/to/frozen_inference_graph.pb
+
+It feeds the seeded synthetic frames of the test-suite through the graph exactly like the plugin does
+(`image_tensor:0` <- the full-resolution uint8 frame, `tensorflow_cpu.py:113-115`) and writes
+`tests/golden/tf_ssd_mobilenet_v2.npz`: the four fetched outputs of the plugin plus, where the graph has them, the
+intermediate tensors the oracle restates (normalised resized image, raw box encodings, class logits, anchors).
+`tests/test_tf_golden.py` consumes the file when it is present (with WATSOR_TF_PB pointing at the same .pb, which supplies
+the weights): oracle vs TensorFlow stage by stage on the CPU, engine vs TensorFlow within the north star's 1e-3 on the GPU.
+"""
+import argparse
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+FRAMES = [(640, 480, 1234), (640, 480, 1235), (640, 480, 1236), (1280, 720, 2000), (1920, 1080, 3000), (300, 300, 4000),
+          (301, 299, 4001)]
+OUTPUTS = ["detection_boxes", "detection_scores", "detection_classes", "num_detections"]       # tensorflow_cpu.py:98-110
+# intermediate tensors of the TF-OD-API export (name candidates by exporter version; recorded only when present)
+OPTIONAL = {
+    "preprocessed": ["Preprocessor/sub"],
+    "box_encodings": ["concat", "Squeeze"],
+    "class_logits": ["concat_1"],
+    "anchors": ["MultipleGridAnchorGenerator/Concatenate/concat", "Concatenate/concat"],
+    "scores_all": ["Postprocessor/convert_scores", "Postprocessor/scale_logits"],
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pb", required=True)
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "tf_ssd_mobilenet_v2.npz"))
+    args = ap.parse_args()
+    import tensorflow as tf
+    tf1 = tf.compat.v1 if hasattr(tf, "compat") and hasattr(tf.compat, "v1") else tf
+    from watsor_amd.synth import synthetic_frame
+
+    graph = tf.Graph()
+    with graph.as_default():                                       # tensorflow_cpu.py:50-62
+        gd = tf1.GraphDef()
+        with open(args.pb, "rb") as f:
+            blob = f.read()
+        gd.ParseFromString(blob)
+        tf.import_graph_def(gd, name="")
+    names = {op.name for op in graph.get_operations()}
+    fetch = {k: graph.get_tensor_by_name(k + ":0") for k in OUTPUTS}
+    found = {}
+    for key, cands in OPTIONAL.items():
+        for c in cands:
+            if c in names:
+                fetch[key] = graph.get_tensor_by_name(c + ":0")
+                found[key] = c
+                break
+    out = {"frames": np.array(FRAMES, np.int32), "tf_version": np.array(tf.__version__),
+           "pb_sha256": np.array(hashlib.sha256(blob).hexdigest()), "optional_tensor_names": np.array(repr(found))}
+    with tf1.Session(graph=graph) as sess:
+        for i, (w, h, seed) in enumerate(FRAMES):
+            frame = synthetic_frame(w, h, seed)
+            res = sess.run(fetch, feed_dict={graph.get_tensor_by_name("image_tensor:0"): frame[None]})
+            for k, v in res.items():
+                out["f%d_%s" % (i, k)] = np.asarray(v)
+    np.savez_compressed(args.out, **out)
+    print("wrote %s (%d arrays; intermediates found: %s)" % (args.out, len(out), found))
+
+
+if __name__ == "__main__":
+    main()

@@ -230,3 +230,21 @@ def test_drop_mode_feeds_the_native_sieve(eng):
         eng.set_camera_drop(9, True)                                      # no filter on that camera
     raw_cam.close()
     drop_cam.close()
+
+
+def test_mask_without_zones_rejects_everything(eng):
+    """A configured mask whose alpha plane has no fully opaque pixel holds no polygon: the reference's MaskFilter then
+    returns False for every detection (mask.py:44-59) -- it must not be taken for "no mask"."""
+    alpha = np.full((100, 100), 200, np.uint8)
+    cfg = {"width": 100, "height": 100, "detect": [{"person": {"area": 0, "confidence": 0, "zones": []}}]}
+    assert len(oz.zone_polygons(alpha)) == 0
+    flt = HipCameraFilter(eng, 2, cfg, alpha=alpha)
+    assert flt.num_zones == 0
+    rows = rows_from([(1, 0.70, (20, 20, 40, 80)), (1, 0.99, (0, 0, 99, 99))])
+    want, _ = oracle_verdict([of.ConfidenceFilter(cfg), of.AreaFilter(cfg), of.MaskFilter(cfg, alpha=alpha)], rows.copy())
+    got = flt.filter_rows(rows)
+    assert not want.any() and not got.any() and not rows["zones"].any()
+    flt.close()
+    nomask = HipCameraFilter(eng, 2, cfg)                      # no mask at all: the same rows pass
+    assert nomask.filter_rows(rows_from([(1, 0.70, (20, 20, 40, 80))]))[0] == 1
+    nomask.close()

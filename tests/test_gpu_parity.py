@@ -504,3 +504,51 @@ def test_postprocess_with_binding_per_class_cap(synth_weights, tmp_path, head_ou
         assert np.bincount(C[0][:N[0]]).max() == 3
     finally:
         e.close()
+
+
+def trained_like_head_outputs(seed, n_objects=14, saturated=3):
+    """Head outputs shaped like a TRAINED SSD's rather than the random-init network's: every class logit well above the
+    graph's 1e-8 score threshold (all 1917 x 90 candidates enter per-class NMS), a few hundred scores above 0.3 in tight
+    clusters of overlapping same-class anchors around each "object", several saturated logits per object (sigmoid == 1.0
+    exactly in fp32: ties that only the anchor index breaks) and duplicated logit values elsewhere."""
+    rng = np.random.default_rng(seed)
+    anchors = pu.anchors_cs()                                      # (ycenter, xcenter, h, w)
+    A, C = anchors.shape[0], 91
+    lg = rng.normal(-7.0, 1.5, (A, C)).astype(np.float32)
+    lg[:, 0] = rng.normal(4.0, 1.0, A)                             # background column: dropped before NMS
+    be = rng.normal(0.0, 0.6, (A, 4)).astype(np.float32)
+    for _ in range(n_objects):
+        cls = int(rng.integers(1, C))
+        cy, cx = rng.random(2)
+        d = np.hypot(anchors[:, 0] - cy, anchors[:, 1] - cx)
+        near = d < 0.12
+        lg[near, cls] = (5.0 - 45.0 * d[near] + rng.normal(0, 0.3, int(near.sum()))).astype(np.float32)
+        lg[np.argsort(d)[:saturated], cls] = 20.0                  # sigmoid(20) == 1.0f: exact ties
+        dup = np.nonzero(near)[0][:6]
+        lg[dup, cls] = np.float32(1.25)                            # equal unsaturated scores, too
+    return be[None], lg[None]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_postprocess_on_trained_like_score_distributions(eng, seed):
+    """SURVEY App. B.5 on realistic inputs: candidate selection (hint-driven bands of wz_k_nms), ties, heavy same-class
+    suppression -- same rows as the literal class-by-class algorithm."""
+    from oracle.postprocess import sigmoid
+    be, lg = trained_like_head_outputs(seed)
+    s = sigmoid(lg)[..., 1:]
+    assert (s > 1e-8).all() and 100 < (s > 0.3).sum() < 2000 and (s == 1.0).sum() >= 20
+    n = _check_post(eng, be, lg)
+    assert n[0] == 100
+
+
+def test_postprocess_band_hint_survives_scene_cuts(eng, head_outputs):
+    """The first score band of a frame slot starts where it started last time (the hint): a slot that sees a busy scene,
+    then an almost empty one, then the busy one again must give the oracle's rows every time."""
+    _, rbe, rlg, _ = head_outputs
+    busy = trained_like_head_outputs(7)
+    quiet_lg = np.full_like(rlg[:1], -12.0)
+    quiet_lg[0, 10:14, 5] = (-3.0, -3.5, -4.0, -9.0)               # four low scores, everything else ~6e-6
+    quiet = (rbe[:1], quiet_lg)
+    dense = (rbe[:1] * 0.2, rlg[:1] + 4.0)                         # thousands of candidates tie near the top
+    for be, lg in (busy, quiet, busy, dense, quiet, (rbe[:1], rlg[:1]), busy):
+        _check_post(eng, be, lg)

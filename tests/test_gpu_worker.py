@@ -59,12 +59,13 @@ def test_plugin_in_a_spawned_worker_writes_the_same_rows(model_dir, asynchronous
     # the parent reads the rows out of shared memory and compares with an in-process engine
     e = make_engine(model_dir, max_batch=8, max_width=1280, max_height=720)
     try:
-        for (cam, rnd), img in images.items():
-            got = rows_of(cams[cam].frames[rnd])
-            ref = np.zeros(100, ROW_DTYPE)
-            e.detect_batch([img], [ref])
-            assert got.tobytes() == ref.tobytes(), (cam, rnd)
-            assert got["label"][0] >= 1 and got["confidence"][0] > 0
+        for rnd, batch in enumerate(batches):                      # the same batches (a batch size picks its split-K counts,
+            refs = [np.zeros(100, ROW_DTYPE) for _ in batch]       # i.e. its fp32 summation order), in process
+            e.detect_batch([images[(p.sender, rnd)] for p in batch], refs)
+            for p, ref in zip(batch, refs):
+                got = rows_of(cams[p.sender].frames[rnd])
+                assert got.tobytes() == ref.tobytes(), (p.sender, rnd)
+                assert got["label"][0] >= 1 and got["confidence"][0] > 0
     finally:
         e.close()
     for fb in cams.values():                                        # exactly one latch step per dequeued payload

@@ -883,7 +883,7 @@ __device__ void wz_apply_filter(const WzCamFilter& cf, wz_detection_t& d, uint8_
         if (ar < 0) ar = -ar;
         ok = (at == at) && (double)ar >= at;
     }
-    if (ok && cf.n_zones > 0) {                            // mask.py:44-59
+    if (ok && (cf.n_zones > 0 || (cf.enabled & 4))) {      // mask.py:44-59 (bit 2: a mask WITHOUT zones -- nothing can hit)
         // lattice rule: hit <=> a filled-zone pixel lies inside the closed box
         const int x0 = max(min(d.x_min, d.x_max), 0), x1 = min(max(d.x_min, d.x_max), cf.width - 1);
         const int y0 = max(min(d.y_min, d.y_max), 0), y1 = min(max(d.y_min, d.y_max), cf.height - 1);

@@ -910,13 +910,11 @@ extern "C" int wz_set_camera_filter(wz_engine_t* e, int cam, int width, int heig
     if (n_zones > 0 && !zone_fill) return wz_fail(WZ_EINVAL, "zone_fill is null");
     HIPCHK(hipSetDevice(e->device));
     { int _rc = sync_all(e); if (_rc != WZ_OK) return _rc; }
-    WzCamFilter& c = e->h_cams[cam];
-    if (e->cam_sat[cam]) {
-        (void)hipFree(e->cam_sat[cam]);
-        e->cam_sat[cam] = nullptr;
-    }
+    // the new state is built aside and committed only when all of it exists: a failure (e.g. no memory for the
+    // summed-area tables of a 1080p multi-zone mask) leaves the camera's previous filter intact
+    WzCamFilter c;
     memset(&c, 0, sizeof(c));
-    c.enabled = 1;
+    c.enabled = 1 | ((n_zones == 0 && zone_fill) ? 4 : 0);   // bit 2: a mask is configured but has no zone -> every row fails it
     c.width = width;
     c.height = height;
     c.n_zones = n_zones;
@@ -924,20 +922,32 @@ extern "C" int wz_set_camera_filter(wz_engine_t* e, int cam, int width, int heig
     memcpy(c.area_thr, area_thr, sizeof(double) * WZ_NUM_LABELS);
     for (int l = 0; l < WZ_NUM_LABELS; ++l)
         for (int z = 0; z < n_zones; ++z) c.allow[l][z] = zone_allow ? (zone_allow[(size_t)l * n_zones + z] ? 1 : 0) : 1;
+    int32_t* sat = nullptr;
     if (n_zones > 0) {
         const size_t plane = (size_t)(width + 1) * (height + 1);
-        int32_t* sat = nullptr;
         uint8_t* d_fill = nullptr;
-        HIPCHK(hipMalloc((void**)&sat, plane * n_zones * 4));
-        HIPCHK(hipMalloc((void**)&d_fill, (size_t)width * height * n_zones));
-        HIPCHK(hipMemcpy(d_fill, zone_fill, (size_t)width * height * n_zones, hipMemcpyHostToDevice));
-        wz_launch_sat(d_fill, sat, width, height, n_zones, e->stream);
-        HIPCHK(hipStreamSynchronize(e->stream));
-        (void)hipFree(d_fill);
-        e->cam_sat[cam] = sat;
+        hipError_t err = hipMalloc((void**)&sat, plane * n_zones * 4);
+        if (err == hipSuccess) err = hipMalloc((void**)&d_fill, (size_t)width * height * n_zones);
+        if (err == hipSuccess) err = hipMemcpy(d_fill, zone_fill, (size_t)width * height * n_zones, hipMemcpyHostToDevice);
+        if (err == hipSuccess) {
+            wz_launch_sat(d_fill, sat, width, height, n_zones, e->stream);
+            err = hipStreamSynchronize(e->stream);
+        }
+        if (d_fill) (void)hipFree(d_fill);
+        if (err != hipSuccess) {
+            if (sat) (void)hipFree(sat);
+            return wz_fail(WZ_EHIP, "wz_set_camera_filter: %s (camera %d keeps its previous filter)", hipGetErrorString(err), cam);
+        }
         c.sat = sat;
     }
-    HIPCHK(hipMemcpy(e->d_cams + cam, &c, sizeof(WzCamFilter), hipMemcpyHostToDevice));
+    hipError_t err = hipMemcpy(e->d_cams + cam, &c, sizeof(WzCamFilter), hipMemcpyHostToDevice);
+    if (err != hipSuccess) {
+        if (sat) (void)hipFree(sat);
+        return wz_fail(WZ_EHIP, "wz_set_camera_filter: %s (camera %d keeps its previous filter)", hipGetErrorString(err), cam);
+    }
+    if (e->cam_sat[cam]) (void)hipFree(e->cam_sat[cam]);   // nothing in flight reads it: every lane was synchronised above
+    e->cam_sat[cam] = sat;
+    e->h_cams[cam] = c;
     return WZ_OK;
 }
 
@@ -946,7 +956,7 @@ extern "C" int wz_set_camera_drop(wz_engine_t* e, int cam, int drop) {
     if (!(e->h_cams[cam].enabled & 1)) return wz_fail(WZ_EINVAL, "camera %d has no filter (wz_set_camera_filter first)", cam);
     HIPCHK(hipSetDevice(e->device));
     { int _rc = sync_all(e); if (_rc != WZ_OK) return _rc; }
-    e->h_cams[cam].enabled = drop ? 3 : 1;
+    e->h_cams[cam].enabled = (e->h_cams[cam].enabled & ~2) | (drop ? 2 : 0);
     HIPCHK(hipMemcpy(e->d_cams + cam, &e->h_cams[cam], sizeof(WzCamFilter), hipMemcpyHostToDevice));
     return WZ_OK;
 }

@@ -183,6 +183,9 @@ class HipEngine:
         assert conf.shape == (_lib.WZ_NUM_LABELS,) and area.shape == (_lib.WZ_NUM_LABELS,)
         nz = 0 if zone_fill is None else int(zone_fill.shape[0])
         fill_p = allow_p = None
+        if zone_fill is not None and nz == 0:      # a mask without zones: nothing can hit it (mask.py:44-59)
+            self._no_zones = np.zeros(1, np.uint8)
+            fill_p = C.c_void_p(self._no_zones.ctypes.data)
         if nz:
             zone_fill = np.ascontiguousarray(zone_fill, np.uint8)
             assert zone_fill.shape == (nz, height, width)
