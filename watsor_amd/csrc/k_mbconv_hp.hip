@@ -41,21 +41,35 @@ __device__ __forceinline__ void wz_hp_split(const float v[8], half8_t& hi, half8
     }
 }
 
-__device__ __forceinline__ void wz_hp_unpack(const wz_u32x4_t t, float x[8]) {
+typedef __attribute__((ext_vector_type(2))) float wz_f32x2_t;
+
+// eight unorm16 -> four pairs of floats (v_cvt_f32_u32 with SDWA word select)
+__device__ __forceinline__ void wz_hp_unpack(const wz_u32x4_t t, wz_f32x2_t x[4]) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        x[2 * r] = (float)(t[r] & 0xffffu);
-        x[2 * r + 1] = (float)(t[r] >> 16);
-    }
+    for (int r = 0; r < 4; ++r) x[r] = (wz_f32x2_t){(float)(t[r] & 0xffffu), (float)(t[r] >> 16)};
+}
+
+// d[0..3] += x[0..3] * (w0, w1) as four v_pk_fma_f32: the depthwise stage is bound by VALU issue, and a packed FMA
+// is one issue for two of them
+__device__ __forceinline__ void wz_hp_fma8(wz_f32x2_t d[4], const wz_f32x2_t x[4], const float4_t w0, const float4_t w1) {
+    d[0] = __builtin_elementwise_fma(x[0], __builtin_shufflevector(w0, w0, 0, 1), d[0]);
+    d[1] = __builtin_elementwise_fma(x[1], __builtin_shufflevector(w0, w0, 2, 3), d[1]);
+    d[2] = __builtin_elementwise_fma(x[2], __builtin_shufflevector(w1, w1, 0, 1), d[2]);
+    d[3] = __builtin_elementwise_fma(x[3], __builtin_shufflevector(w1, w1, 2, 3), d[3]);
 }
 
 // MPW: halo m-tiles (16 pixels) per wave, MQW: output m-tiles per wave, KCI: 32-channel K chunks of the expand conv,
 // NTO: 16-column tiles of the project output.  STEM: the "expand" stage is the stem convolution gathered from the
 // 300x300 input pair tensor (8 halves per pixel: r g b 0 hi | r g b 0 lo), as in k_mbconv_wave.hip.
 // NW: wavefronts per workgroup (CS: they share one tile and deal its 32-channel chunks out among themselves).
-template <int NW, bool CS, bool STEM, int MPW, int MQW, int KCI, int NTO>
-__global__ __launch_bounds__(NW * 64, 2) void wz_k_mbconv_hp(const WzMbArgs a) {
+// OCC: wavefronts per SIMD the kernel is compiled for (2: 256 registers, everything prefetched into them; 3 / 4: 168 / 128
+// registers -- depthwise weights read from LDS where they are used, taps requested a row at a time -- for the blocks
+// whose waves spend their time waiting rather than issuing).
+template <int NW, bool CS, bool STEM, int MPW, int MQW, int KCI, int NTO, int OCC = 2>
+__global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wz_hp_smem[];
+    constexpr bool LDSW = CS || OCC > 2;                 // depthwise weights staged in LDS (else: registers, from L2)
+    constexpr bool PRE = OCC <= 2;                       // all taps of an output requested before the first is used
     constexpr int ES = 40;                               // unorm16 per row of the chunk buffer: 32 channels + 8 of padding
     constexpr int EBYTES = MPW * 16 * ES * 2;
     constexpr int RED_BYTES = CS ? NW * MQW * NTO * 1024 : 0;
@@ -70,7 +84,7 @@ __global__ __launch_bounds__(NW * 64, 2) void wz_k_mbconv_hp(const WzMbArgs a) {
     // are used (broadcast reads); !CS: they come from L2 into registers at the top of a pass (LDS is the busy unit there)
     float* const wd_l = be_l + a.cmid_pad;                               // CS only: [9][cmid_pad]
 
-    if constexpr (CS)
+    if constexpr (LDSW)
         for (int i = threadIdx.x; i < 9 * (a.cmid_pad >> 2); i += NW * 64)
             *reinterpret_cast<float4_t*>(wd_l + i * 4) = *reinterpret_cast<const float4_t*>(wd32 + (size_t)i * 4);
     for (int i = threadIdx.x; i < (a.cmid_pad >> 2); i += NW * 64) {
@@ -161,6 +175,12 @@ __global__ __launch_bounds__(NW * 64, 2) void wz_k_mbconv_hp(const WzMbArgs a) {
         }
     }
 
+    // a tile whose halo lies inside the frame needs no per-pixel masking of the expanded values (wave-uniform; rows of
+    // the last m-tile beyond the halo are never read by the depthwise stage, whatever they hold)
+    bool interior = true;
+#pragma unroll
+    for (int i = 0; i < MPW; ++i) interior = interior && __builtin_amdgcn_ballot_w64(!inimg[i] && i * 16 + r16 < P) == 0;
+
     float4_t acc[MQW][NTO];
 #pragma unroll
     for (int j = 0; j < MQW; ++j)
@@ -199,8 +219,8 @@ __global__ __launch_bounds__(NW * 64, 2) void wz_k_mbconv_hp(const WzMbArgs a) {
             wph[nt] = *reinterpret_cast<const half8_t*>(a.wp + off);
             wpl[nt] = *reinterpret_cast<const half8_t*>(a.wp_lo + off);
         }
-        float4_t wt0[9], wt1[9];   // (CS: unused, the weights are read from LDS where they are needed)
-        if constexpr (!CS) {
+        float4_t wt0[9], wt1[9];   // (LDSW: unused, the weights are read from LDS where they are needed)
+        if constexpr (!LDSW) {
 #pragma unroll
             for (int tp = 0; tp < 9; ++tp) {
                 wt0[tp] = *reinterpret_cast<const float4_t*>(wd32 + (size_t)tp * a.cmid_pad + coff);
@@ -218,7 +238,7 @@ __global__ __launch_bounds__(NW * 64, 2) void wz_k_mbconv_hp(const WzMbArgs a) {
             float4_t d[MPW];
 #pragma unroll
             for (int i = 0; i < MPW; ++i) {
-                d[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+                d[i] = bv;                        // the bias is the accumulators' initial value (the MFMA's C operand)
 #pragma unroll
                 for (int c = 0; c < KCI; ++c) d[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wal[nt][c], xh[i][c], d[i], 0, 0, 0);
             }
@@ -233,15 +253,25 @@ __global__ __launch_bounds__(NW * 64, 2) void wz_k_mbconv_hp(const WzMbArgs a) {
 #pragma unroll
                 for (int c = 0; c < KCI; ++c) d[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wah[nt][c], xh[i][c], d[i], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+            if (interior && have) {
 #pragma unroll
-            for (int i = 0; i < MPW; ++i) {
-                const bool keep = inimg[i] && have;
-                const wz_us2_t p0 = __builtin_amdgcn_cvt_pknorm_u16(d[i][0] + bv[0], d[i][1] + bv[1]);
-                const wz_us2_t p1 = __builtin_amdgcn_cvt_pknorm_u16(d[i][2] + bv[2], d[i][3] + bv[3]);
-                wz_u32x2_t o;
-                o[0] = keep ? __builtin_bit_cast(unsigned int, p0) : 0u;
-                o[1] = keep ? __builtin_bit_cast(unsigned int, p1) : 0u;
-                *reinterpret_cast<wz_u32x2_t*>(E + (i * 16 + r16) * ES + nt * 16 + g * 4) = o;
+                for (int i = 0; i < MPW; ++i) {
+                    wz_u32x2_t o;
+                    o[0] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pknorm_u16(d[i][0], d[i][1]));
+                    o[1] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pknorm_u16(d[i][2], d[i][3]));
+                    *reinterpret_cast<wz_u32x2_t*>(E + (i * 16 + r16) * ES + nt * 16 + g * 4) = o;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < MPW; ++i) {
+                    const bool keep = inimg[i] && have;
+                    const wz_us2_t p0 = __builtin_amdgcn_cvt_pknorm_u16(d[i][0], d[i][1]);
+                    const wz_us2_t p1 = __builtin_amdgcn_cvt_pknorm_u16(d[i][2], d[i][3]);
+                    wz_u32x2_t o;
+                    o[0] = keep ? __builtin_bit_cast(unsigned int, p0) : 0u;
+                    o[1] = keep ? __builtin_bit_cast(unsigned int, p1) : 0u;
+                    *reinterpret_cast<wz_u32x2_t*>(E + (i * 16 + r16) * ES + nt * 16 + g * 4) = o;
+                }
             }
         }
         if (ps + STEP < nk32) load_wa(ps + STEP);   // next pass's expand fragments, in flight under the depthwise stage
@@ -253,58 +283,49 @@ __global__ __launch_bounds__(NW * 64, 2) void wz_k_mbconv_hp(const WzMbArgs a) {
         // ---- depthwise (lane = output pixel x 8 channels), fp32
         const float4_t b0 = *reinterpret_cast<const float4_t*>(bd_l + coff);
         const float4_t b1 = *reinterpret_cast<const float4_t*>(bd_l + coff + 4);
-        float dd[MQW][8];
+        wz_f32x2_t dd[MQW][4];
 #pragma unroll
-        for (int j = 0; j < MQW; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { dd[j][r] = b0[r]; dd[j][4 + r] = b1[r]; }
+        for (int j = 0; j < MQW; ++j) {
+            dd[j][0] = __builtin_shufflevector(b0, b0, 0, 1);
+            dd[j][1] = __builtin_shufflevector(b0, b0, 2, 3);
+            dd[j][2] = __builtin_shufflevector(b1, b1, 0, 1);
+            dd[j][3] = __builtin_shufflevector(b1, b1, 2, 3);
+        }
         auto W0 = [&](int tp) -> float4_t {
-            if constexpr (CS) return *reinterpret_cast<const float4_t*>(wd_l + tp * a.cmid_pad + coff);
+            if constexpr (LDSW) return *reinterpret_cast<const float4_t*>(wd_l + tp * a.cmid_pad + coff);
             else return wt0[tp];
         };
         auto W1 = [&](int tp) -> float4_t {
-            if constexpr (CS) return *reinterpret_cast<const float4_t*>(wd_l + tp * a.cmid_pad + coff + 4);
+            if constexpr (LDSW) return *reinterpret_cast<const float4_t*>(wd_l + tp * a.cmid_pad + coff + 4);
             else return wt1[tp];
         };
         if constexpr (MQW == 2) {
             // rows hp0 .. hp0 + 3 of the halo serve both outputs: row rr is tap row rr of output 0 and rr - 1 of output 1.
             // All 12 taps are requested before the first one is used: one LDS latency instead of twelve.
             const unsigned short* ep = E + hp0[0] * ES + g * 8;
-            wz_u32x4_t tq[12];
+            constexpr int RR = PRE ? 4 : 1;                 // halo rows requested per group
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr)
+            for (int r0 = 0; r0 < 4; r0 += RR) {
+                wz_u32x4_t tq[RR * 3];
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) tq[rr * 3 + kx] = *reinterpret_cast<const wz_u32x4_t*>(ep + (rr * hw_ + kx) * ES);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int t = 0; t < RR * 3; ++t)
+                    tq[t] = *reinterpret_cast<const wz_u32x4_t*>(ep + ((r0 + t / 3) * hw_ + t % 3) * ES);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    float x[8];
-                    wz_hp_unpack(tq[rr * 3 + kx], x);
-                    if (rr < 3) {
-                        const float4_t w0 = W0(rr * 3 + kx), w1 = W1(rr * 3 + kx);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            dd[0][r] = fmaf(x[r], w0[r], dd[0][r]);
-                            dd[0][4 + r] = fmaf(x[4 + r], w1[r], dd[0][4 + r]);
-                        }
-                    }
-                    if (rr > 0) {
-                        const float4_t w0 = W0((rr - 1) * 3 + kx), w1 = W1((rr - 1) * 3 + kx);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            dd[1][r] = fmaf(x[r], w0[r], dd[1][r]);
-                            dd[1][4 + r] = fmaf(x[4 + r], w1[r], dd[1][4 + r]);
-                        }
-                    }
+                for (int t = 0; t < RR * 3; ++t) {
+                    const int rr = r0 + t / 3, kx = t % 3;
+                    wz_f32x2_t x[4];
+                    wz_hp_unpack(tq[t], x);
+                    if (rr < 3) wz_hp_fma8(dd[0], x, W0(rr * 3 + kx), W1(rr * 3 + kx));
+                    if (rr > 0) wz_hp_fma8(dd[1], x, W0((rr - 1) * 3 + kx), W1((rr - 1) * 3 + kx));
                 }
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < MQW; ++j) {
                 const unsigned short* ep = E + hp0[j] * ES + g * 8;
                 // the taps are requested ahead of their use, all nine at once where the registers allow it
-                constexpr int ROWS = KCI >= 3 ? 1 : 3;          // tap rows per request group
+                constexpr int ROWS = (KCI >= 3 || !PRE) ? 1 : 3;   // tap rows per request group
 #pragma unroll
                 for (int k0 = 0; k0 < 3; k0 += ROWS) {
                     wz_u32x4_t tq[ROWS * 3];
@@ -315,14 +336,9 @@ __global__ __launch_bounds__(NW * 64, 2) void wz_k_mbconv_hp(const WzMbArgs a) {
 #pragma unroll
                     for (int t = 0; t < ROWS * 3; ++t) {
                         const int tp = k0 * 3 + t;
-                        float x[8];
+                        wz_f32x2_t x[4];
                         wz_hp_unpack(tq[t], x);
-                        const float4_t w0 = W0(tp), w1 = W1(tp);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            dd[j][r] = fmaf(x[r], w0[r], dd[j][r]);
-                            dd[j][4 + r] = fmaf(x[4 + r], w1[r], dd[j][4 + r]);
-                        }
+                        wz_hp_fma8(dd[j], x, W0(tp), W1(tp));
                     }
                 }
             }
@@ -332,7 +348,7 @@ __global__ __launch_bounds__(NW * 64, 2) void wz_k_mbconv_hp(const WzMbArgs a) {
         for (int j = 0; j < MQW; ++j) {
             float v[8];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] = fminf(fmaxf(dd[j][r], 0.0f), 6.0f);
+            for (int r = 0; r < 8; ++r) v[r] = fminf(fmaxf(dd[j][r >> 1][r & 1], 0.0f), 6.0f);
             half8_t bh, bl;
             wz_hp_split(v, bh, bl);
 #pragma unroll
@@ -419,7 +435,7 @@ static int wz_hp_env(const char* name, int dflt) {
     return (e && atoi(e) > 0) ? atoi(e) : dflt;
 }
 
-template <int NW, bool CS, bool STEM, int MPW, int MQW, int KCI, int NTO>
+template <int NW, bool CS, bool STEM, int MPW, int MQW, int KCI, int NTO, int OCC = 2>
 static int wz_hp_launch(WzMbArgs a, int n, hipStream_t s, bool prepare) {
     a.nb = n;
     if (MQW == 2) { a.th = 4; a.tw = 8; } else { a.th = 4; a.tw = 4; }
@@ -428,8 +444,8 @@ static int wz_hp_launch(WzMbArgs a, int n, hipStream_t s, bool prepare) {
     constexpr int EB = MPW * 16 * 40 * 2;
     constexpr int RED = CS ? NW * MQW * NTO * 1024 : 0;
     const size_t region = (size_t)(NW * EB > RED ? NW * EB : RED);
-    const size_t lds = region + (size_t)a.cmid_pad * (CS ? 8 + 36 : 8);
-    auto k = wz_k_mbconv_hp<NW, CS, STEM, MPW, MQW, KCI, NTO>;
+    const size_t lds = region + (size_t)a.cmid_pad * ((CS || OCC > 2) ? 8 + 36 : 8);
+    auto k = wz_k_mbconv_hp<NW, CS, STEM, MPW, MQW, KCI, NTO, OCC>;
     if (prepare) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return lds <= 160 * 1024 ? 0 : -1;
@@ -455,7 +471,23 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
     a.nsplit = 1;
     if (a.nmid_pad != a.cmid_pad || (a.cmid_pad & 31) || a.kc != (a.cmid_pad >> 5) || !a.we_lo || !a.wp_lo) return -1;
     const int nk32 = a.cmid_pad >> 5;
-    if (a.stem) return (a.kc0 == 1 && nto == 2 && a.stride == 1) ? wz_hp_launch<4, false, true, 4, 2, 1, 2>(a, n, s, prepare) : -1;
+    // waves per SIMD of the one-wave-per-tile kernels.  Measured (profiles/r02g_*, batch 8): 3 instead of 2 takes the stem
+    // block from 22.4 to 18.1 us and the stride-2 blocks from 16.5 / 10.5 to 11.9 / 9.9 us (their waves wait for the halo
+    // gather and for LDS, a third wave fills the gaps), leaves the 75x75 stride-1 block where it is and costs the 38x38
+    // ones 0.7 us (too few waves to fill even two per SIMD); 4 spills and loses everywhere.  WZ_HP_OCC=2|3|4 forces one.
+    static const int occ_env = wz_hp_env("WZ_HP_OCC", 0);
+    const int occ = occ_env ? occ_env : (a.stem || a.stride == 2 || a.wout >= 75) ? 3 : 2;
+    if (a.stem) {
+        if (!(a.kc0 == 1 && nto == 2 && a.stride == 1)) return -1;
+        if (prepare) {
+            (void)wz_hp_launch<4, false, true, 4, 2, 1, 2, 3>(a, n, s, true);
+            (void)wz_hp_launch<4, false, true, 4, 2, 1, 2, 4>(a, n, s, true);
+            return wz_hp_launch<4, false, true, 4, 2, 1, 2>(a, n, s, true);
+        }
+        if (occ == 3) return wz_hp_launch<4, false, true, 4, 2, 1, 2, 3>(a, n, s, false);
+        if (occ == 4) return wz_hp_launch<4, false, true, 4, 2, 1, 2, 4>(a, n, s, false);
+        return wz_hp_launch<4, false, true, 4, 2, 1, 2>(a, n, s, false);
+    }
     if (a.cin0 == 0) return -1;
     if (a.wout > 19 && a.kc0 == 1 && nto == 2) {
         const bool cs = (prepare || a.wout <= cs_max_w) && nk32 >= 4 && nk32 <= 6;
@@ -463,18 +495,26 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
             if (prepare) {
                 (void)wz_hp_launch<5, true, false, 4, 2, 1, 2>(a, n, s, true);
                 (void)wz_hp_launch<6, true, false, 4, 2, 1, 2>(a, n, s, true);
+                (void)wz_hp_launch<4, false, false, 4, 2, 1, 2, 3>(a, n, s, true);
+                (void)wz_hp_launch<4, false, false, 4, 2, 1, 2, 4>(a, n, s, true);
                 return wz_hp_launch<4, false, false, 4, 2, 1, 2>(a, n, s, true);
             }
             if (cs && nk32 <= 5) return wz_hp_launch<5, true, false, 4, 2, 1, 2>(a, n, s, false);
             if (cs) return wz_hp_launch<6, true, false, 4, 2, 1, 2>(a, n, s, false);
+            if (occ == 3) return wz_hp_launch<4, false, false, 4, 2, 1, 2, 3>(a, n, s, false);
+            if (occ == 4) return wz_hp_launch<4, false, false, 4, 2, 1, 2, 4>(a, n, s, false);
             return wz_hp_launch<4, false, false, 4, 2, 1, 2>(a, n, s, false);
         }
         // stride 2: 4 x 4 tiles, halo 9 x 9 = 81 pixels
         if (prepare) {
             (void)wz_hp_launch<5, true, false, 6, 1, 1, 2>(a, n, s, true);
+            (void)wz_hp_launch<4, false, false, 6, 1, 1, 2, 3>(a, n, s, true);
+            (void)wz_hp_launch<4, false, false, 6, 1, 1, 2, 4>(a, n, s, true);
             return wz_hp_launch<4, false, false, 6, 1, 1, 2>(a, n, s, true);
         }
         if (cs && nk32 <= 5) return wz_hp_launch<5, true, false, 6, 1, 1, 2>(a, n, s, false);
+        if (occ == 3) return wz_hp_launch<4, false, false, 6, 1, 1, 2, 3>(a, n, s, false);
+        if (occ == 4) return wz_hp_launch<4, false, false, 6, 1, 1, 2, 4>(a, n, s, false);
         return wz_hp_launch<4, false, false, 6, 1, 1, 2>(a, n, s, false);
     }
     if (a.wout > 19) return -1;
