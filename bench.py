@@ -223,6 +223,86 @@ def pmc_traffic(kernel):
         return None
 
 
+def kernel_class_of(name):
+    """rocprofv3's kernel name -> the class names used in this file."""
+    k = name.replace("void ", "").split("(")[0]
+    base = k.split("<")[0]
+    if base.startswith("_Z"):
+        return "wz_k_preprocess" if "preprocess" in base else "wz_k_stem" if "stem" in base else base
+    if base.startswith("wz_k_mbconv_hp"):
+        return "wz_k_mbconv_hp"
+    if base.startswith("wz_k_mbconv"):
+        return "wz_k_mbconv"
+    if base in ("wz_k_conv_lds", "wz_k_conv"):
+        return "wz_k_conv<%s>" % k.split("<")[1].split(",")[0].split(">")[0]
+    return base
+
+
+def live_pmc_traffic(timeout_s=150):
+    """HBM-side bytes per launch and kernel class, measured NOW: two `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE --
+    they do not fit one pass, MI355X_MICROARCH.md) over a short single-lane run of this same file (`--pmc-child`).
+    FETCH_SIZE is doubled as the guide prescribes for 16 B/lane reads on gfx950 (it tallies a 128-B request as 64 B);
+    both counters are reported in KiB.  Returns {class: {...}} or None when rocprofv3 is not usable here."""
+    import glob
+    import shutil
+    import sqlite3
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.isfile("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    sums = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="wz_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp", WZ_LANES="1", WZ_BENCH_VERBOSE="0")
+            p = subprocess.run([exe, "--pmc", counter, "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+                                "--pmc-child"], cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                               timeout=timeout_s)
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if p.returncode != 0 or not dbs:
+                return None
+            db = sqlite3.connect(dbs[0])
+            for kname, value in db.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
+                a = sums.setdefault(kernel_class_of(kname), {}).setdefault(counter, [0.0, 0])
+                a[0] += value
+                a[1] += 1
+            db.close()
+        except (subprocess.TimeoutExpired, OSError, sqlite3.Error):
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    out = {}
+    for k, c in sums.items():
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            f = c["FETCH_SIZE"][0] / c["FETCH_SIZE"][1] * 1024.0
+            w = c["WRITE_SIZE"][0] / c["WRITE_SIZE"][1] * 1024.0
+            out[k] = dict(bytes=round(2 * f + w), fetch_bytes_raw=round(f), fetch_bytes_corrected=round(2 * f), write_bytes=round(w),
+                          launches_sampled=c["FETCH_SIZE"][1],
+                          source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two passes of this run (single lane), mean per launch")
+    return out or None
+
+
+def pmc_child():
+    """The workload the two counter passes of `live_pmc_traffic` profile: 12 batches on one lane, nothing else."""
+    from watsor_amd import engine as builder
+    from watsor_amd.runtime import HipEngine
+    from watsor_amd.synth import synthetic_frame, synthetic_weights
+    d = "/tmp/wz_pmc_child_%d" % os.getpid()
+    os.makedirs(d, exist_ok=True)
+    path = os.path.join(d, "mi355x.bin")
+    builder.save_engine(builder.build_engine(synthetic_weights(1234)), path)
+    eng = HipEngine(path, int(os.environ.get("LOCAL_RANK", "0")), BATCH, WIDTH, HEIGHT)
+    try:
+        fr = [eng.upload(synthetic_frame(WIDTH, HEIGHT, 1234 + i)) for i in range(BATCH)]
+        for _ in range(12):
+            eng.submit_device(0, fr, [WIDTH] * BATCH, [HEIGHT] * BATCH)
+            eng.wait(0)
+    finally:
+        eng.close()
+        os.remove(path)
+        os.rmdir(d)
+
+
 def rocprof_avg_us(kernel):
     """Average per-dispatch duration of `kernel` in the committed rocprofv3 kernel trace of this command
     (profiles/rocprof_kernel_avg.json)."""
@@ -545,11 +625,15 @@ def main():
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the -p 32 and --plain-fp16 engine legs (profiling runs: one engine's kernels only)")
     ap.add_argument("--no-parity", action="store_true", help="skip the live score check against the oracle")
     ap.add_argument("--table", default=None, help="write the per-kernel roofline table (JSON) here")
+    ap.add_argument("--no-live-pmc", action="store_true", help="take roofline.traffic from the committed profiles/pmc_traffic.json instead of two rocprofv3 --pmc passes of this run")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--dry-run", action="store_true",
                     help="harness self-test without a GPU: a stub engine that sleeps 2 ms per step (used by the "
                          "world_size-2 tests; its output is marked invalid)")
     args = ap.parse_args()
 
+    if args.pmc_child:
+        return pmc_child()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
@@ -703,6 +787,14 @@ def main():
         }
         if world == 1:
             eng.close()
+        if world == 1 and not args.no_live_pmc:
+            live = live_pmc_traffic()
+            note("live counter passes %s" % ("done" if live else "unavailable (committed json kept)"))
+            if live and roof["kernel"] in live:
+                roof["traffic"] = live[roof["kernel"]]
+                roof["frac_counter_traffic"] = round(roof["traffic"]["bytes"] / (roof["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
+                roof["traffic_over_fused_min"] = round(roof["traffic"]["bytes"] / max(roof["fused_min_bytes_per_launch"], 1), 3)
+                out["roofline"] = roof
         if world == 1 and not args.no_legs:
             legs = {}
             legs.update(host_legs(engine_path, model_dir, local_rank, host_frames))

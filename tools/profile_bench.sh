@@ -6,7 +6,7 @@ TAG=${1:-prof}; shift || true
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $PWD/bench.py --steps 40 --warmup 10 --rounds 3 --no-cpu-baseline --no-legs --no-fp32-leg --no-parity $*"
+BENCH="python $PWD/bench.py --steps 40 --warmup 10 --rounds 3 --no-cpu-baseline --no-legs --no-fp32-leg --no-parity --no-live-pmc $*"
 cd /tmp
 rm -rf /tmp/wzprof && mkdir -p /tmp/wzprof
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/wzprof/kt -o kt -- $BENCH > "$OUT/bench_under_rocprof.json" 2> "$OUT/kt.err"
