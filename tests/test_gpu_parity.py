@@ -443,19 +443,22 @@ def test_submit_host_equals_detect_batch(eng):
         eng.host_unregister(arena)
 
 
-@pytest.mark.parametrize("knob", ["WZ_DEFER_HEADS", "WZ_FUSE_DECODE"])
+@pytest.mark.parametrize("knob", ["WZ_HEAD_INLINE=1", "WZ_DEFER_HEADS=0", "WZ_FUSE_DECODE=0"])
 def test_grouped_head_launches_are_bit_identical_to_separate_ones(eng, model_dir, knob):
-    """The launch-count work on the SSD heads must not change a bit: `WZ_DEFER_HEADS=0` runs every head and its split-K
+    """The launch-count work on the SSD heads must not change a bit: `WZ_HEAD_INLINE=1` moves the split-K reduction of the
+    heads into the head convolutions (each tile's last K slice sums the slices itself, in the same order; measured slower,
+    hence off by default), `WZ_DEFER_HEADS=0` runs every head and its split-K
     reduction as launches of their own (same split counts, same summation order), `WZ_FUSE_DECODE=0` keeps the box
     decode in wz_k_decode instead of the grouped reduce (same arithmetic, compiled without contraction)."""
     frames = [synthetic_frame(640, 480, 300 + i) for i in range(4)]
     ref = [np.zeros(100, ROW_DTYPE) for _ in frames]
     eng.detect_batch(frames, ref)
-    os.environ[knob] = "0"
+    name, value = knob.split("=")
+    os.environ[name] = value
     try:
         other = make_engine(model_dir)
     finally:
-        os.environ.pop(knob)
+        os.environ.pop(name)
     try:
         got = [np.zeros(100, ROW_DTYPE) for _ in frames]
         other.detect_batch(frames, got)
@@ -552,3 +555,45 @@ def test_postprocess_band_hint_survives_scene_cuts(eng, head_outputs):
     dense = (rbe[:1] * 0.2, rlg[:1] + 4.0)                         # thousands of candidates tie near the top
     for be, lg in (busy, quiet, busy, dense, quiet, (rbe[:1], rlg[:1]), busy):
         _check_post(eng, be, lg)
+
+
+def test_inline_head_reduction_under_load(eng, model_dir):
+    """The in-launch reduction of the SSD heads is a cross-workgroup hand-off (write-through slabs, ticket, acquire): run it
+    the way it fails when it is wrong -- four lanes in flight, two alternating scenes so that every slab and every cached
+    line holds last step's values of the OTHER scene, hundreds of steps, every row of every frame compared with the rows of
+    an engine that reduces in a launch of its own."""
+    os.environ["WZ_HEAD_INLINE"] = "1"
+    try:
+        inl = make_engine(model_dir)
+    finally:
+        os.environ.pop("WZ_HEAD_INLINE")
+    ref_eng, eng = eng, inl                 # `eng` (the default: a reduce launch of its own) supplies the reference rows
+    scenes = [[synthetic_frame(640, 480, 5000 + 100 * s + i) for i in range(8)] for s in range(2)]
+    try:
+        refs = []
+        for sc in scenes:
+            r = [np.zeros(100, ROW_DTYPE) for _ in sc]
+            ref_eng.detect_batch(sc, r)
+            refs.append(np.stack(r))
+    except Exception:
+        inl.close()
+        raise
+    assert refs[0].tobytes() != refs[1].tobytes()
+    dev = [[eng.upload(f) for f in sc] for sc in scenes]
+    ws, hs = [640] * 8, [480] * 8
+    lanes = eng.num_slots
+    pending = {}
+    bad = 0
+    for step in range(240):
+        lane = step % lanes
+        if lane in pending:
+            eng.wait(lane)
+            bad += int(eng.slot_rows(lane, 8).tobytes() != refs[pending[lane]].tobytes())
+        which = (step // 3 + step) % 2 if step % 7 else 1 - (step % 2)       # an irregular alternation
+        eng.submit_device(lane, dev[which], ws, hs)
+        pending[lane] = which
+    for lane, which in pending.items():
+        eng.wait(lane)
+        bad += int(eng.slot_rows(lane, 8).tobytes() != refs[which].tobytes())
+    inl.close()
+    assert bad == 0

@@ -162,6 +162,85 @@ __device__ __forceinline__ void wz_epilogue4(const WzConvArgs& a, int m, int n4,
     }
 }
 
+// The reductions of several convolutions in one launch: a workgroup finds its entry from the prefix table, then does
+// exactly what wz_k_splitk_reduce does (same order over the splits: bit-identical results).
+// box decode + clip of one anchor from its finished encoding (ty, tx, th, tw): the arithmetic of wz_k_decode
+// (k_post.hip, which is compiled without contraction -- hence the pragma), operation for operation
+__device__ __forceinline__ void wz_decode_anchor(const float4_t e, const float4_t an, const WzPostConsts& k,
+                                                 float* __restrict__ box_out, uint8_t* __restrict__ valid_out) {
+#pragma clang fp contract(off)
+    const float ty = e[0] / k.scale_y, tx = e[1] / k.scale_x, th = e[2] / k.scale_h, tw = e[3] / k.scale_w;
+    const float w = expf(tw) * an[3];
+    const float h = expf(th) * an[2];
+    const float yc = ty * an[2] + an[0];
+    const float xc = tx * an[3] + an[1];
+    const float hh = h / 2.0f, hw = w / 2.0f;
+    float ymin = yc - hh, xmin = xc - hw, ymax = yc + hh, xmax = xc + hw;
+    ymin = fminf(fmaxf(ymin, 0.0f), 1.0f);
+    xmin = fminf(fmaxf(xmin, 0.0f), 1.0f);
+    ymax = fminf(fmaxf(ymax, 0.0f), 1.0f);
+    xmax = fminf(fmaxf(xmax, 0.0f), 1.0f);
+    const float area = (ymax - ymin) * (xmax - xmin);
+    *reinterpret_cast<float4_t*>(box_out) = (float4_t){ymin, xmin, ymax, xmax};
+    *valid_out = area > 0.0f ? 1 : 0;
+}
+
+// Everything that happens to four finished output columns n4 .. n4+3 of pixel m of an SSD head (v = the K sum, bias not yet
+// added): the epilogue proper (bias, store into the box-encoding / class-logit buffers), and optionally the candidate
+// marking for wz_k_nms and the box decode.  Shared by the grouped reduce launch and by the in-launch reduction.
+__device__ __forceinline__ void wz_head_finish(const WzConvArgs& a, int m, int n4, float4_t v, bool list, bool decode,
+                                               const float* __restrict__ hint_logit, uint32_t* __restrict__ cbits,
+                                               int cbits_words, const WzPostConsts& pc, const float* __restrict__ anchors,
+                                               float* __restrict__ boxes, uint8_t* __restrict__ valid) {
+    wz_epilogue4(a, m, n4, v);
+    if (m >= a.M) return;
+    const int n_box = a.out_mode == WZ_OUT_HEAD ? a.n_box : (a.out_mode == WZ_OUT_BOX ? a.cout : 0);
+    if (list && n4 >= n_box && n4 < a.cout && a.out_mode != WZ_OUT_BOX && a.out_mode != WZ_OUT_ACT) {
+        // class logits of one anchor location, four at a time: the ones that can reach the frame's first score band
+        // are listed for wz_k_nms (which re-derives score, validity and bin exactly as its own scan would)
+        const int hw = a.hout * a.wout;
+        const int b = m / hw, pix = m - b * hw;
+        const int cols = a.cout - n_box, n0 = n4 - n_box;
+        const long long off = a.out_mode == WZ_OUT_HEAD ? a.out2_off : a.out_off;
+        const float lf = hint_logit[b];
+        const float4_t bv = *reinterpret_cast<const float4_t*>(a.bias + n4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float x = v[r] + bv[r];   // what the epilogue stored
+            if (n0 + r < cols && x >= lf) {
+                const long long j = off + (long long)pix * cols + n0 + r;   // entry index within the frame's logits
+                atomicOr(&cbits[(size_t)b * cbits_words + (size_t)(j >> 5)], 1u << (j & 31));   // result unused
+            }
+        }
+    }
+    if (decode && n4 < n_box) {   // columns n4 .. n4+3 = the encoding of anchor (pixel, n4 / 4)
+        const float4_t bv = *reinterpret_cast<const float4_t*>(a.bias + n4);
+        float4_t enc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) enc[r] = v[r] + bv[r];   // what the epilogue stored
+        const int hw = a.hout * a.wout;
+        const int b = m / hw, pix = m - b * hw;
+        const int anchor = (int)(a.out_off >> 2) + pix * (n_box >> 2) + (n4 >> 2);
+        const size_t i = (size_t)b * pc.num_anchors + anchor;
+        wz_decode_anchor(enc, *reinterpret_cast<const float4_t*>(anchors + (size_t)anchor * 4), pc, boxes + i * 4, valid + i);
+    }
+}
+
+// ---- in-launch split-K reduction (see WzConvArgs::inline_reduce) ----------------------------------------------------
+// publish: write-through (sc1) stores, then the issuing wave waits for them (the compiler knows nothing of asm stores)
+__device__ __forceinline__ void wz_store_partial_sc1(float* p, const float4_t v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void wz_wait_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// the head's finish for the summed K slices of (m, n4) (summed in slice order: wz_k_splitk_reduce's arithmetic)
+__device__ __forceinline__ void wz_inline_finish(const WzConvArgs& a, int m, int n4, const float4_t v) {
+    if (m >= a.M || n4 >= a.n_pad) return;
+    const WzHeadFinish& f = *a.fin;
+    wz_head_finish(a, m, n4, v, (a.fin_flags & 2) != 0, (a.fin_flags & 1) != 0, f.hint_logit, f.cbits, f.cbits_words, f.pc,
+                   f.anchors, f.boxes, f.valid);
+}
+
+
 // Tile configuration: a wave computes (MT*16 pixels) x (NT*16 channels); U K-chunks (32 channels each)
 // per register buffer, two buffers in flight.
 //   <2,2,4>  small layers / small N: many waves, 1 KiB of loads per MFMA
@@ -270,6 +349,52 @@ __device__ __forceinline__ void wz_conv_body(const WzConvArgs& a, int bx, int by
     }
 
     // D layout: lane holds rows (n) g*4..g*4+3 of column (m) r16
+    if (a.splitk > 1 && a.inline_reduce) {
+        // in-launch reduction, one WAVE tile at a time (the waves of this kernel never meet): publish, take a ticket,
+        // and the wave that finds the other K slices already there sums them all in slice order and finishes
+        float* const ws = a.ws;   // (a.out is where the FINISHED columns go)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = m_base + mt * 16 + r16;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                if (m < a.M) wz_store_partial_sc1(ws + ((size_t)bz * a.M + m) * a.n_pad + (nt0 + nt) * 16 + g * 4, acc[mt][nt]);
+        }
+        wz_wait_stores();
+        int32_t* const tk = a.tickets + ((int)(by * a.grid_m + bx) * 4 + (int)(threadIdx.x >> 6));
+        int t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (t != a.splitk - 1) return;
+        if (lane == 0) __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < a.splitk; ++z) {   // a slice's fragments are all requested before the first is added
+            float4_t pz[MT][NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = m_base + mt * 16 + r16;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    pz[mt][nt] = m < a.M ? *reinterpret_cast<const float4_t*>(ws + ((size_t)z * a.M + m) * a.n_pad + (nt0 + nt) * 16 + g * 4)
+                                         : (float4_t){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[mt][nt][r] += pz[mt][nt][r];
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wz_inline_finish(a, m_base + mt * 16 + r16, (nt0 + nt) * 16 + g * 4, acc[mt][nt]);
+        return;
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int m = m_base + mt * 16 + r16;
@@ -387,27 +512,6 @@ __global__ __launch_bounds__(256) void wz_k_splitk_reduce(const WzConvArgs a, co
 
 // The reductions of several convolutions in one launch: a workgroup finds its entry from the prefix table, then does
 // exactly what wz_k_splitk_reduce does (same order over the splits: bit-identical results).
-// box decode + clip of one anchor from its finished encoding (ty, tx, th, tw): the arithmetic of wz_k_decode
-// (k_post.hip, which is compiled without contraction -- hence the pragma), operation for operation
-__device__ __forceinline__ void wz_decode_anchor(const float4_t e, const float4_t an, const WzPostConsts& k,
-                                                 float* __restrict__ box_out, uint8_t* __restrict__ valid_out) {
-#pragma clang fp contract(off)
-    const float ty = e[0] / k.scale_y, tx = e[1] / k.scale_x, th = e[2] / k.scale_h, tw = e[3] / k.scale_w;
-    const float w = expf(tw) * an[3];
-    const float h = expf(th) * an[2];
-    const float yc = ty * an[2] + an[0];
-    const float xc = tx * an[3] + an[1];
-    const float hh = h / 2.0f, hw = w / 2.0f;
-    float ymin = yc - hh, xmin = xc - hw, ymax = yc + hh, xmax = xc + hw;
-    ymin = fminf(fmaxf(ymin, 0.0f), 1.0f);
-    xmin = fminf(fmaxf(xmin, 0.0f), 1.0f);
-    ymax = fminf(fmaxf(ymax, 0.0f), 1.0f);
-    xmax = fminf(fmaxf(xmax, 0.0f), 1.0f);
-    const float area = (ymax - ymin) * (xmax - xmin);
-    *reinterpret_cast<float4_t*>(box_out) = (float4_t){ymin, xmin, ymax, xmax};
-    *valid_out = area > 0.0f ? 1 : 0;
-}
-
 __global__ __launch_bounds__(256) void wz_k_splitk_reduce_group(const WzReduceGroup g) {
     if (g.decode && !g.list) {   // first kernel of the histogram-based post chain: clear its per-frame scratch
         const int i = blockIdx.x * 256 + threadIdx.x;
@@ -429,38 +533,7 @@ __global__ __launch_bounds__(256) void wz_k_splitk_reduce_group(const WzReduceGr
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += p[r];
     }
-    wz_epilogue4(a, m, n4, v);
-    const int n_box = a.out_mode == WZ_OUT_HEAD ? a.n_box : (a.out_mode == WZ_OUT_BOX ? a.cout : 0);
-    if (g.list && n4 >= n_box && n4 < a.cout && a.out_mode != WZ_OUT_BOX && a.out_mode != WZ_OUT_ACT) {
-        // class logits of one anchor location, four at a time: the ones that can reach the frame's first score band
-        // are listed for wz_k_nms (which re-derives score, validity and bin exactly as its own scan would)
-        const int hw = a.hout * a.wout;
-        const int b = m / hw, pix = m - b * hw;
-        const int cols = a.cout - n_box, n0 = n4 - n_box;
-        const long long off = a.out_mode == WZ_OUT_HEAD ? a.out2_off : a.out_off;
-        const float lf = g.hint_logit[b];
-        const float4_t bv = *reinterpret_cast<const float4_t*>(a.bias + n4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float x = v[r] + bv[r];   // what the epilogue stored
-            if (n0 + r < cols && x >= lf) {
-                const long long j = off + (long long)pix * cols + n0 + r;   // entry index within the frame's logits
-                atomicOr(&g.cbits[(size_t)b * g.cbits_words + (size_t)(j >> 5)], 1u << (j & 31));   // result unused
-            }
-        }
-    }
-    if (g.decode && n4 < n_box) {   // columns n4 .. n4+3 = the encoding of anchor (pixel, n4 / 4)
-        const float4_t bv = *reinterpret_cast<const float4_t*>(a.bias + n4);
-        float4_t enc;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) enc[r] = v[r] + bv[r];   // what the epilogue stored
-        const int hw = a.hout * a.wout;
-        const int b = m / hw, pix = m - b * hw;
-        const int anchor = (int)(a.out_off >> 2) + pix * (n_box >> 2) + (n4 >> 2);
-        const size_t i = (size_t)b * g.pc.num_anchors + anchor;
-        wz_decode_anchor(enc, *reinterpret_cast<const float4_t*>(g.anchors + (size_t)anchor * 4), g.pc, g.boxes + i * 4,
-                         g.valid + i);
-    }
+    wz_head_finish(a, m, n4, v, g.list != 0, g.decode != 0, g.hint_logit, g.cbits, g.cbits_words, g.pc, g.anchors, g.boxes, g.valid);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -678,6 +751,9 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void wz_k_conv_lds(const WzConvAr
 struct WzEpiF16 {
     static __device__ __forceinline__ void apply(const WzConvArgs& a, int m, int n4, float4_t v) { wz_epilogue4(a, m, n4, v); }
     static __device__ __forceinline__ float* partials(const WzConvArgs& a) { return reinterpret_cast<float*>(a.out); }
+    static constexpr bool INLINE = true;   // supports WzConvArgs::inline_reduce
+    static __device__ __forceinline__ void publish(float* p, const float4_t v) { wz_store_partial_sc1(p, v); }
+    static __device__ __forceinline__ void finish(const WzConvArgs& a, int m, int n4, const float4_t v) { wz_inline_finish(a, m, n4, v); }
 };
 
 template <int KS, int NW, bool SPEC>
@@ -858,6 +934,10 @@ void wz_conv_group_add(WzConvGroup& g, const WzConvArgs& a) {
     g.gx[i] = (mtiles + 3) / 4;
     g.gy[i] = a.n_pad / 32;
     g.first[i + 1] = g.first[i] + g.gx[i] * g.gy[i] * a.splitk;
+    g.a[i].grid_m = g.gx[i];
+    g.a[i].grid_n = g.gy[i];
+    g.a[i].tickets = g.tickets ? g.tickets + g.ticket_off : nullptr;   // one counter per wave tile
+    g.ticket_off += g.gx[i] * g.gy[i] * 4;
 }
 void wz_launch_conv_group(const WzConvGroup& g, hipStream_t s) {
     WZ_LAUNCH(wz_k_conv_group, dim3(g.first[g.n]), dim3(256), 0, s, g);
@@ -879,6 +959,8 @@ void wz_conv_rs_group_add(WzConvGroup& g, const WzConvArgs& a0) {
     g.gx[i] = nw;
     g.gy[i] = 0;
     g.first[i + 1] = g.first[i] + ((a.grid_m * a.grid_n * a.splitk + 7) & ~7);   // entries start on an XCD boundary
+    a.tickets = g.tickets ? g.tickets + g.ticket_off : nullptr;                  // one counter per workgroup tile
+    g.ticket_off += a.grid_m * a.grid_n;
 }
 void wz_launch_conv_rs_group(const WzConvGroup& g, hipStream_t s) {
     WZ_LAUNCH(wz_k_conv_rs_group, dim3(g.first[g.n]), dim3(256), 0, s, g);

@@ -230,6 +230,69 @@ __device__ __forceinline__ void wz_conv_rs_body(const WzConvArgs& a, unsigned ch
     }
     if (!worker) return;
 
+    if constexpr (!SPEC && !F32) {
+        if (a.splitk > 1 && a.inline_reduce) {
+            // in-launch reduction (WzConvArgs::inline_reduce): every K slice publishes its partial tile write-through and
+            // takes a ticket on the tile's counter; the workgroup that finds the other slices already there sums them
+            // all in slice order (wz_k_splitk_reduce's arithmetic: bit-identical) and finishes the head's outputs
+            float* const ws = a.ws;   // (a.out is where the FINISHED columns go)
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+                const int m = m_base + mt * 16 + r16;
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    const int n4 = (nt_w + nt) * 16 + g * 4;
+                    if (m < a.M && n4 < a.n_pad) EPI::publish(ws + ((size_t)bz * a.M + m) * a.n_pad + n4, acc[mt][nt]);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                       // every wave's stores have landed (and nobody reads the LDS tiles any more)
+            int* const flag = reinterpret_cast<int*>(smem);
+            if (threadIdx.x == 0) {
+                int32_t* const tk = a.tickets + (by * a.grid_m + bx);
+                const int t = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (t == a.splitk - 1) {
+                    __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                        // this CU reads the slabs fresh
+                }
+                *flag = t;
+            }
+            __syncthreads();
+            if (*flag != a.splitk - 1) return;
+            // slice by slice, all of a slice's fragments requested before the first is added (one memory latency per
+            // slice, not per fragment); the sum order per element is slice 0, 1, 2 ... as in wz_k_splitk_reduce
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            for (int z = 0; z < a.splitk; ++z) {
+                float4_t pz[8][NTW];
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt) {
+                    const int m = m_base + mt * 16 + r16;
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt) {
+                        const int n4 = (nt_w + nt) * 16 + g * 4;
+                        pz[mt][nt] = (m < a.M && n4 < a.n_pad)
+                                         ? *reinterpret_cast<const float4_t*>(ws + ((size_t)z * a.M + m) * a.n_pad + n4)
+                                         : (float4_t){0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[mt][nt][r] += pz[mt][nt][r];
+            }
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) EPI::finish(a, m_base + mt * 16 + r16, (nt_w + nt) * 16 + g * 4, acc[mt][nt]);
+            return;
+        }
+    }
+
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
         const int m = m_base + mt * 16 + r16;

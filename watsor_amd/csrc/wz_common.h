@@ -59,6 +59,32 @@ struct WzConvArgs {
     float* ws;                  // fp32 engine: split-K workspace (the fp16 kernels get it through `out`)
     unsigned long long* dbg;    // WZ_MB_DEBUG=1: 16 slots of phase timestamps (LDS-tiled kernel), else nullptr
     int32_t order;              // tile order of the LDS-tiled kernels (experiment knob WZ_LDS_ORDER)
+    // In-launch split-K reduction of the SSD heads (splitk > 1 && inline_reduce): every K slice publishes its fp32 partial tile
+    // write-through, takes a ticket on the tile's counter, and the LAST arriver sums the slices in slice order (the order of
+    // wz_k_splitk_reduce: bit-identical) and finishes the outputs -- no reduce launch behind the convolution.
+    int32_t inline_reduce;
+    int32_t fin_flags;          // bit 0: decode the boxes, bit 1: mark the NMS candidates (see WzHeadFinish)
+    int32_t* tickets;           // one counter per output tile of this convolution, zero between launches
+    const struct WzHeadFinish* fin;   // device-resident, per lane
+};
+
+
+struct WzPostConsts {
+    int32_t num_anchors, num_classes;   // classes incl. background
+    int32_t max_total, max_per_class;
+    float score_thr, iou_thr;
+    float scale_y, scale_x, scale_h, scale_w;
+};
+
+// What finishing a head output needs beyond the convolution's own arguments (static per lane, lives in HBM).
+struct WzHeadFinish {
+    const float* hint_logit;    // [n] see WzPostBuffers
+    uint32_t* cbits;            // [n][cbits_words]
+    int32_t cbits_words, _pad;
+    WzPostConsts pc;
+    const float* anchors;       // [A][4]
+    float* boxes;               // [n][A][4] decoded + clipped
+    uint8_t* valid;             // [n][A]
 };
 
 // One fused inverted-residual block (k_mbconv.hip).  cin/kc/n_pad/cout describe the project conv.
@@ -99,12 +125,6 @@ struct WzCamFilter {
 };
 #define WZ_MAX_ZONES_PER_CAM (WZ_MAX_ZONES * 4)
 
-struct WzPostConsts {
-    int32_t num_anchors, num_classes;   // classes incl. background
-    int32_t max_total, max_per_class;
-    float score_thr, iou_thr;
-    float scale_y, scale_x, scale_h, scale_w;
-};
 
 // ---- launchers (each enqueues exactly one kernel on `s`) ------------------------------------
 // ... except under wz_profile_stages(), which has the network's launchers enqueue every kernel `wz_launch_repeat` times
@@ -149,6 +169,8 @@ struct WzConvGroup {
     int32_t first[WZ_CONV_GROUP_MAX + 1];
     int32_t gx[WZ_CONV_GROUP_MAX], gy[WZ_CONV_GROUP_MAX];
     WzConvArgs a[WZ_CONV_GROUP_MAX];
+    int32_t* tickets;           // host side only: the lane's counter block and how much of it the entries added so far use
+    int32_t ticket_off;
 };
 // split-K across the waves of a workgroup (no partials in HBM, no reduce launch): the extras chain
 bool wz_conv_ws_applies(const WzConvArgs& a);

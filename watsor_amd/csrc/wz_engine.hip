@@ -47,6 +47,7 @@ int wz_set_error(int code, const char* fmt, ...) {
 
 #define WZ_MAX_CAMS 256
 #define WZ_WS_BYTES (64ull << 20)
+#define WZ_TICKETS 8192   // tile counters per lane: first half the tile-kernel heads, second half the small ones
 
 struct StageTimer {
     std::vector<hipEvent_t> ev;
@@ -76,6 +77,11 @@ struct wz_engine {
     bool post_self = true;     // WZ_POST_SELF=0: histogram + compaction kernels in front of the NMS kernel
     bool fuse_decode = true;   // WZ_FUSE_DECODE=0: keep wz_k_decode as its own launch
     bool defer_heads = true;   // the SSD heads' split-K reductions run as one launch after the last head (WZ_DEFER_HEADS=0: one each)
+    bool head_inline = false;  // WZ_HEAD_INLINE=1: ... or inside the head convolutions themselves, by each tile's last K slice.
+                               // Bit-identical and one launch less, but measured SLOWER (profiles/r02l_*: heads 76 + 18 us against
+                               // 33 + 7 + 10 us, 37.4 k against 41.5 k frames/s): the reduction of a tile then runs on ONE workgroup at
+                               // the tail of the launch and its epilogue stores from the MFMA fragment layout (16 pixels x 4 columns per
+                               // instruction) instead of row-contiguous as the reduce kernel does.  Off by default.
 
     uint8_t* d_weights = nullptr;
     half_t* d_zeros = nullptr;               // 4 KiB of zeros
@@ -98,6 +104,8 @@ struct wz_engine {
         float* d_box_enc = nullptr;
         float* d_logits = nullptr;
         float* d_ws = nullptr;
+        int32_t* d_tickets = nullptr;        // tile counters of the in-launch head reductions (zero between launches)
+        WzHeadFinish* d_fin = nullptr;       // what finishing a head output needs (static)
         bool decode_fused = false;           // set by enqueue_network: the grouped head reduce decoded the boxes
         bool cands_listed = false;           // ... and listed the candidates of the NMS kernel's first band
         uint8_t* d_frames = nullptr;         // staging for host frames of this lane [max_batch][frame_stride] (lazy)
@@ -192,6 +200,11 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
     WzConvGroup small, big;
     small.n = big.n = 0;
     small.first[0] = big.first[0] = 0;
+    big.tickets = L.d_tickets;
+    small.tickets = L.d_tickets ? L.d_tickets + WZ_TICKETS / 2 : nullptr;
+    big.ticket_off = small.ticket_off = 0;
+    int heads_in_groups = 0;                // entries of `heads` whose convolution sits in `big` or `small`
+    int big_head[WZ_CONV_GROUP_MAX] = {0}, small_head[WZ_CONV_GROUP_MAX] = {0};   // ... and which entry
     for (uint32_t i = 0; i < e->hdr.n_ops; ++i) {
         const WzOpDesc& op = e->ops[i];
         const uint8_t* wbase = e->d_weights;
@@ -310,12 +323,17 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
                 float* const park = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(L.d_ws) + ws_top);
                 a.splitk = sk;
                 a.out = park;
-                if (small.n < WZ_CONV_GROUP_MAX && wz_conv_groupable(a))
+                if (small.n < WZ_CONV_GROUP_MAX && wz_conv_groupable(a)) {
+                    small_head[small.n] = heads.n;
                     wz_conv_group_add(small, a);   // launched with the other small heads after the last op
-                else if (big.n < WZ_CONV_GROUP_MAX && wz_conv_rs_groupable(a))
+                    ++heads_in_groups;
+                } else if (big.n < WZ_CONV_GROUP_MAX && wz_conv_rs_groupable(a)) {
+                    big_head[big.n] = heads.n;
                     wz_conv_rs_group_add(big, a);  // the heads on the tile kernel: one launch, too
-                else
+                    ++heads_in_groups;
+                } else {
                     wz_launch_conv(a, s);
+                }
                 if (t) { t->mark(); t->mark(); }   // its own reduce slot stays empty
                 a.out = final_out;
                 wz_reduce_group_add(heads, a, park);
@@ -346,12 +364,29 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
         }
         if (t) t->mark();
     }
+    // every box encoding is finished by the grouped reduce: let it decode the boxes as well (one launch less)
+    L.decode_fused = heads.n > 0 && box_ops > 0 && box_ops == box_ops_grouped && e->fuse_decode;
+    // ... and, when the NMS kernel selects its own candidates, list the class logits that can reach its first band
+    L.cands_listed = with_post && L.decode_fused && e->post_self && head_ops == heads.n && e->list_cands;
+    // With WZ_HEAD_INLINE=1 (and all of the above) the reduction does not take a launch of its own: the head convolutions do
+    // it themselves, tile by tile, in the workgroup (wave) that publishes a tile's last K slice
+    const bool inline_heads = e->head_inline && !f32 && L.cands_listed && L.d_tickets && L.d_fin && heads.n > 0 &&
+                              heads_in_groups == heads.n && big.ticket_off <= WZ_TICKETS / 2 && small.ticket_off <= WZ_TICKETS / 2;
+    if (inline_heads) {
+        for (int i = 0; i < big.n + small.n; ++i) {
+            WzConvArgs& a = i < big.n ? big.a[i] : small.a[i - big.n];
+            const WzConvArgs& fin = heads.a[i < big.n ? big_head[i] : small_head[i - big.n]];
+            a.ws = reinterpret_cast<float*>(a.out);     // the slab of partial tiles ...
+            a.out = fin.out;                            // ... and where the finished columns go
+            a.inline_reduce = 1;
+            a.fin_flags = 3;                            // decode + list
+            a.fin = L.d_fin;
+        }
+    }
     if (big.n > 0) wz_launch_conv_rs_group(big, s);
     if (t) t->mark();
     if (small.n > 0) wz_launch_conv_group(small, s);
     if (t) t->mark();
-    // every box encoding is finished by the grouped reduce: let it decode the boxes as well (one launch less)
-    L.decode_fused = heads.n > 0 && box_ops > 0 && box_ops == box_ops_grouped && e->fuse_decode;
     if (L.decode_fused) {
         heads.decode = 1;
         heads.n_frames = n;
@@ -363,15 +398,13 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
         heads.count = L.post.count;
         heads.band = L.post.band;
     }
-    // ... and, when the NMS kernel selects its own candidates, list the class logits that can reach its first band
-    L.cands_listed = with_post && L.decode_fused && e->post_self && head_ops == heads.n && e->list_cands;
     heads.list = L.cands_listed ? 1 : 0;
     if (L.cands_listed) {
         heads.hint_logit = L.post.hint_logit;
         heads.cbits = L.post.cbits;
         heads.cbits_words = (e->pc.num_anchors * e->pc.num_classes + 31) >> 5;
     }
-    if (heads.n > 0) wz_launch_splitk_reduce_group(heads, s);
+    if (heads.n > 0 && !inline_heads) wz_launch_splitk_reduce_group(heads, s);
     if (t) t->mark();
 }
 
@@ -558,6 +591,7 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     e->fuse_decode = !((env = getenv("WZ_FUSE_DECODE")) && atoi(env) == 0);
     e->post_self = !((env = getenv("WZ_POST_SELF")) && atoi(env) == 0);
     e->list_cands = !((env = getenv("WZ_LIST_CANDS")) && atoi(env) == 0);
+    e->head_inline = (env = getenv("WZ_HEAD_INLINE")) && atoi(env) != 0;
     if ((env = getenv("WZ_LANES")) && atoi(env) >= 1 && atoi(env) <= WZ_SLOTS) e->n_lanes = atoi(env);
 
 #define CK(expr)                                                                                        \
@@ -650,6 +684,9 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
         CK(hipMalloc((void**)&L.d_box_enc, (size_t)max_batch * h.num_anchors * 4 * 4));
         CK(hipMalloc((void**)&L.d_logits, (size_t)max_batch * h.num_anchors * h.num_classes * 4));
         CK(hipMalloc((void**)&L.d_ws, WZ_WS_BYTES));
+        CK(hipMalloc((void**)&L.d_tickets, WZ_TICKETS * 4));
+        CK(hipMemset(L.d_tickets, 0, WZ_TICKETS * 4));
+        CK(hipMalloc((void**)&L.d_fin, sizeof(WzHeadFinish)));
         CK(hipMalloc((void**)&L.d_frames, e->frame_stride * max_batch));
         WzPostBuffers& pb = L.post;
         pb.box_enc = L.d_box_enc;
@@ -675,6 +712,18 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
             CK(hipMemcpy(pb.hint_logit, hl0.data(), hl0.size() * 4, hipMemcpyHostToDevice));
             pb.cbits = reinterpret_cast<uint32_t*>(pb.hint_logit + max_batch);
             CK(hipMemset(pb.cbits, 0, (size_t)max_batch * ((h.num_anchors * h.num_classes + 31) >> 5) * 4));
+        }
+        {
+            WzHeadFinish hf;
+            memset(&hf, 0, sizeof(hf));
+            hf.hint_logit = pb.hint_logit;
+            hf.cbits = pb.cbits;
+            hf.cbits_words = (int32_t)((h.num_anchors * h.num_classes + 31) >> 5);
+            hf.pc = e->pc;
+            hf.anchors = pb.anchors;
+            hf.boxes = pb.boxes;
+            hf.valid = pb.valid;
+            CK(hipMemcpy(L.d_fin, &hf, sizeof(hf), hipMemcpyHostToDevice));
         }
         CK(hipMalloc((void**)&pb.cand, (size_t)max_batch * WZ_CAND_CAP * sizeof(uint2)));
         CK(hipMalloc((void**)&pb.det_boxes, (size_t)max_batch * h.max_total * 16));
@@ -744,7 +793,7 @@ extern "C" void wz_destroy(wz_engine_t* e) {
         Lane& L = e->lanes[li];
         for (auto& kv : L.graphs) (void)hipGraphExecDestroy(kv.second);
         for (void* p : L.bufs) (void)hipFree(p);
-        void* lp[] = {L.d_frames, L.d_box_enc, L.d_logits, L.d_ws, L.post.boxes, L.post.valid, L.d_post_scratch, L.post.cand,
+        void* lp[] = {L.d_frames, L.d_box_enc, L.d_logits, L.d_ws, L.d_tickets, L.d_fin, L.post.boxes, L.post.valid, L.d_post_scratch, L.post.cand,
                       L.post.det_boxes, L.post.det_scores, L.post.det_classes, L.post.det_num, L.post.dbg, L.d_desc, L.d_rows,
                       L.d_pass};
         for (void* p : lp)
