@@ -219,8 +219,14 @@ def test_split_operand_blocks_carry_hi_and_lo_weights(hp_blob, default_blob, syn
         assert np.abs(lo).max() <= np.abs(hi).max() * 2.0 ** -10 and lo.any()
         # expand (or stem): the same with the factor 1/6
         wf, bf = engine.fold_batch_norm(synth_weights, ex)
-        kin = 27 if op.stem else ex.cin
-        ref = wf.reshape(1, kin, ex.cout) / 6.0
+        kin = 32 if op.stem else ex.cin
+        if op.stem:                  # K order of the stem gather: tap*4 + c, the ninth tap in the pad slots of taps 0 .. 2
+            rows = engine.stem_k_rows(wf)
+            assert np.array_equal(rows[5], wf[0, 1, 1]) and np.array_equal(rows[7], wf[2, 2, 1]) and not rows[15].any()
+            assert np.count_nonzero(np.abs(rows).sum(1)) == 27
+            ref = rows.reshape(1, 32, ex.cout) / 6.0
+        else:
+            ref = wf.reshape(1, kin, ex.cout) / 6.0
         d = dict(ksize=1, n_pad=o["nmid_pad"], kc=o["kc0"])
         hi = unpack_conv(hp_blob, hdr, dict(d, w_off=o["we_off"])).astype(np.float64)
         lo = unpack_conv(hp_blob, hdr, dict(d, w_off=o["we_lo_off"])).astype(np.float64)

@@ -134,35 +134,23 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
         const bool ok = live && p < P && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
         inimg[i] = ok;
         if constexpr (STEM) {
-            // k = g*8 + j = (ky*3 + kx)*3 + c: this lane needs taps tb .. tb+3 with tb = (g*8)/3 = {0, 2, 5, 8}
-            const int tb = (g * 8) / 3;
-            half4_t tph[4], tpl[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int tq = tb + q;
+            // K order of the stem GEMM in this program (engine.py: stem_k_rows): k = tap*4 + c for taps 0 .. 7, i.e. lane group
+            // g holds the 4-channel pixels of taps 2g and 2g+1 exactly as they lie in the input pair tensor, and the ninth
+            // tap's three channels sit in the always-zero fourth-channel slots of taps 0, 1, 2 (k = 3, 7, 11: groups 0 and 1)
+            auto tap = [&](int tq, bool want) -> half8_t {
                 const int ky = tq / 3, kx = tq - ky * 3;
                 const int sy = iy * 2 - a.spad_t + ky, sx = ix * 2 - a.spad_l + kx;   // stem: stride 2 on the input image
-                const bool in = ok && tq < 9 && sy >= 0 && sy < a.sin_h && sx >= 0 && sx < a.sin_w;
+                const bool in = want && ok && sy >= 0 && sy < a.sin_h && sx >= 0 && sx < a.sin_w;
                 const int cy = min(max(sy, 0), a.sin_h - 1), cx = min(max(sx, 0), a.sin_w - 1);
                 const half8_t v = *reinterpret_cast<const half8_t*>(a.in + ((size_t)(b * a.sin_h + cy) * a.sin_w + cx) * 8);
-                tph[q] = in ? (half4_t){v[0], v[1], v[2], v[3]} : (half4_t){0, 0, 0, 0};
-                tpl[q] = in ? (half4_t){v[4], v[5], v[6], v[7]} : (half4_t){0, 0, 0, 0};
-            }
-            half8_t x, y;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                half_t eh[4], el[4];
-#pragma unroll
-                for (int gg = 0; gg < 4; ++gg) {
-                    const int k = gg * 8 + j;
-                    eh[gg] = k < 27 ? tph[k / 3 - (gg * 8) / 3][k % 3] : (half_t)0.0f;
-                    el[gg] = k < 27 ? tpl[k / 3 - (gg * 8) / 3][k % 3] : (half_t)0.0f;
-                }
-                x[j] = g == 0 ? eh[0] : g == 1 ? eh[1] : g == 2 ? eh[2] : eh[3];
-                y[j] = g == 0 ? el[0] : g == 1 ? el[1] : g == 2 ? el[2] : el[3];
-            }
-            xh[i][0] = x;
-            xl[i][0] = y;
+                return in ? v : zero8;
+            };
+            const half8_t va = tap(2 * g, true), vb = tap(2 * g + 1, true), v8 = tap(8, g <= 1);
+            const half_t z16 = (half_t)0.0f;
+            const half_t e0h = g == 0 ? v8[0] : g == 1 ? v8[2] : z16, e1h = g == 0 ? v8[1] : z16;
+            const half_t e0l = g == 0 ? v8[4] : g == 1 ? v8[6] : z16, e1l = g == 0 ? v8[5] : z16;
+            xh[i][0] = (half8_t){va[0], va[1], va[2], e0h, vb[0], vb[1], vb[2], e1h};
+            xl[i][0] = (half8_t){va[4], va[5], va[6], e0l, vb[4], vb[5], vb[6], e1l};
         } else {
             const half_t* src = a.in + ((size_t)(b * a.hin + (ok ? iy : 0)) * a.win + (ok ? ix : 0)) * (2 * a.cin0);
 #pragma unroll

@@ -80,6 +80,21 @@ def split_halves(w: np.ndarray):
 UNORM16_PER_6 = 65535.0 / 6.0    # the split-operand blocks keep relu6 outputs in LDS as unorm16 of x / 6
 
 
+def stem_k_rows(w: np.ndarray) -> np.ndarray:
+    """Stem weights [3,3,3,cout] -> [32, cout] in the K order the split-operand stem block gathers its B fragments in
+    (csrc/k_mbconv_hp.hip): k = tap*4 + c for taps 0 .. 7 (a lane group's 8 values = the 4-channel pixels of two taps,
+    loaded as they lie in the input tensor, no element shuffling), and the ninth tap's three channels in the zero-channel
+    slots of taps 0, 1, 2 (k = 3, 7, 11).  The plain program keeps k = tap*3 + c (csrc/k_mbconv_wave.hip)."""
+    cout = w.shape[3]
+    out = np.zeros((32, cout), w.dtype)
+    for t in range(8):
+        for c in range(3):
+            out[t * 4 + c] = w[t // 3, t % 3, c]
+    for c in range(3):
+        out[c * 4 + 3] = w[2, 2, c]
+    return out
+
+
 def pack_conv_weights_f32(w: np.ndarray, n_pad: int, kc: int) -> np.ndarray:
     """[k,k,cin,cout] -> fp32 [n_pad/16][taps][kc][64][4]: lane (r16, g) of N-tile t holds W[k = c*16 + 4g + j][n = t*16 + r16]
     (the A operands of four v_mfma_f32_16x16x4_f32, one float4 load per lane; csrc/k_f32.hip)."""
@@ -218,7 +233,7 @@ def build_engine(weights: Dict[str, np.ndarray], precision: int = 16, model_widt
             if op.stem:
                 st = parts.pop(0)
                 w, b = fold_batch_norm(weights, st)
-                mb["we_off"], mb["we_lo_off"] = put_split(w.reshape(1, 1, 27, st.cout) / 6.0, 32, 1)
+                mb["we_off"], mb["we_lo_off"] = put_split(stem_k_rows(w).reshape(1, 1, 32, st.cout) / 6.0, 32, 1)
                 mb["be_off"] = put((b / 6.0).astype(np.float32))
                 mb.update(nmid_pad=32, kc0=1, stem=1, stem_pad=(op.stem_pad[0] << 16) | op.stem_pad[1])
             else:
