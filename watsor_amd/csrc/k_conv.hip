@@ -948,19 +948,31 @@ bool wz_conv_rs_groupable(const WzConvArgs& a) {
     static const int rs = wz_env_int("WZ_LDS_RS", 1);
     return rs && !wz_lds_spec() && a.ksize == 3 && wz_conv_use_lds(a);
 }
-void wz_conv_rs_group_add(WzConvGroup& g, const WzConvArgs& a0) {
-    const int i = g.n++;
-    WzConvArgs& a = g.a[i];
-    a = a0;
-    const int nw = wz_lds_nw(a.M, a.n_pad, a.kchunks);
-    a.grid_m = (a.M + WZ_LDS_TM - 1) / WZ_LDS_TM;
-    a.grid_n = (a.n_pad + WZ_LDS_TN(nw) - 1) / WZ_LDS_TN(nw);
-    a.order = 0;
-    g.gx[i] = nw;
-    g.gy[i] = 0;
-    g.first[i + 1] = g.first[i] + ((a.grid_m * a.grid_n * a.splitk + 7) & ~7);   // entries start on an XCD boundary
-    a.tickets = g.tickets ? g.tickets + g.ticket_off : nullptr;                  // one counter per workgroup tile
-    g.ticket_off += a.grid_m * a.grid_n;
+// Returns the number of entries added (0: the group is full).  A head whose packed columns are an odd number of 64-column
+// tiles (BoxPredictor_0: 320 = 2 x 128 + 64, BoxPredictor_1: 576 = 4 x 128 + 64) goes in as TWO entries -- the 128-column
+// tiles and one 64-column tile behind them -- instead of rounding up to 128-column tiles (384 / 640 columns of MFMA work: 20 % /
+// 11 % of it on padding).  Both write the same partial-sum slab ([z][M][n_pad], absolute columns) with the same split count.
+int wz_conv_rs_group_add(WzConvGroup& g, const WzConvArgs& a0) {
+    static const int split_n = wz_env_int("WZ_HEAD_SPLIT_N", 1);
+    const int nw = wz_lds_nw(a0.M, a0.n_pad, a0.kchunks);
+    const bool two = split_n && nw == 4 && (a0.n_pad % 128) == 64 && a0.n_pad > 128;
+    if (g.n + (two ? 2 : 1) > WZ_CONV_GROUP_MAX) return 0;
+    for (int part = 0; part < (two ? 2 : 1); ++part) {
+        const int i = g.n++;
+        WzConvArgs& a = g.a[i];
+        a = a0;
+        const int pnw = (two && part == 1) ? 2 : nw;
+        a.grid_m = (a.M + WZ_LDS_TM - 1) / WZ_LDS_TM;
+        a.nt_base = (two && part == 1) ? (a.n_pad / 128) * 8 : 0;
+        a.grid_n = two ? (part == 0 ? a.n_pad / 128 : 1) : (a.n_pad + WZ_LDS_TN(nw) - 1) / WZ_LDS_TN(nw);
+        a.order = 0;
+        g.gx[i] = pnw;
+        g.gy[i] = 0;
+        g.first[i + 1] = g.first[i] + ((a.grid_m * a.grid_n * a.splitk + 7) & ~7);   // entries start on an XCD boundary
+        a.tickets = g.tickets ? g.tickets + g.ticket_off : nullptr;                  // one counter per workgroup tile
+        g.ticket_off += a.grid_m * a.grid_n;
+    }
+    return two ? 2 : 1;
 }
 void wz_launch_conv_rs_group(const WzConvGroup& g, hipStream_t s) {
     WZ_LAUNCH(wz_k_conv_rs_group, dim3(g.first[g.n]), dim3(256), 0, s, g);

@@ -58,7 +58,7 @@ __device__ __forceinline__ void wz_conv_rs_body(const WzConvArgs& a, unsigned ch
         bz = rest / a.grid_n;
     }
     const int m_base = bx * WZ_RS_TM;
-    const int nt_w = by * (2 * NW) + wave * NTW;   // first channel tile of this wave
+    const int nt_w = a.nt_base + by * (2 * NW) + wave * NTW;   // first channel tile of this wave
 
     // Addressing is the expensive part of an implicit GEMM step if done naively (a first version spent 900 of its
     // 2 400 cycles per step on 64-bit address arithmetic and bounds tests): both operands are read through buffer

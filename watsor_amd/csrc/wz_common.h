@@ -62,6 +62,7 @@ struct WzConvArgs {
     // In-launch split-K reduction of the SSD heads (splitk > 1 && inline_reduce): every K slice publishes its fp32 partial tile
     // write-through, takes a ticket on the tile's counter, and the LAST arriver sums the slices in slice order (the order of
     // wz_k_splitk_reduce: bit-identical) and finishes the outputs -- no reduce launch behind the convolution.
+    int32_t nt_base;            // tile kernel: first 16-channel tile this launch entry serves (a head split along N, see wz_conv_rs_group_add)
     int32_t inline_reduce;
     int32_t fin_flags;          // bit 0: decode the boxes, bit 1: mark the NMS candidates (see WzHeadFinish)
     int32_t* tickets;           // one counter per output tile of this convolution, zero between launches
@@ -163,7 +164,7 @@ struct WzReduceGroup {
 };
 void wz_reduce_group_add(WzReduceGroup& g, const WzConvArgs& a, const float* ws);
 // several independent small 3x3 convolutions (wz_k_conv<3, 2, 2, 4> shapes) in ONE launch
-#define WZ_CONV_GROUP_MAX 4
+#define WZ_CONV_GROUP_MAX 6
 struct WzConvGroup {
     int32_t n;
     int32_t first[WZ_CONV_GROUP_MAX + 1];
@@ -180,7 +181,7 @@ void wz_conv_group_add(WzConvGroup& g, const WzConvArgs& a);
 void wz_launch_conv_group(const WzConvGroup& g, hipStream_t s);
 // ... and the convolutions of the register-staged 128 x 128 tile kernel (the two big heads)
 bool wz_conv_rs_groupable(const WzConvArgs& a);
-void wz_conv_rs_group_add(WzConvGroup& g, const WzConvArgs& a);
+int wz_conv_rs_group_add(WzConvGroup& g, const WzConvArgs& a);   // entries added (a head may be split along N), 0 = full
 void wz_launch_conv_rs_group(const WzConvGroup& g, hipStream_t s);
 void wz_launch_splitk_reduce_group(const WzReduceGroup& g, hipStream_t s);
 int wz_choose_splitk(int M, int n_pad, int kchunks);

@@ -327,9 +327,8 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
                     small_head[small.n] = heads.n;
                     wz_conv_group_add(small, a);   // launched with the other small heads after the last op
                     ++heads_in_groups;
-                } else if (big.n < WZ_CONV_GROUP_MAX && wz_conv_rs_groupable(a)) {
-                    big_head[big.n] = heads.n;
-                    wz_conv_rs_group_add(big, a);  // the heads on the tile kernel: one launch, too
+                } else if (int added = wz_conv_rs_groupable(a) ? wz_conv_rs_group_add(big, a) : 0) {
+                    for (int k = 0; k < added; ++k) big_head[big.n - 1 - k] = heads.n;   // the heads on the tile kernel: one launch, too
                     ++heads_in_groups;
                 } else {
                     wz_launch_conv(a, s);
