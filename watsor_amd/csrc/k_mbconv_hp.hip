@@ -65,7 +65,9 @@ __device__ __forceinline__ void wz_hp_fma8(wz_f32x2_t d[4], const wz_f32x2_t x[4
 // OCC: wavefronts per SIMD the kernel is compiled for (2: 256 registers, everything prefetched into them; 3 / 4: 168 / 128
 // registers -- depthwise weights read from LDS where they are used, taps requested a row at a time -- for the blocks
 // whose waves spend their time waiting rather than issuing).
-template <int NW, bool CS, bool STEM, int MPW, int MQW, int KCI, int NTO, int OCC = 2>
+// ONEPASS (CS only): the workgroup has at least as many waves as the block has chunks, every wave walks at most ONE -- the
+// halo fragments and the expand weights are then dead after the expand stage and the kernel fits 3 waves per SIMD.
+template <int NW, bool CS, bool STEM, int MPW, int MQW, int KCI, int NTO, int OCC = 2, bool ONEPASS = false>
 __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wz_hp_smem[];
     constexpr bool LDSW = CS || OCC > 2;                 // depthwise weights staged in LDS (else: registers, from L2)
@@ -262,7 +264,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
                 }
             }
         }
-        if (ps + STEP < nk32) load_wa(ps + STEP);   // next pass's expand fragments, in flight under the depthwise stage
+        if constexpr (!ONEPASS)
+            if (ps + STEP < nk32) load_wa(ps + STEP);   // next pass's expand fragments, in flight under the depthwise stage
         // the wave's own LDS writes are ordered before its reads by the LDS queue; keep the compiler from moving the reads up
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -346,6 +349,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
 #pragma unroll
             for (int nt = 0; nt < NTO; ++nt) acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wph[nt], bh, acc[j][nt], 0, 0, 0);
         }
+        if constexpr (ONEPASS) break;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();   // (the next pass's E stores stay behind these reads)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -420,11 +424,12 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
 // ---------------------------------------------------------------------------------------------
 static int wz_hp_env(const char* name, int dflt) {
     const char* e = getenv(name);
-    return (e && atoi(e) > 0) ? atoi(e) : dflt;
+    return (e && e[0] && atoi(e) >= 0) ? atoi(e) : dflt;
 }
 
-template <int NW, bool CS, bool STEM, int MPW, int MQW, int KCI, int NTO, int OCC = 2>
+template <int NW, bool CS, bool STEM, int MPW, int MQW, int KCI, int NTO, int OCC = 2, bool ONEPASS = false>
 static int wz_hp_launch(WzMbArgs a, int n, hipStream_t s, bool prepare) {
+    if (ONEPASS && (a.cmid_pad >> 5) > NW) return -1;
     a.nb = n;
     if (MQW == 2) { a.th = 4; a.tw = 8; } else { a.th = 4; a.tw = 4; }
     a.tiles_y = (a.hout + a.th - 1) / a.th;
@@ -433,7 +438,7 @@ static int wz_hp_launch(WzMbArgs a, int n, hipStream_t s, bool prepare) {
     constexpr int RED = CS ? NW * MQW * NTO * 1024 : 0;
     const size_t region = (size_t)(NW * EB > RED ? NW * EB : RED);
     const size_t lds = region + (size_t)a.cmid_pad * ((CS || OCC > 2) ? 8 + 36 : 8);
-    auto k = wz_k_mbconv_hp<NW, CS, STEM, MPW, MQW, KCI, NTO, OCC>;
+    auto k = wz_k_mbconv_hp<NW, CS, STEM, MPW, MQW, KCI, NTO, OCC, ONEPASS>;
     if (prepare) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return lds <= 160 * 1024 ? 0 : -1;
@@ -509,6 +514,19 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
     if (a.stride == 2) {
         if (a.kc0 == 1 && nto == 4) return wz_hp_launch<HP_CS_WAVES, true, false, 6, 1, 1, 4>(a, n, s, prepare);
         return -1;
+    }
+    // 12 chunks (cmid 384), WZ_HP_ONEPASS=1: 12 waves with one chunk each instead of 8 waves with up to two.  Measured
+    // (profiles/r02r_*, A/B in one run): 8.97 against 8.0 us per block -- four more waves repeat the halo load and the
+    // accumulators of twelve waves meet in LDS; the chunk walk is not what these launches wait for.  Off by default.
+    static const int onepass = wz_hp_env("WZ_HP_ONEPASS", 0);
+    if (nk32 <= 12 && a.kc0 == 2 && (nto == 4 || nto == 6)) {
+        if (prepare) {
+            (void)wz_hp_launch<12, true, false, 3, 1, 2, 4, 3, true>(a, n, s, true);
+            (void)wz_hp_launch<12, true, false, 3, 1, 2, 6, 3, true>(a, n, s, true);
+        } else if (onepass == 1) {
+            return nto == 4 ? wz_hp_launch<12, true, false, 3, 1, 2, 4, 3, true>(a, n, s, false)
+                            : wz_hp_launch<12, true, false, 3, 1, 2, 6, 3, true>(a, n, s, false);
+        }
     }
 #define HP_CASE(K, N) if (a.kc0 == K && nto == N) return wz_hp_launch<HP_CS_WAVES, true, false, 3, 1, K, N>(a, n, s, prepare)
     HP_CASE(2, 4);
