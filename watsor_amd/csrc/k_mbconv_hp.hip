@@ -459,6 +459,7 @@ static int wz_hp_launch(WzMbArgs a, int n, hipStream_t s, bool prepare) {
 //     with one wave per tile (75x75 on it as well: 35.0 k).
 int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) {
     static const int cs_max_w = wz_hp_env("WZ_HP_CS_MAX_W", 19);
+    static const int cs_few_wgs = wz_hp_env("WZ_HP_CS_FEW_WGS", 64);   // chunk-split when one wave per tile gives at most this many workgroups
     const int nto = a0.n_pad / 16;
     WzMbArgs a = a0;
     a.nsplit = 1;
@@ -483,7 +484,13 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
     }
     if (a.cin0 == 0) return -1;
     if (a.wout > 19 && a.kc0 == 1 && nto == 2) {
-        const bool cs = (prepare || a.wout <= cs_max_w) && nk32 >= 4 && nk32 <= 6;
+        // Few frames (a single camera's frame at a time is the reference's normal load, detector.py:102-112): one wave per tile
+        // would leave most CUs empty and every wave walking 5 - 6 chunks, ~2 us each -- there the chunks go to the waves of a
+        // workgroup instead (measured at batch 1, profiles/r02t_*).  With the GPU filled by the batch it is the other way
+        // round (comment above wz_launch_mbconv_hp).
+        const int tiles_s1 = ((a.hout + 3) / 4) * ((a.wout + (a.stride == 1 ? 7 : 3)) / (a.stride == 1 ? 8 : 4));
+        const bool few = (tiles_s1 * n + 3) / 4 <= cs_few_wgs;
+        const bool cs = (prepare || a.wout <= cs_max_w || few) && nk32 >= 4 && nk32 <= 6;
         if (a.stride == 1) {        // 4 x 8 tiles, halo 6 x 10 = 60 pixels
             if (prepare) {
                 (void)wz_hp_launch<5, true, false, 4, 2, 1, 2>(a, n, s, true);
