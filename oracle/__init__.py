@@ -5,9 +5,10 @@ integer stages), the algorithm that the reference's CPU detector plugin runs for
 frame (`watsor/detection/tensorflow_cpu.py:74-121`) together with the per-camera
 filters that run right behind it (`watsor/filter/{confidence,area,mask}.py`).
 
-Who may use it: `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of
-`bench.py` -- as the *checker* or the *reported baseline*, never as the thing that is
-shipped or measured.  Nothing under `watsor_amd/` imports this package; the product
+Who may use it: `tests/`, `__graft_entry__.smoke()` and two legs of `bench.py` -- `cpu_baseline`
+(the reported baseline) and `parity` (the live check of the timed engine's scores against the
+north star's 1e-3, requested by the round-1 review) -- as the *checker* or the *reported
+baseline*, never as the thing that is shipped or measured.  Nothing under `watsor_amd/` imports this package; the product
 path fails loudly when the HIP library is missing instead of falling back to it.
 
 Pinning status (see DESIGN.md "Oracle"):
@@ -20,7 +21,9 @@ Pinning status (see DESIGN.md "Oracle"):
   asserts a detection *count*.  The restatement follows the published TF1 Object
   Detection API graph semantics and the reference's own SSD
   config (`watsor/test/model/prepare.py:19-150`); the backbone is cross-checked
-  against the independent `transformers` MobileNetV2 (tests/test_oracle_backbone.py).
+  against the independent `transformers` MobileNetV2 (tests/test_oracle_witness.py).
+  Route to pinned: `tests/golden/make_tf_golden.py` (run where TensorFlow and the model exist)
+  + `tests/test_tf_golden.py` (consumes the vectors when present).
 * row fill / int truncation / struct ABI: pinned by `tensorflow_cpu.py:79-90` and the
   ctypes layout of `watsor/stream/share.py:11-32` (checked against the real structs
   when `/root/reference` is importable, tests/test_abi.py).
