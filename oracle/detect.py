@@ -56,7 +56,11 @@ def rows_as_array(image_shape, boxes, label_codes, scores) -> Dict[str, np.ndarr
 class OracleObjectDetector:
     """CPU restatement of `TensorFlowObjectDetector` (tensorflow_cpu.py:10-121) on explicit weights."""
 
-    def __init__(self, model_path=None, weights: Optional[Dict[str, np.ndarray]] = None, size: int = 300):
+    def __init__(self, model_path=None, weights: Optional[Dict[str, np.ndarray]] = None, size: int = 300,
+                 fast_post: bool = False):
+        """fast_post: post-process in one global score order (`postprocess.multiclass_nms_global_order`, held equal to the
+        literal class-by-class version by tests) -- for the CPU baseline of bench.py; the checker uses the literal one."""
+        self._fast_post = fast_post
         if weights is None:
             import os
             path = os.path.join(model_path, "oracle.npz")
@@ -82,7 +86,7 @@ class OracleObjectDetector:
         """(boxes[100,4], classes[100] 1-based float, scores[100], box_enc, logits) for one frame."""
         x = pre.preprocess(image_np, self._size)[None]
         be, cl, _ = self._net.forward(x)
-        b, s, c, _ = post.postprocess(be[0], cl[0], self._anchors)
+        b, s, c, _ = post.postprocess(be[0], cl[0], self._anchors, fast=self._fast_post)
         return b, c, s, be[0], cl[0]
 
     def detect(self, image_shape, image_np, detections) -> float:

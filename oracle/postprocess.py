@@ -197,7 +197,60 @@ def multiclass_nms(boxes: np.ndarray, scores: np.ndarray,
     return out_b, out_s, out_c, nd
 
 
-def postprocess(box_enc: np.ndarray, cls_logits: np.ndarray, anchors_cs: np.ndarray, **kw):
+def multiclass_nms_global_order(boxes: np.ndarray, scores: np.ndarray,
+                                score_thr: float = SCORE_THRESHOLD, iou_thr: float = IOU_THRESHOLD,
+                                max_per_class: int = MAX_PER_CLASS, max_total: int = MAX_TOTAL
+                                ) -> Tuple[np.ndarray, np.ndarray, np.ndarray, int]:
+    """The same function as `multiclass_nms`, evaluated in ONE global descending-score order (a candidate's
+    fate depends only on higher-scored boxes of its own class, and only the first `max_total` survivors reach the output,
+    so the walk can stop there).  Used by bench.py's `cpu_baseline` leg so that the baseline is bounded by the network, not
+    by 90 Python loops; `tests/test_oracle_postprocess_fast.py` holds it equal to the literal version above, which stays
+    the checker of the GPU path.  Ties: (-score, class, anchor) == the literal version's concatenation + stable sort."""
+    n, c = scores.shape
+    clipped = clip_to_unit_window(boxes)
+    valid = area(clipped) > F32(0.0)
+    flat = np.where(valid[:, None], scores, F32(-1.0)).T.reshape(-1)          # [class][anchor]: index = class * n + anchor
+    cand = np.nonzero(flat > F32(score_thr))[0]
+    out_b = np.zeros((max_total, 4), np.float32)
+    out_s = np.zeros((max_total,), np.float32)
+    out_c = np.zeros((max_total,), np.float32)
+    if cand.size == 0:
+        return out_b, out_s, out_c, 0
+    thr = F32(iou_thr)
+    kept_boxes = np.zeros((c, max_per_class, 4), np.float32)
+    kept_n = np.zeros(c, np.int64)
+    # a class that has filled its quota takes no more candidates -- and its LATER (lower) survivors could never displace
+    # anything: the walk is over the candidates in order, in chunks so that the sort is not over all 172 k of them
+    def ordered(idx):
+        return idx[np.lexsort((idx, -flat[idx].astype(np.float64)))]          # (-score, class * n + anchor)
+
+    # the top of the order first (everything at or above the 4096th score, ties included); the rest only if the walk
+    # gets that far -- sorting all 172 k candidates would cost more than the walk
+    top_k = 4096
+    if cand.size > top_k:
+        cut = np.partition(flat[cand], cand.size - top_k)[cand.size - top_k]
+        parts = [cand[flat[cand] >= cut], cand[flat[cand] < cut]]
+    else:
+        parts = [cand]
+    nd = 0
+    for part in parts:
+        for i in ordered(part):
+            cls, a = divmod(int(i), n)
+            k = int(kept_n[cls])
+            if k >= max_per_class:
+                continue
+            if k and np.any(iou_many(clipped[a], kept_boxes[cls, :k]) > thr):
+                continue
+            kept_boxes[cls, k] = clipped[a]
+            kept_n[cls] = k + 1
+            out_b[nd], out_s[nd], out_c[nd] = clipped[a], flat[i], cls
+            nd += 1
+            if nd == max_total:
+                return out_b, out_s, out_c, nd
+    return out_b, out_s, out_c, nd
+
+
+def postprocess(box_enc: np.ndarray, cls_logits: np.ndarray, anchors_cs: np.ndarray, fast: bool = False, **kw):
     """One frame: raw head outputs -> (detection_boxes[100,4], scores[100], classes[100] 1-based, n).
 
     `classes` carries the exporter's label offset (+1) on *every* row including the zero padding,
@@ -205,5 +258,5 @@ def postprocess(box_enc: np.ndarray, cls_logits: np.ndarray, anchors_cs: np.ndar
     """
     boxes = decode_boxes(box_enc.astype(np.float32), anchors_cs)
     scores = sigmoid(cls_logits)[:, 1:]
-    b, s, c, nd = multiclass_nms(boxes, scores, **kw)
+    b, s, c, nd = (multiclass_nms_global_order if fast else multiclass_nms)(boxes, scores, **kw)
     return b, s, (c + F32(1.0)).astype(np.float32), nd
