@@ -238,7 +238,7 @@ def kernel_class_of(name):
     return base
 
 
-def live_pmc_traffic(timeout_s=150):
+def live_pmc_traffic(timeout_s=60):
     """HBM-side bytes per launch and kernel class, measured NOW: two `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE --
     they do not fit one pass, MI355X_MICROARCH.md) over a short single-lane run of this same file (`--pmc-child`).
     FETCH_SIZE is doubled as the guide prescribes for 16 B/lane reads on gfx950 (it tallies a 128-B request as 64 B);
