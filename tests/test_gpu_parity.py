@@ -443,23 +443,36 @@ def test_submit_host_equals_detect_batch(eng):
         eng.host_unregister(arena)
 
 
+def _engine_with(model_dir, **env):
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return make_engine(model_dir)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k)
+            else:
+                os.environ[k] = v
+
+
 @pytest.mark.parametrize("knob", ["WZ_HEAD_INLINE=1", "WZ_DEFER_HEADS=0", "WZ_FUSE_DECODE=0"])
 def test_grouped_head_launches_are_bit_identical_to_separate_ones(eng, model_dir, knob):
     """The launch-count work on the SSD heads must not change a bit: `WZ_HEAD_INLINE=1` moves the split-K reduction of the
     heads into the head convolutions (each tile's last K slice sums the slices itself, in the same order; measured slower,
     hence off by default), `WZ_DEFER_HEADS=0` runs every head and its split-K
     reduction as launches of their own (same split counts, same summation order), `WZ_FUSE_DECODE=0` keeps the box
-    decode in wz_k_decode instead of the grouped reduce (same arithmetic, compiled without contraction)."""
+    decode in wz_k_decode instead of the grouped reduce (same arithmetic, compiled without contraction).
+    The first two are variants of the 128 x 128 tile kernel's launches (`WZ_CONV_WIDE=0`; the wide tile kernel of the default
+    program cuts K into other slices, i.e. another fp32 summation order: see the test below)."""
     frames = [synthetic_frame(640, 480, 300 + i) for i in range(4)]
-    ref = [np.zeros(100, ROW_DTYPE) for _ in frames]
-    eng.detect_batch(frames, ref)
     name, value = knob.split("=")
-    os.environ[name] = value
+    narrow = name != "WZ_FUSE_DECODE"
+    base = _engine_with(model_dir, WZ_CONV_WIDE="0") if narrow else eng
+    other = _engine_with(model_dir, **({name: value, "WZ_CONV_WIDE": "0"} if narrow else {name: value}))
     try:
-        other = make_engine(model_dir)
-    finally:
-        os.environ.pop(name)
-    try:
+        ref = [np.zeros(100, ROW_DTYPE) for _ in frames]
+        base.detect_batch(frames, ref)
         got = [np.zeros(100, ROW_DTYPE) for _ in frames]
         other.detect_batch(frames, got)
         for a, b in zip(ref, got):
@@ -467,10 +480,43 @@ def test_grouped_head_launches_are_bit_identical_to_separate_ones(eng, model_dir
         one = [np.zeros(100, ROW_DTYPE)]                       # batch of 1: other split counts, other group shapes
         other.detect_batch(frames[:1], one)
         ref1 = [np.zeros(100, ROW_DTYPE)]
-        eng.detect_batch(frames[:1], ref1)
+        base.detect_batch(frames[:1], ref1)
         assert one[0].tobytes() == ref1[0].tobytes()
     finally:
         other.close()
+        if narrow:
+            base.close()
+
+
+@pytest.mark.parametrize("batch", [1, 3, 8])
+def test_wide_head_kernel_agrees_with_the_tile_kernel(model_dir, batch):
+    """The big SSD heads run on wz_k_conv_wide (128 pixels x 288 channels per workgroup, k_conv_wide.hip); `WZ_CONV_WIDE=0` gives
+    them back to wz_k_conv_rs.  Same products, other K slices (fp32 summation order): the head outputs agree to fp32 rounding of a
+    5 184- / 11 520-term sum, far inside the score tolerance, and the rows match."""
+    frames = [synthetic_frame(640, 480, 700 + i) for i in range(batch)]
+    wide = _engine_with(model_dir, WZ_CONV_WIDE="1")
+    narrow = _engine_with(model_dir, WZ_CONV_WIDE="0")
+    try:
+        x = np.stack([wide.stage_preprocess(f) for f in frames])
+        bw, lw = wide.stage_forward(x)
+        bn, ln = narrow.stage_forward(x)
+        assert np.isfinite(lw).all() and np.isfinite(bw).all()
+        assert np.abs(lw - ln).max() <= 2e-4 * max(1.0, np.abs(ln).max())
+        assert np.abs(bw - bn).max() <= 2e-4 * max(1.0, np.abs(bn).max())
+        assert np.abs(lw - ln).max() > 0 or batch == 0            # (they ARE different programs)
+        rw = [np.zeros(100, ROW_DTYPE) for _ in frames]
+        rn = [np.zeros(100, ROW_DTYPE) for _ in frames]
+        wide.detect_batch(frames, rw)
+        narrow.detect_batch(frames, rn)
+        for a, b in zip(rn, rw):
+            pairs, missing = pu.match_rows(b, {"label": a["label"], "confidence": a["confidence"],
+                                               "box": np.stack([a["x_min"], a["y_min"], a["x_max"], a["y_max"]], 1)},
+                                           min_score=0.1)
+            assert len(missing) <= 2, missing
+            assert max(abs(p[3]) for p in pairs) <= 1e-4
+    finally:
+        wide.close()
+        narrow.close()
 
 
 def test_limits_and_errors(model_dir):

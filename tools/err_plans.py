@@ -87,7 +87,7 @@ def hp(n, dw_in="u", out_last="h"):
     return plan
 
 
-for n in (10, 11, 12, 13, 14, 16):
+for n in range(2, 17):
     PLANS["hp%d" % n] = hp(n)
     PLANS["hp%dh" % n] = hp(n, dw_in="h")
     PLANS["hp%dx" % n] = hp(n, dw_in="x")

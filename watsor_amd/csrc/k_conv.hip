@@ -527,6 +527,7 @@ __global__ __launch_bounds__(256) void wz_k_splitk_reduce_group(const WzReduceGr
     const int n4s = a.n_pad >> 2;
     if (tid >= a.M * n4s) return;
     const int m = tid / n4s, n4 = (tid - m * n4s) * 4;
+    if (n4 >= a.cout) return;   // padding columns: nothing is stored for them (and the wide tile kernel does not write their partials)
     float4_t v = {0.f, 0.f, 0.f, 0.f};
     for (int z = 0; z < a.splitk; ++z) {
         const float4_t p = *reinterpret_cast<const float4_t*>(ws + ((size_t)z * a.M + m) * a.n_pad + n4);

@@ -63,6 +63,7 @@ struct WzConvArgs {
     // write-through, takes a ticket on the tile's counter, and the LAST arriver sums the slices in slice order (the order of
     // wz_k_splitk_reduce: bit-identical) and finishes the outputs -- no reduce launch behind the convolution.
     int32_t nt_base;            // tile kernel: first 16-channel tile this launch entry serves (a head split along N, see wz_conv_rs_group_add)
+    int32_t nt_live, nt_group;  // wide tile kernel (k_conv_wide.hip): 16-channel tiles that hold real columns / tiles per workgroup
     int32_t inline_reduce;
     int32_t fin_flags;          // bit 0: decode the boxes, bit 1: mark the NMS candidates (see WzHeadFinish)
     int32_t* tickets;           // one counter per output tile of this convolution, zero between launches
@@ -183,6 +184,12 @@ void wz_launch_conv_group(const WzConvGroup& g, hipStream_t s);
 bool wz_conv_rs_groupable(const WzConvArgs& a);
 int wz_conv_rs_group_add(WzConvGroup& g, const WzConvArgs& a);   // entries added (a head may be split along N), 0 = full
 void wz_launch_conv_rs_group(const WzConvGroup& g, hipStream_t s);
+// ... and the wide tile kernel (k_conv_wide.hip: 128 pixels x up to 320 channels per workgroup), which serves the big heads by default
+bool wz_conv_wide_applies(const WzConvArgs& a);
+void wz_conv_wide_shape(const WzConvArgs& a, int* tiles, int* steps);   // workgroup tiles and K steps (of 64 channels x one tap)
+int wz_choose_wide_T(const int* tiles, const int* steps, const long long* tile_bytes, int n, int cus);   // steps per K slice
+int wz_conv_wide_group_add(WzConvGroup& g, const WzConvArgs& a);         // a.splitk set by the caller; 0 = the group is full
+void wz_launch_conv_wide_group(const WzConvGroup& g, hipStream_t s);
 void wz_launch_splitk_reduce_group(const WzReduceGroup& g, hipStream_t s);
 int wz_choose_splitk(int M, int n_pad, int kchunks);
 bool wz_conv_use_lds(const WzConvArgs& a);               // the LDS-tiled kernel will serve this conv

@@ -46,7 +46,7 @@ int wz_set_error(int code, const char* fmt, ...) {
     } while (0)
 
 #define WZ_MAX_CAMS 256
-#define WZ_WS_BYTES (64ull << 20)
+#define WZ_WS_BYTES (256ull << 20)
 #define WZ_TICKETS 8192   // tile counters per lane: first half the tile-kernel heads, second half the small ones
 
 struct StageTimer {
@@ -77,6 +77,9 @@ struct wz_engine {
     bool post_self = true;     // WZ_POST_SELF=0: histogram + compaction kernels in front of the NMS kernel
     bool fuse_decode = true;   // WZ_FUSE_DECODE=0: keep wz_k_decode as its own launch
     bool defer_heads = true;   // the SSD heads' split-K reductions run as one launch after the last head (WZ_DEFER_HEADS=0: one each)
+    bool conv_wide = true;     // the big SSD heads on the wide tile kernel (k_conv_wide.hip); WZ_CONV_WIDE=0: on wz_k_conv_rs
+    int wide_T = 0;            // WZ_WIDE_T=n: K steps per slice of that kernel (0: chosen per launch by wz_choose_wide_T)
+    int num_cus = 256;         // compute units of the device (the wide head kernel sizes its K slices for one round over them)
     bool head_inline = false;  // WZ_HEAD_INLINE=1: ... or inside the head convolutions themselves, by each tile's last K slice.
                                // Bit-identical and one launch less, but measured SLOWER (profiles/r02l_*: heads 76 + 18 us against
                                // 33 + 7 + 10 us, 37.4 k against 41.5 k frames/s): the reduction of a tile then runs on ONE workgroup at
@@ -204,6 +207,34 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
     small.tickets = L.d_tickets ? L.d_tickets + WZ_TICKETS / 2 : nullptr;
     big.ticket_off = small.ticket_off = 0;
     int heads_in_groups = 0;                // entries of `heads` whose convolution sits in `big` or `small`
+    // The heads with a long K loop run on the wide tile kernel (k_conv_wide.hip), all in one launch; their K slices are chosen
+    // together, for the whole launch (one round over the CUs, slices of equal length), before the first one is enqueued.
+    WzConvGroup wide;
+    wide.n = 0;
+    wide.first[0] = 0;
+    wide.tickets = nullptr;
+    wide.ticket_off = 0;
+    int wide_T = 0;   // K steps per slice (0: no head goes there)
+    if (!f32 && e->conv_wide && e->use_splitk && e->defer_heads && !e->head_inline) {
+        int tiles[WZ_CONV_GROUP_MAX], steps[WZ_CONV_GROUP_MAX], cnt = 0;
+        long long tile_bytes[WZ_CONV_GROUP_MAX];
+        for (uint32_t i = 0; i < e->hdr.n_ops && cnt < WZ_CONV_GROUP_MAX; ++i) {
+            const WzOpDesc& op = e->ops[i];
+            if (op.kind == WZ_OP_STEM || op.kind == WZ_OP_DW || op.kind == WZ_OP_MBCONV) continue;
+            WzConvArgs a;
+            memset(&a, 0, sizeof(a));
+            a.M = n * op.hout * op.wout;
+            a.cin = op.cin; a.cout = op.cout; a.n_pad = op.n_pad; a.ksize = op.ksize; a.kc = op.kc;
+            a.out_mode = op.out_mode;
+            a.kchunks = op.ksize * op.ksize * op.kc;
+            a.zeros = e->d_zeros;
+            if (!wz_conv_wide_applies(a)) continue;
+            wz_conv_wide_shape(a, &tiles[cnt], &steps[cnt]);
+            tile_bytes[cnt] = 128ll * 4 * (((a.cout + 15) & ~15) / (((a.cout + 15) / 16 + 19) / 20));
+            ++cnt;
+        }
+        if (cnt > 0) wide_T = e->wide_T > 0 ? e->wide_T : wz_choose_wide_T(tiles, steps, tile_bytes, cnt, e->num_cus);
+    }
     int big_head[WZ_CONV_GROUP_MAX] = {0}, small_head[WZ_CONV_GROUP_MAX] = {0};   // ... and which entry
     for (uint32_t i = 0; i < e->hdr.n_ops; ++i) {
         const WzOpDesc& op = e->ops[i];
@@ -316,14 +347,24 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
             int sk = 1;
             if (e->use_splitk)
                 sk = wz_conv_use_lds(a) ? wz_choose_splitk_lds(a.M, a.n_pad, a.kchunks) : wz_choose_splitk(a.M, a.n_pad, a.kchunks);
+            bool to_wide = wide_T > 0 && wide.n < WZ_CONV_GROUP_MAX && wz_conv_wide_applies(a);
+            if (to_wide) {   // its partial sums always go through the grouped reduce, also with a single K slice
+                const int wsk = ((a.kchunks >> 1) + wide_T - 1) / wide_T;
+                if (heads.n < WZ_REDUCE_GROUP_MAX && ((((size_t)wsk * a.M * a.n_pad * 4) + 255) & ~(size_t)255) + (WZ_WS_BYTES >> 1) <= ws_top)
+                    sk = wsk;
+                else
+                    to_wide = false;
+            }
             const size_t slab = (((size_t)sk * a.M * a.n_pad * 4) + 255) & ~(size_t)255;
-            if (sk > 1 && e->defer_heads && op.out_mode != WZ_OUT_ACT && heads.n < WZ_REDUCE_GROUP_MAX &&
+            if ((sk > 1 || to_wide) && e->defer_heads && op.out_mode != WZ_OUT_ACT && heads.n < WZ_REDUCE_GROUP_MAX &&
                 slab + (WZ_WS_BYTES >> 1) <= ws_top) {   // keep at least half of the workspace for the other ops
                 ws_top -= slab;
                 float* const park = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(L.d_ws) + ws_top);
                 a.splitk = sk;
                 a.out = park;
-                if (small.n < WZ_CONV_GROUP_MAX && wz_conv_groupable(a)) {
+                if (to_wide) {
+                    wz_conv_wide_group_add(wide, a);
+                } else if (small.n < WZ_CONV_GROUP_MAX && wz_conv_groupable(a)) {
                     small_head[small.n] = heads.n;
                     wz_conv_group_add(small, a);   // launched with the other small heads after the last op
                     ++heads_in_groups;
@@ -382,6 +423,7 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
             a.fin = L.d_fin;
         }
     }
+    if (wide.n > 0) wz_launch_conv_wide_group(wide, s);
     if (big.n > 0) wz_launch_conv_rs_group(big, s);
     if (t) t->mark();
     if (small.n > 0) wz_launch_conv_group(small, s);
@@ -591,6 +633,13 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     e->post_self = !((env = getenv("WZ_POST_SELF")) && atoi(env) == 0);
     e->list_cands = !((env = getenv("WZ_LIST_CANDS")) && atoi(env) == 0);
     e->head_inline = (env = getenv("WZ_HEAD_INLINE")) && atoi(env) != 0;
+    e->conv_wide = !((env = getenv("WZ_CONV_WIDE")) && atoi(env) == 0);
+    e->wide_T = (env = getenv("WZ_WIDE_T")) ? atoi(env) : 0;
+    {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            e->num_cus = cus;
+    }
     if ((env = getenv("WZ_LANES")) && atoi(env) >= 1 && atoi(env) <= WZ_SLOTS) e->n_lanes = atoi(env);
 
 #define CK(expr)                                                                                        \
