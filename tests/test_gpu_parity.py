@@ -519,6 +519,28 @@ def test_wide_head_kernel_agrees_with_the_tile_kernel(model_dir, batch):
         narrow.close()
 
 
+@pytest.mark.parametrize("T", ["4", "5", "9", "200"])
+def test_wide_head_kernel_with_any_slice_length(model_dir, T):
+    """`WZ_WIDE_T` forces the K slice length of wz_k_conv_wide (normally chosen per launch by a cost model).  The kernel walks a
+    slice two steps at a time: an odd slice ends with a phantom step whose activations are zeros (T = 5, 9, and the odd
+    remainders that T = 4 leaves of BoxPredictor_0's 81 steps), a slice longer than K is the whole K loop in one workgroup per
+    tile (T = 200: no split at all, partial sums still go through the grouped reduce).  All of them are the same sums in
+    another order."""
+    frames = [synthetic_frame(640, 480, 900 + i) for i in range(2)]
+    ref = _engine_with(model_dir, WZ_CONV_WIDE="0")
+    other = _engine_with(model_dir, WZ_WIDE_T=T)
+    try:
+        x = np.stack([ref.stage_preprocess(f) for f in frames])
+        br, lr = ref.stage_forward(x)
+        bo, lo = other.stage_forward(x)
+        assert np.isfinite(lo).all() and np.isfinite(bo).all()
+        assert np.abs(lo - lr).max() <= 2e-4 * max(1.0, np.abs(lr).max())
+        assert np.abs(bo - br).max() <= 2e-4 * max(1.0, np.abs(br).max())
+    finally:
+        ref.close()
+        other.close()
+
+
 def test_limits_and_errors(model_dir):
     e = make_engine(model_dir, max_batch=2, max_width=640, max_height=480)
     try:
