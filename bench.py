@@ -418,6 +418,31 @@ def host_legs(engine_path, model_dir, device, host_frames):
             eng.host_unregister(arena)
     finally:
         eng.close()
+    # configs[3] / [4] put 1920x1080 cameras on a GPU: there the boundary is PCIe-bound (6.2 MB per RGB24 frame), and the
+    # decoder side of SURVEY 8(f)-3 -- NV12 frames, converted inside the resize kernel -- halves the bytes
+    from watsor_amd.runtime import FMT_NV12
+    from watsor_amd.synth import synthetic_frame
+    eng = HipEngine(engine_path, device, BATCH, 1920, 1080)
+    try:
+        big = [synthetic_frame(1920, 1080, 900 + i) for i in range(4)]
+        for name, fmt, shape in (("rgb24", None, (1080, 1920, 3)), ("nv12", FMT_NV12, (1620, 1920))):
+            arena = np.zeros((2 * BATCH,) + shape, np.uint8)
+            for i in range(2 * BATCH):   # (pixel values do not matter to the transfer; the NV12 planes are the RGB bytes re-cut)
+                arena[i] = big[i % 4].reshape(-1)[:arena[i].size].reshape(shape)
+            eng.host_register(arena)
+            try:
+                views = [[arena[b * BATCH + i] for i in range(BATCH)] for b in range(2)]
+                fmts = [fmt] * BATCH if fmt is not None else None
+                r = throughput(eng, lambda lane, s: eng.submit_host(lane, views[s % 2], formats=fmts), BATCH, steps=60)
+                r["bytes_per_frame"] = int(arena[0].size)
+                r["workload"] = ("1920x1080 %s frames in page-locked host memory, batch 8, H2D inside the step" % name.upper()
+                                 + ("" if fmt is None else " (colour conversion in the resize kernel; the decoder writes -pix_fmt nv12)"))
+                legs["host_frames_pinned_1080p_%s_b8" % name] = r
+            finally:
+                eng.sync()
+                eng.host_unregister(arena)
+    finally:
+        eng.close()
     # the plugin call the reference worker makes: one frame from (pageable) host memory, synchronous -- the time
     # `ObjectDetector._next_frame` feeds into `inference_time` (detector.py:107-109)
     with HipObjectDetector(model_dir, device, max_batch=1, max_width=WIDTH, max_height=HEIGHT) as det:

@@ -86,6 +86,22 @@ int wz_submit_device(wz_engine_t* e, int slot, int n, const uint8_t* const* d_rg
  * ride the lane's stream, so the H2D of one batch overlaps the kernels of the batches on the other lanes. */
 int wz_submit_host(wz_engine_t* e, int slot, int n, const uint8_t* const* rgb, const int* w,
                    const int* h, const int* cam);
+/* ---- other pixel formats (the decoder side).  The reference's decoders write rawvideo RGB24 because its schema
+ * says so (`watsor/config/schema.py:161`, `watsor/stream/ffmpeg.py:78-88` reads whatever the decoder writes into the
+ * FrameBuffer); a decoder told `-pix_fmt nv12` / `yuv420p` writes half the bytes, and the colour conversion ffmpeg would have
+ * done on the host happens in the resize kernel (8-bit BT.601 limited range, nearest chroma; csrc/k_preprocess.hip).
+ *   fmt[i]  WZ_FMT_* of frame i; fmt == NULL: all RGB24.  NV12 / I420 frames are w*h*3/2 bytes and need even w and h.
+ * The three calls are the ones above with that one argument more. */
+#define WZ_FMT_RGB24 0
+#define WZ_FMT_NV12 1   /* h x w luma, then h/2 x w/2 interleaved (U, V) */
+#define WZ_FMT_I420 2   /* h x w luma, then the h/2 x w/2 U plane, then the V plane (ffmpeg's yuv420p) */
+int wz_detect_batch_fmt(wz_engine_t* e, int n, const uint8_t* const* frames, const int* w, const int* h, const int* fmt,
+                        const int* cam, wz_detection_t* const* out, uint8_t* const* pass, float* ms);
+int wz_submit_device_fmt(wz_engine_t* e, int slot, int n, const uint8_t* const* d_frames, const int* w, const int* h,
+                         const int* fmt, const int* cam);
+int wz_submit_host_fmt(wz_engine_t* e, int slot, int n, const uint8_t* const* frames, const int* w, const int* h,
+                       const int* fmt, const int* cam);
+uint64_t wz_frame_bytes(int w, int h, int fmt);   /* bytes of one frame; 0 for a format / size the engine does not take */
 /* Page-lock / release a host range that frames are handed over from (the reference's FrameBuffer arenas,
  * watsor/stream/share.py:35-41): copies out of it become DMA transfers at PCIe rate. */
 int wz_host_register(wz_engine_t* e, void* ptr, uint64_t bytes);
@@ -195,6 +211,7 @@ int wz_dev_download(wz_engine_t* e, void* h_dst, const void* d_src, uint64_t byt
 /* resize + normalise of one frame -> half[size*size*4] (x,y,z,0 per pixel); when the input tensor is a pair
  * (wz_tensor_flags) half[size*size*8]: (x,y,z,0) hi then (x,y,z,0) lo per pixel */
 int wz_stage_preprocess(wz_engine_t* e, const uint8_t* rgb, int w, int h, uint16_t* out_half);
+int wz_stage_preprocess_fmt(wz_engine_t* e, const uint8_t* frame, int w, int h, int fmt, uint16_t* out_half);
 /* network only: half input [n][size][size][4] -> float box encodings [n][A][4], logits [n][A][C]
  * (a pair input tensor gets these halves as its hi parts and zeros as its lo parts) */
 int wz_stage_forward(wz_engine_t* e, int n, const uint16_t* in_half, float* box_enc, float* logits);

@@ -27,6 +27,9 @@ Pinning status (see DESIGN.md "Oracle"):
 * row fill / int truncation / struct ABI: pinned by `tensorflow_cpu.py:79-90` and the
   ctypes layout of `watsor/stream/share.py:11-32` (checked against the real structs
   when `/root/reference` is importable, tests/test_abi.py).
+* YUV 4:2:0 -> RGB24 in front of the resize (oracle/yuv.py; only for frames handed over as NV12 / I420, which the
+  reference itself never does -- `watsor/config/schema.py:161`): the formula is pinned by BT.601 known answers
+  (tests/test_yuv_oracle.py); **unpinned** against ffmpeg's swscale, which would do this conversion on the host.
 * confidence / area / mask filters: pinned by the known-answer tests of
   `watsor/test/test_filter.py:14-74` (tests/test_filters_oracle.py) and by fixtures
   generated from the reference's own `ConfidenceFilter` / `AreaFilter`

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libwatsor_hip.so")
 
 WZ_OK, WZ_EINVAL, WZ_ENOENT, WZ_EFORMAT, WZ_EHIP, WZ_ENODEV, WZ_ELIMIT = 0, -1, -2, -3, -4, -5, -6
 WZ_SLOTS = 8
+WZ_FMT_RGB24, WZ_FMT_NV12, WZ_FMT_I420 = 0, 1, 2
 WZ_NUM_LABELS = 91
 
 c_u8p = C.POINTER(C.c_uint8)
@@ -37,6 +38,11 @@ SIGNATURES = {
                                   C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), c_f32p]),
     "wz_submit_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), c_i32p, c_i32p, c_i32p]),
     "wz_submit_host": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), c_i32p, c_i32p, c_i32p]),
+    "wz_detect_batch_fmt": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), c_i32p, c_i32p, c_i32p, c_i32p,
+                                      C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), c_f32p]),
+    "wz_submit_device_fmt": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), c_i32p, c_i32p, c_i32p, c_i32p]),
+    "wz_submit_host_fmt": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), c_i32p, c_i32p, c_i32p, c_i32p]),
+    "wz_frame_bytes": (C.c_uint64, [C.c_int, C.c_int, C.c_int]),
     "wz_host_register": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "wz_host_unregister": (C.c_int, [C.c_void_p, C.c_void_p]),
     "wz_collect": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
@@ -80,6 +86,7 @@ SIGNATURES = {
     "wz_dev_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "wz_dev_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "wz_stage_preprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "wz_stage_preprocess_fmt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "wz_stage_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "wz_stage_read_tensor": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "wz_stage_postprocess": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

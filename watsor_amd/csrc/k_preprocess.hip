@@ -1,4 +1,4 @@
-// Resize + normalise: packed RGB24 frame of any resolution -> 300x300 fp16 network input.
+// Resize + normalise: a frame of any resolution (packed RGB24, or NV12 / I420) -> 300x300 fp16 network input.
 //
 // Stands in for the first nodes of the TF graph the reference's CPU plugin runs on the full
 // resolution frame (`watsor/detection/tensorflow_cpu.py:113-115`):
@@ -11,6 +11,43 @@
 // written (the 4th channel is zero padding so the stem conv reads one aligned 8-byte pixel).
 #pragma clang fp contract(off)
 #include "wz_common.h"
+
+// Pixel formats (WzFrameDesc::fmt; SURVEY 8f-3, the decoder side: `watsor/stream/ffmpeg.py:78-88` reads rawvideo frames
+// of whatever `-pix_fmt` the decoder was told to write).  RGB24 is what the reference's schema asks for
+// (`watsor/config/schema.py:161`); NV12 / I420 are what a video decoder produces natively and half the bytes per
+// frame on PCIe.  For those the RGB value of a source pixel is worked out here, where ffmpeg's swscale would have
+// done it on the host: 8-bit BT.601 limited range, the chroma sample of the pixel's 2x2 block (no chroma
+// interpolation), the usual 8.8 fixed-point form
+//     C = Y - 16, D = U - 128, E = V - 128
+//     R = clip8((298 C + 409 E + 128) >> 8),  G = clip8((298 C - 100 D - 208 E + 128) >> 8),  B = clip8((298 C + 516 D + 128) >> 8)
+// -- integer arithmetic, bit-exact against oracle/yuv.py; the bytes equal a host-side conversion by that formula, they
+// are NOT pinned against a particular swscale code path (its C and SIMD converters differ from each other by one LSB).
+__device__ __forceinline__ void wz_fetch_rgb(const WzFrameDesc& f, int x, int y, float (&c)[3]) {
+    if (f.fmt == WZ_FMT_RGB24) {
+        const uint8_t* p = f.rgb + ((size_t)y * f.w + x) * 3;
+        c[0] = (float)p[0];
+        c[1] = (float)p[1];
+        c[2] = (float)p[2];
+        return;
+    }
+    const int Y = f.rgb[(size_t)y * f.w + x];
+    const size_t cw = (size_t)(f.w >> 1);
+    const uint8_t* chroma = f.rgb + (size_t)f.w * f.h;
+    int U, V;
+    if (f.fmt == WZ_FMT_NV12) {
+        const uint8_t* uv = chroma + ((size_t)(y >> 1) * cw + (x >> 1)) * 2;
+        U = uv[0];
+        V = uv[1];
+    } else {   // I420: a U plane, then a V plane
+        const uint8_t* up = chroma + (size_t)(y >> 1) * cw + (x >> 1);
+        U = up[0];
+        V = up[cw * (size_t)(f.h >> 1)];
+    }
+    const int C = Y - 16, D = U - 128, E = V - 128;
+    c[0] = (float)min(max((298 * C + 409 * E + 128) >> 8, 0), 255);
+    c[1] = (float)min(max((298 * C - 100 * D - 208 * E + 128) >> 8, 0), 255);
+    c[2] = (float)min(max((298 * C + 516 * D + 128) >> 8, 0), 255);
+}
 
 // HP: the network input is stored as a hi + lo pair of halves per value (hi = RN16(v), lo = RN16(v - hi), both
 // roundings and the subtraction exact-or-once-rounded fp32 operations): the first blocks of the `-p 16` program take
@@ -34,13 +71,16 @@ __global__ __launch_bounds__(256) void wz_k_preprocess(const WzFrameDesc* __rest
     const int x_hi = min((int)ceilf(in_x), f.w - 1);
     const float lx = in_x - fl_x;
 
-    const uint8_t* r0 = f.rgb + (size_t)y_lo * f.w * 3;
-    const uint8_t* r1 = f.rgb + (size_t)y_hi * f.w * 3;
+    float tap[4][3];   // top-left, top-right, bottom-left, bottom-right
+    wz_fetch_rgb(f, x_lo, y_lo, tap[0]);
+    wz_fetch_rgb(f, x_hi, y_lo, tap[1]);
+    wz_fetch_rgb(f, x_lo, y_hi, tap[2]);
+    wz_fetch_rgb(f, x_hi, y_hi, tap[3]);
     half_t v[4], vl[4];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float tl = (float)r0[x_lo * 3 + c], tr = (float)r0[x_hi * 3 + c];
-        const float bl = (float)r1[x_lo * 3 + c], br = (float)r1[x_hi * 3 + c];
+        const float tl = tap[0][c], tr = tap[1][c];
+        const float bl = tap[2][c], br = tap[3][c];
         const float top = tl + (tr - tl) * lx;
         const float bot = bl + (br - bl) * lx;
         const float px = top + (bot - top) * ly;

@@ -29,11 +29,11 @@ __device__ __forceinline__ half4_t wz_relu6_pack(const float4_t d, const float4_
 
 // One frame handed to the pre-processing kernel.
 struct WzFrameDesc {
-    const uint8_t* rgb;   // packed RGB24, h x w x 3 (device)
+    const uint8_t* rgb;   // the frame (device): packed RGB24 h x w x 3, or NV12 / I420 (h x w luma, then the 2x2-subsampled chroma)
     int32_t w, h;
     float scale_x, scale_y;   // (float)w / (float)size, TF legacy ResizeBilinear scale
     int32_t cam;              // camera filter index or -1
-    int32_t _pad;
+    int32_t fmt;              // WZ_FMT_* (include/watsor_hip.h)
 };
 
 struct WzConvArgs {

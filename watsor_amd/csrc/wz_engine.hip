@@ -860,13 +860,23 @@ extern "C" const char* wz_device_name(wz_engine_t* e) { return e ? e->name.c_str
 // ------------------------------------------------------------------------------------------------
 // the hot call
 // ------------------------------------------------------------------------------------------------
+extern "C" uint64_t wz_frame_bytes(int w, int h, int fmt) {
+    if (w < 1 || h < 1) return 0;
+    if (fmt == WZ_FMT_RGB24) return (uint64_t)w * h * 3;
+    if ((fmt == WZ_FMT_NV12 || fmt == WZ_FMT_I420) && !(w & 1) && !(h & 1)) return (uint64_t)w * h * 3 / 2;
+    return 0;
+}
+
 static int fill_desc(wz_engine* e, int slot, int n, const uint8_t* const* d_rgb, const int* w, const int* h,
-                     const int* cam) {
+                     const int* fmt, const int* cam) {
     if (slot < 0 || slot >= e->n_lanes) return wz_fail(WZ_EINVAL, "slot %d out of range [0,%d)", slot, e->n_lanes);
     if (n < 1 || n > e->max_batch) return wz_fail(WZ_ELIMIT, "batch %d exceeds max_batch %d", n, e->max_batch);
     const float size = (float)e->hdr.input_size;
     for (int i = 0; i < n; ++i) {
         if (w[i] < 1 || h[i] < 1 || !d_rgb[i]) return wz_fail(WZ_EINVAL, "frame %d: bad pointer or size", i);
+        const int pf = fmt ? fmt[i] : WZ_FMT_RGB24;
+        if (!wz_frame_bytes(w[i], h[i], pf))
+            return wz_fail(WZ_EINVAL, "frame %d: pixel format %d at %dx%d (NV12 / I420 need even sides)", i, pf, w[i], h[i]);
         const int c = cam ? cam[i] : -1;
         if (c >= WZ_MAX_CAMS) return wz_fail(WZ_ELIMIT, "camera id %d >= %d", c, WZ_MAX_CAMS);
         if (c >= 0 && e->h_cams[c].enabled && (e->h_cams[c].width != w[i] || e->h_cams[c].height != h[i]))
@@ -879,20 +889,24 @@ static int fill_desc(wz_engine* e, int slot, int n, const uint8_t* const* d_rgb,
         d.scale_x = (float)w[i] / size;   // CalculateResizeScale(in, out, align_corners=false)
         d.scale_y = (float)h[i] / size;
         d.cam = c < 0 ? -1 : c;
-        d._pad = 0;
+        d.fmt = pf;
     }
     return WZ_OK;
 }
 
-extern "C" int wz_submit_device(wz_engine_t* e, int slot, int n, const uint8_t* const* d_rgb, const int* w,
-                                const int* h, const int* cam) {
+extern "C" int wz_submit_device_fmt(wz_engine_t* e, int slot, int n, const uint8_t* const* d_rgb, const int* w,
+                                    const int* h, const int* fmt, const int* cam) {
     if (!e || !d_rgb || !w || !h) return wz_fail(WZ_EINVAL, "wz_submit_device: null argument");
     if (slot < 0 || slot >= e->n_lanes) return wz_fail(WZ_EINVAL, "slot %d out of range [0,%d)", slot, e->n_lanes);
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipEventSynchronize(e->lanes[slot].done));   // the lane's previous batch has fully drained
-    int rc = fill_desc(e, slot, n, d_rgb, w, h, cam);
+    int rc = fill_desc(e, slot, n, d_rgb, w, h, fmt, cam);
     if (rc != WZ_OK) return rc;
     return run_batch(e, slot, n);
+}
+extern "C" int wz_submit_device(wz_engine_t* e, int slot, int n, const uint8_t* const* d_rgb, const int* w,
+                                const int* h, const int* cam) {
+    return wz_submit_device_fmt(e, slot, n, d_rgb, w, h, nullptr, cam);
 }
 
 extern "C" int wz_wait(wz_engine_t* e, int slot) {
@@ -927,6 +941,10 @@ extern "C" int wz_sync(wz_engine_t* e) {
 
 extern "C" int wz_detect_batch(wz_engine_t* e, int n, const uint8_t* const* rgb, const int* w, const int* h,
                                const int* cam, wz_detection_t* const* out, uint8_t* const* pass, float* ms) {
+    return wz_detect_batch_fmt(e, n, rgb, w, h, nullptr, cam, out, pass, ms);
+}
+extern "C" int wz_detect_batch_fmt(wz_engine_t* e, int n, const uint8_t* const* rgb, const int* w, const int* h, const int* fmt,
+                                   const int* cam, wz_detection_t* const* out, uint8_t* const* pass, float* ms) {
     if (!e || !rgb || !w || !h) return wz_fail(WZ_EINVAL, "wz_detect_batch: null argument");
     if (n < 1 || n > e->max_batch) return wz_fail(WZ_ELIMIT, "batch %d exceeds max_batch %d", n, e->max_batch);
     const auto t0 = std::chrono::steady_clock::now();
@@ -938,11 +956,13 @@ extern "C" int wz_detect_batch(wz_engine_t* e, int n, const uint8_t* const* rgb,
         if (w[i] > e->max_w || h[i] > e->max_h || (size_t)w[i] * h[i] * 3 > e->frame_stride)
             return wz_fail(WZ_ELIMIT, "frame %d is %dx%d, engine was created for at most %dx%d", i, w[i], h[i],
                            e->max_w, e->max_h);
+        const uint64_t bytes = wz_frame_bytes(w[i], h[i], fmt ? fmt[i] : WZ_FMT_RGB24);
+        if (!bytes) return wz_fail(WZ_EINVAL, "frame %d: pixel format %d at %dx%d (NV12 / I420 need even sides)", i, fmt[i], w[i], h[i]);
         uint8_t* dst = e->d_frames + e->frame_stride * i;
-        HIPCHK(hipMemcpyAsync(dst, rgb[i], (size_t)w[i] * h[i] * 3, hipMemcpyHostToDevice, e->lanes[0].stream));
+        HIPCHK(hipMemcpyAsync(dst, rgb[i], bytes, hipMemcpyHostToDevice, e->lanes[0].stream));
         dptr[i] = dst;
     }
-    int rc = wz_submit_device(e, 0, n, dptr.data(), w, h, cam);
+    int rc = wz_submit_device_fmt(e, 0, n, dptr.data(), w, h, fmt, cam);
     if (rc != WZ_OK) return rc;
     rc = wz_collect(e, 0, out, pass);
     if (rc != WZ_OK) return rc;
@@ -957,6 +977,10 @@ extern "C" int wz_detect_batch(wz_engine_t* e, int n, const uint8_t* const* rgb,
 // ------------------------------------------------------------------------------------------------
 extern "C" int wz_submit_host(wz_engine_t* e, int slot, int n, const uint8_t* const* rgb, const int* w, const int* h,
                               const int* cam) {
+    return wz_submit_host_fmt(e, slot, n, rgb, w, h, nullptr, cam);
+}
+extern "C" int wz_submit_host_fmt(wz_engine_t* e, int slot, int n, const uint8_t* const* rgb, const int* w, const int* h,
+                                  const int* fmt, const int* cam) {
     if (!e || !rgb || !w || !h) return wz_fail(WZ_EINVAL, "wz_submit_host: null argument");
     if (slot < 0 || slot >= e->n_lanes) return wz_fail(WZ_EINVAL, "slot %d out of range [0,%d)", slot, e->n_lanes);
     if (n < 1 || n > e->max_batch) return wz_fail(WZ_ELIMIT, "batch %d exceeds max_batch %d", n, e->max_batch);
@@ -970,12 +994,14 @@ extern "C" int wz_submit_host(wz_engine_t* e, int slot, int n, const uint8_t* co
         if (w[i] > e->max_w || h[i] > e->max_h || (size_t)w[i] * h[i] * 3 > e->frame_stride)
             return wz_fail(WZ_ELIMIT, "frame %d is %dx%d, engine was created for at most %dx%d", i, w[i], h[i],
                            e->max_w, e->max_h);
+        const uint64_t bytes = wz_frame_bytes(w[i], h[i], fmt ? fmt[i] : WZ_FMT_RGB24);
+        if (!bytes) return wz_fail(WZ_EINVAL, "frame %d: pixel format %d at %dx%d (NV12 / I420 need even sides)", i, fmt[i], w[i], h[i]);
         uint8_t* dst = L.d_frames + e->frame_stride * i;
         // pageable source: the runtime stages it (slow, synchronous); registered / pinned source: one DMA
-        HIPCHK(hipMemcpyAsync(dst, rgb[i], (size_t)w[i] * h[i] * 3, hipMemcpyHostToDevice, L.stream));
+        HIPCHK(hipMemcpyAsync(dst, rgb[i], bytes, hipMemcpyHostToDevice, L.stream));
         dptr[i] = dst;
     }
-    int rc = fill_desc(e, slot, n, dptr.data(), w, h, cam);
+    int rc = fill_desc(e, slot, n, dptr.data(), w, h, fmt, cam);
     if (rc != WZ_OK) return rc;
     return run_batch(e, slot, n);
 }
@@ -1157,7 +1183,7 @@ extern "C" int wz_profile_stages(wz_engine_t* e, int n, const uint8_t* const* d_
     if (!e || !stage_ms || reps < 1 || inner < 1 || inner > 64) return wz_fail(WZ_EINVAL, "wz_profile_stages: bad argument");
     HIPCHK(hipSetDevice(e->device));
     { int _rc = sync_all(e); if (_rc != WZ_OK) return _rc; }
-    int rc = fill_desc(e, 0, n, d_rgb, w, h, nullptr);
+    int rc = fill_desc(e, 0, n, d_rgb, w, h, nullptr, nullptr);
     if (rc != WZ_OK) return rc;
     const size_t ns = e->stage_names.size();
     std::vector<double> acc(ns, 0.0);
@@ -1213,13 +1239,18 @@ extern "C" int wz_dev_download(wz_engine_t* e, void* h_dst, const void* d_src, u
 // stage-level entry points (parity tests)
 // ------------------------------------------------------------------------------------------------
 extern "C" int wz_stage_preprocess(wz_engine_t* e, const uint8_t* rgb, int w, int h, uint16_t* out_half) {
+    return wz_stage_preprocess_fmt(e, rgb, w, h, WZ_FMT_RGB24, out_half);
+}
+extern "C" int wz_stage_preprocess_fmt(wz_engine_t* e, const uint8_t* rgb, int w, int h, int fmt, uint16_t* out_half) {
     if (!e || !rgb || !out_half) return wz_fail(WZ_EINVAL, "wz_stage_preprocess: null argument");
     if (w > e->max_w || h > e->max_h || (size_t)w * h * 3 > e->frame_stride) return wz_fail(WZ_ELIMIT, "frame too large");
+    const uint64_t bytes = wz_frame_bytes(w, h, fmt);
+    if (!bytes) return wz_fail(WZ_EINVAL, "pixel format %d at %dx%d (NV12 / I420 need even sides)", fmt, w, h);
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipStreamSynchronize(e->stream));
-    HIPCHK(hipMemcpy(e->d_frames, rgb, (size_t)w * h * 3, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->d_frames, rgb, bytes, hipMemcpyHostToDevice));
     const uint8_t* p = e->d_frames;
-    int rc = fill_desc(e, 0, 1, &p, &w, &h, nullptr);
+    int rc = fill_desc(e, 0, 1, &p, &w, &h, &fmt, nullptr);
     if (rc != WZ_OK) return rc;
     HIPCHK(hipMemcpyAsync(e->lanes[0].d_desc, e->lanes[0].h_desc, sizeof(WzFrameDesc), hipMemcpyHostToDevice, e->stream));
     const int S = (int)e->hdr.input_size;

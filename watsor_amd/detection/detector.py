@@ -272,7 +272,8 @@ def create_object_detectors(delegate_class, stop_event, log_queue, frame_queue, 
     Optional entries of `kwargs` (all consumed inside the detector processes):
       hip_cameras  {camera name: normalised camera config}  -> the camera's Confidence / Area / Mask filters run on the GPU
       hip_drop     True: rows failing those filters come back as all-zero rows (for `hip_detection_sieve()`)
-      hip_options  dict(max_batch=, max_width=, max_height=) overriding what is derived from the frame buffers
+      hip_options  dict(max_batch=, max_width=, max_height=) overriding what is derived from the frame buffers;
+                   pixel_format= "rgb24" | "nv12" | "yuv420p" (or {camera name: ...}): what the decoders write (hip_gpu.py)
       hip_lanes    batches kept in flight per GPU by the worker (default 2)"""
     _ref = _require_watsor()
     detectors = []

@@ -22,10 +22,34 @@ from typing import List, Optional, Sequence
 
 import numpy as np
 
-from ..runtime import HipEngine
+from ..runtime import FMT_I420, FMT_NV12, FMT_RGB24, HipEngine
 from ..share import Detection
 
+# what a decoder's `-pix_fmt` may say (watsor/stream/ffmpeg.py:78-88 reads whatever it writes; the reference's schema asks for
+# rgb24, `watsor/config/schema.py:161` -- NV12 / yuv420p frames are half the bytes and are converted on the GPU)
+PIXEL_FORMATS = {"rgb24": FMT_RGB24, "nv12": FMT_NV12, "yuv420p": FMT_I420, "i420": FMT_I420}
+
 ENGINE_FILE = "mi355x.bin"       # the analogue of gpu.trt (watsor/detection/detector.py:44)
+
+
+def pixel_format_code(name) -> int:
+    try:
+        return PIXEL_FORMATS[str(name).lower()]
+    except KeyError:
+        raise ValueError("pixel_format %r: expected one of %s" % (name, ", ".join(sorted(PIXEL_FORMATS)))) from None
+
+
+def frame_formats(frames: Sequence[np.ndarray], cameras: Optional[Sequence[int]], default: int, by_camera: dict):
+    """Pixel format of every frame of a call: the camera's configured one, else the detector's; a planar (2-D) array that would
+    be read as RGB24 takes the one YUV format that is configured (NV12 if none is).  None = all RGB24."""
+    yuv = next((f for f in [default] + list(by_camera.values()) if f != FMT_RGB24), FMT_NV12)
+    out = []
+    for i, f in enumerate(frames):
+        fmt = by_camera.get(cameras[i], default) if cameras is not None else default
+        if fmt == FMT_RGB24 and (f.ndim == 2 or (f.ndim == 3 and f.shape[2] == 1)):
+            fmt = yuv
+        out.append(fmt)
+    return out if any(f != FMT_RGB24 for f in out) else None
 
 
 class HipObjectDetector:
@@ -35,7 +59,10 @@ class HipObjectDetector:
                  max_width: Optional[int] = None, max_height: Optional[int] = None):
         """`options` (third positional argument, what `create_object_detectors` passes in `detector_args`):
         dict(max_batch=, max_width=, max_height=) -- the factory derives the frame size from the cameras' frame buffers;
-        the keyword forms and the WATSOR_HIP_MAX_* environment variables are the fallbacks."""
+        the keyword forms and the WATSOR_HIP_MAX_* environment variables are the fallbacks.
+        `options["pixel_format"]`: "rgb24" (default) | "nv12" | "yuv420p", or {camera name: one of these} -- what the cameras'
+        decoders write into their frame buffers.  An NV12 / yuv420p frame is handed over as the (H*3/2, W) uint8 array of its
+        bytes (that is its `image_shape`)."""
         engine_path = os.path.join(model_path, ENGINE_FILE)
         if not os.path.isfile(engine_path):
             raise FileNotFoundError(engine_path)
@@ -43,10 +70,17 @@ class HipObjectDetector:
         max_batch = max_batch or options.get("max_batch") or int(os.environ.get("WATSOR_HIP_MAX_BATCH", "8"))
         max_width = max_width or options.get("max_width") or int(os.environ.get("WATSOR_HIP_MAX_WIDTH", "1920"))
         max_height = max_height or options.get("max_height") or int(os.environ.get("WATSOR_HIP_MAX_HEIGHT", "1080"))
+        pf = options.get("pixel_format") or "rgb24"
+        self.__fmt_by_name = {str(k): pixel_format_code(v) for k, v in pf.items()} if isinstance(pf, dict) else {}
+        self.__fmt_default = FMT_RGB24 if isinstance(pf, dict) else pixel_format_code(pf)
+        self.__fmt_by_cam = {}
         self.__engine = HipEngine(engine_path, device, max_batch, max_width, max_height)
         self.__device = device
         self.__filters = []
         self.__pinned = []
+
+    def _formats(self, frames: Sequence[np.ndarray], cameras: Optional[Sequence[int]]):
+        return frame_formats(frames, cameras, self.__fmt_default, self.__fmt_by_cam)
 
     @property
     def engine(self) -> HipEngine:
@@ -88,6 +122,7 @@ class HipObjectDetector:
         Returns {camera name: id}."""
         from ..filter.hip_filter import HipCameraFilter
         ids = {name: i for i, name in enumerate(sorted(frame_buffers, key=str))}
+        self.__fmt_by_cam = {i: self.__fmt_by_name.get(str(name), self.__fmt_default) for name, i in ids.items()}
         for name, cfg in (camera_configs or {}).items():
             if name in ids:
                 self.__filters.append(HipCameraFilter(self.__engine, ids[name], cfg, drop=drop))
@@ -106,16 +141,17 @@ class HipObjectDetector:
 
     def submit_host(self, lane: int, images: Sequence[np.ndarray], cameras: Optional[Sequence[int]] = None) -> None:
         """Asynchronous `detect_batch`: the frames (views of shared memory, unchanged until `collect`) are enqueued on `lane`."""
-        self.__engine.submit_host(lane, images, cameras)
+        self.__engine.submit_host(lane, images, cameras, self._formats(images, cameras))
 
     def collect(self, lane: int, detections: Sequence) -> None:
         """Waits for `lane` and writes its rows into the given `Detection[100]` arrays (the frame headers)."""
         self.__engine.collect(lane, detections)
 
     def detect(self, image_shape, image_np, detections: List[Detection]):
-        return self.__engine.detect_batch([image_np.reshape(image_shape)], [detections])
+        frames = [image_np.reshape(image_shape)]
+        return self.__engine.detect_batch(frames, [detections], formats=self._formats(frames, None))
 
     def detect_batch(self, image_shapes: Sequence, images: Sequence[np.ndarray], detections: Sequence,
                      cameras: Optional[Sequence[int]] = None, passes: Optional[Sequence[np.ndarray]] = None):
         frames = [im.reshape(sh) for sh, im in zip(image_shapes, images)]
-        return self.__engine.detect_batch(frames, detections, cameras, passes)
+        return self.__engine.detect_batch(frames, detections, cameras, passes, self._formats(frames, cameras))

@@ -17,6 +17,7 @@ from .share import Detection, DetectionArray, MAX_DETECTIONS
 ROW_DTYPE = np.dtype([("label", "<i4"), ("zones", "<i4", (10,)), ("_pad", "<i4"), ("confidence", "<f8"),
                       ("x_min", "<i4"), ("y_min", "<i4"), ("x_max", "<i4"), ("y_max", "<i4")])
 assert ROW_DTYPE.itemsize == C.sizeof(Detection) == 72
+FMT_RGB24, FMT_NV12, FMT_I420 = _lib.WZ_FMT_RGB24, _lib.WZ_FMT_NV12, _lib.WZ_FMT_I420   # pixel formats of a frame (include/watsor_hip.h)
 
 
 def device_count() -> int:
@@ -79,10 +80,30 @@ class HipEngine:
             return obj
         return C.addressof(obj)
 
+    @staticmethod
+    def frame_geometry(f: np.ndarray, fmt: int = FMT_RGB24):
+        """(width, height) of a frame array: (H,W,3) uint8 for RGB24; for NV12 / I420 the usual planar view (H*3/2, W) [or (H*3/2, W, 1)] uint8
+        -- H rows of luma, then H/2 rows holding the subsampled chroma (the bytes a decoder writes with `-pix_fmt nv12` /
+        `yuv420p`).  Raises ValueError for anything else."""
+        if f.dtype != np.uint8:
+            raise ValueError("frames are uint8 arrays")
+        if fmt == FMT_RGB24:
+            if f.ndim != 3 or f.shape[2] != 3:
+                raise ValueError("an RGB24 frame must be (H,W,3) uint8")
+            return f.shape[1], f.shape[0]
+        if fmt in (FMT_NV12, FMT_I420):
+            if f.ndim == 3 and f.shape[2] == 1:      # (H*3/2, W, 1): a one-"channel" frame buffer of the reference (share.py:37-40)
+                f = f[:, :, 0]
+            if f.ndim != 2 or f.shape[0] % 3 or (f.shape[0] // 3 * 2) % 2 or f.shape[1] % 2:
+                raise ValueError("an NV12 / I420 frame must be (H*3/2, W) uint8 with even H and W")
+            return f.shape[1], f.shape[0] // 3 * 2
+        raise ValueError("unknown pixel format %r" % (fmt,))
+
     def detect_batch(self, frames: Sequence[np.ndarray], out_rows: Sequence, cams: Optional[Sequence[int]] = None,
-                     out_pass: Optional[Sequence[np.ndarray]] = None) -> float:
-        """frames: (H,W,3) uint8 C-contiguous arrays (host); out_rows[i]: ctypes Detection[100] (or a
-        ROW_DTYPE array of 100) written in place.  Returns the batch wall time in ms."""
+                     out_pass: Optional[Sequence[np.ndarray]] = None, formats: Optional[Sequence[int]] = None) -> float:
+        """frames: (H,W,3) uint8 C-contiguous arrays (host) -- or, with `formats[i]` = FMT_NV12 / FMT_I420, (H*3/2, W) planar
+        views; out_rows[i]: ctypes Detection[100] (or a ROW_DTYPE array of 100) written in place.  Returns the batch wall
+        time in ms."""
         n = len(frames)
         ptrs = (C.c_void_p * n)()
         ws = (C.c_int32 * n)()
@@ -90,14 +111,16 @@ class HipEngine:
         outs = (C.c_void_p * n)()
         keep = []
         for i, f in enumerate(frames):
-            if f.dtype != np.uint8 or f.ndim != 3 or f.shape[2] != 3:
-                raise ValueError("frame %d must be (H,W,3) uint8" % i)
+            try:
+                ws[i], hs[i] = self.frame_geometry(f, formats[i] if formats is not None else FMT_RGB24)
+            except ValueError as exc:
+                raise ValueError("frame %d: %s" % (i, exc)) from None
             if not f.flags["C_CONTIGUOUS"]:
                 f = np.ascontiguousarray(f)
             keep.append(f)
             ptrs[i] = f.ctypes.data
-            hs[i], ws[i] = f.shape[0], f.shape[1]
             outs[i] = self._addr(out_rows[i])
+        fmtv = (C.c_int32 * n)(*[int(x) for x in formats]) if formats is not None else None
         camv = None
         if cams is not None:
             camv = (C.c_int32 * n)(*[int(c) for c in cams])
@@ -105,30 +128,37 @@ class HipEngine:
         if out_pass is not None:
             passv = (C.c_void_p * n)(*[p.ctypes.data for p in out_pass])
         ms = (C.c_float * n)()
-        _lib.check(self._lib.wz_detect_batch(self._h, n, ptrs, ws, hs, camv, outs, passv, ms))
+        _lib.check(self._lib.wz_detect_batch_fmt(self._h, n, ptrs, ws, hs, fmtv, camv, outs, passv, ms))
         return float(ms[0])
 
     def submit_device(self, slot: int, d_frames: Sequence[int], widths: Sequence[int], heights: Sequence[int],
-                      cams: Optional[Sequence[int]] = None) -> None:
+                      cams: Optional[Sequence[int]] = None, formats: Optional[Sequence[int]] = None) -> None:
         n = len(d_frames)
         ptrs = (C.c_void_p * n)(*d_frames)
         ws = (C.c_int32 * n)(*widths)
         hs = (C.c_int32 * n)(*heights)
         camv = (C.c_int32 * n)(*cams) if cams is not None else None
-        _lib.check(self._lib.wz_submit_device(self._h, slot, n, ptrs, ws, hs, camv))
+        fmtv = (C.c_int32 * n)(*[int(x) for x in formats]) if formats is not None else None
+        _lib.check(self._lib.wz_submit_device_fmt(self._h, slot, n, ptrs, ws, hs, fmtv, camv))
 
-    def submit_host(self, slot: int, frames: Sequence[np.ndarray], cams: Optional[Sequence[int]] = None) -> None:
-        """Asynchronous detect of host frames ((H,W,3) uint8, C-contiguous) on lane `slot`; collect with
-        `collect()` / `slot_rows()`.  The arrays must stay alive and unchanged until the slot is collected."""
+    def submit_host(self, slot: int, frames: Sequence[np.ndarray], cams: Optional[Sequence[int]] = None,
+                    formats: Optional[Sequence[int]] = None) -> None:
+        """Asynchronous detect of host frames ((H,W,3) uint8, C-contiguous; NV12 / I420: see `frame_geometry`) on lane
+        `slot`; collect with `collect()` / `slot_rows()`.  The arrays must stay alive and unchanged until the slot is collected."""
         n = len(frames)
+        ws = (C.c_int32 * n)()
+        hs = (C.c_int32 * n)()
         for i, f in enumerate(frames):
-            if f.dtype != np.uint8 or f.ndim != 3 or f.shape[2] != 3 or not f.flags["C_CONTIGUOUS"]:
-                raise ValueError("frame %d must be a C-contiguous (H,W,3) uint8 array (it is read in place, asynchronously)" % i)
+            try:
+                ws[i], hs[i] = self.frame_geometry(f, formats[i] if formats is not None else FMT_RGB24)
+            except ValueError as exc:
+                raise ValueError("frame %d: %s" % (i, exc)) from None
+            if not f.flags["C_CONTIGUOUS"]:
+                raise ValueError("frame %d must be C-contiguous (it is read in place, asynchronously)" % i)
         ptrs = (C.c_void_p * n)(*[f.ctypes.data for f in frames])
-        ws = (C.c_int32 * n)(*[f.shape[1] for f in frames])
-        hs = (C.c_int32 * n)(*[f.shape[0] for f in frames])
         camv = (C.c_int32 * n)(*cams) if cams is not None else None
-        _lib.check(self._lib.wz_submit_host(self._h, slot, n, ptrs, ws, hs, camv))
+        fmtv = (C.c_int32 * n)(*[int(x) for x in formats]) if formats is not None else None
+        _lib.check(self._lib.wz_submit_host_fmt(self._h, slot, n, ptrs, ws, hs, fmtv, camv))
 
     def host_register(self, arr: np.ndarray) -> None:
         """Page-lock the memory behind `arr` (frames handed over from it then travel by DMA)."""
@@ -255,13 +285,14 @@ class HipEngine:
     def tensor_is_pair(self, idx: int) -> bool:
         return bool(self._lib.wz_tensor_flags(self._h, idx) & 1)
 
-    def stage_preprocess(self, frame: np.ndarray) -> np.ndarray:
+    def stage_preprocess(self, frame: np.ndarray, fmt: int = FMT_RGB24) -> np.ndarray:
         """(S,S,4) float16; for a pair input tensor (S,S,8): hi (r,g,b,0) then lo (r,g,b,0)."""
         frame = np.ascontiguousarray(frame, np.uint8)
+        w, h = self.frame_geometry(frame, fmt)
         S = self.input_size
         out = np.empty((S, S, 8 if self.tensor_is_pair(0) else 4), np.float16)
-        _lib.check(self._lib.wz_stage_preprocess(self._h, C.c_void_p(frame.ctypes.data), frame.shape[1],
-                                                 frame.shape[0], C.c_void_p(out.ctypes.data)))
+        _lib.check(self._lib.wz_stage_preprocess_fmt(self._h, C.c_void_p(frame.ctypes.data), w, h, int(fmt),
+                                                     C.c_void_p(out.ctypes.data)))
         return out
 
     def stage_forward(self, x_half: np.ndarray):
