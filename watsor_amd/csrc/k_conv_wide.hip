@@ -350,7 +350,11 @@ __global__ __launch_bounds__(256, 1) void wz_k_conv_wide_group(const WzConvGroup
 // 3x3 heads with a K loop worth tiling (the conditions of the LDS-tiled kernels); the engine's WZ_CONV_WIDE=0 gives them back to
 // wz_k_conv_rs
 bool wz_conv_wide_applies(const WzConvArgs& a) {
-    return a.ksize == 3 && a.out_mode != WZ_OUT_ACT && wz_conv_use_lds(a);
+    // whole 64-column tiles in the packed weights, whole 2-chunk K steps, 32-channel chunks.  Any number of pixels: the small
+    // heads (3x3 ... 1x1 maps) fill little of a 128-pixel tile, but what they cost is the walk over K = 9 x cin, and that is cut
+    // into slices here like everybody else's (measured: wz_k_conv_group took 18.7 us for them at batch 1, 7 us at batch 8)
+    return a.ksize == 3 && a.out_mode != WZ_OUT_ACT && a.zeros && a.n_pad % 64 == 0 && a.kc % 2 == 0 && a.cin % 32 == 0 &&
+           a.kchunks >= 16;
 }
 
 void wz_conv_wide_shape(const WzConvArgs& a, int* tiles, int* steps) {

@@ -78,6 +78,7 @@ struct wz_engine {
     bool fuse_decode = true;   // WZ_FUSE_DECODE=0: keep wz_k_decode as its own launch
     bool defer_heads = true;   // the SSD heads' split-K reductions run as one launch after the last head (WZ_DEFER_HEADS=0: one each)
     bool conv_wide = true;     // the big SSD heads on the wide tile kernel (k_conv_wide.hip); WZ_CONV_WIDE=0: on wz_k_conv_rs
+    int wide_min_m = 1;        // WZ_WIDE_MIN_M=n: heads with fewer output pixels than this (per batch) stay on wz_k_conv_group
     int wide_T = 0;            // WZ_WIDE_T=n: K steps per slice of that kernel (0: chosen per launch by wz_choose_wide_T)
     int num_cus = 256;         // compute units of the device (the wide head kernel sizes its K slices for one round over them)
     bool head_inline = false;  // WZ_HEAD_INLINE=1: ... or inside the head convolutions themselves, by each tile's last K slice.
@@ -228,7 +229,7 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
             a.out_mode = op.out_mode;
             a.kchunks = op.ksize * op.ksize * op.kc;
             a.zeros = e->d_zeros;
-            if (!wz_conv_wide_applies(a)) continue;
+            if (!wz_conv_wide_applies(a) || a.M < e->wide_min_m) continue;
             wz_conv_wide_shape(a, &tiles[cnt], &steps[cnt]);
             tile_bytes[cnt] = 128ll * 4 * (((a.cout + 15) & ~15) / (((a.cout + 15) / 16 + 19) / 20));
             ++cnt;
@@ -347,7 +348,7 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
             int sk = 1;
             if (e->use_splitk)
                 sk = wz_conv_use_lds(a) ? wz_choose_splitk_lds(a.M, a.n_pad, a.kchunks) : wz_choose_splitk(a.M, a.n_pad, a.kchunks);
-            bool to_wide = wide_T > 0 && wide.n < WZ_CONV_GROUP_MAX && wz_conv_wide_applies(a);
+            bool to_wide = wide_T > 0 && wide.n < WZ_CONV_GROUP_MAX && wz_conv_wide_applies(a) && a.M >= e->wide_min_m;
             if (to_wide) {   // its partial sums always go through the grouped reduce, also with a single K slice
                 const int wsk = ((a.kchunks >> 1) + wide_T - 1) / wide_T;
                 if (heads.n < WZ_REDUCE_GROUP_MAX && ((((size_t)wsk * a.M * a.n_pad * 4) + 255) & ~(size_t)255) + (WZ_WS_BYTES >> 1) <= ws_top)
@@ -635,6 +636,7 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     e->head_inline = (env = getenv("WZ_HEAD_INLINE")) && atoi(env) != 0;
     e->conv_wide = !((env = getenv("WZ_CONV_WIDE")) && atoi(env) == 0);
     e->wide_T = (env = getenv("WZ_WIDE_T")) ? atoi(env) : 0;
+    e->wide_min_m = (env = getenv("WZ_WIDE_MIN_M")) ? atoi(env) : 1;
     {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
