@@ -32,6 +32,12 @@ typedef __attribute__((ext_vector_type(4))) unsigned int wz_u32x4_t;
 typedef __attribute__((ext_vector_type(2))) unsigned int wz_u32x2_t;
 
 #define HP_CS_WAVES 8
+#ifndef WZ_HP_STAMPS
+#define WZ_HP_STAMPS 0   // 1: cycle counts of the first workgroup's wave 0 into WzMbArgs::dbg (tools/hp_probe.py)
+#endif
+#ifndef WZ_HP_STAMP_LAST
+#define WZ_HP_STAMP_LAST 0   // 1: ... of the LAST workgroup instead (one that starts on a CU another workgroup has run on)
+#endif
 
 __device__ __forceinline__ void wz_hp_split(const float v[8], half8_t& hi, half8_t& lo) {
 #pragma unroll
@@ -70,6 +76,7 @@ __device__ __forceinline__ void wz_hp_fma8(wz_f32x2_t d[4], const wz_f32x2_t x[4
 template <int NW, bool CS, bool STEM, int MPW, int MQW, int KCI, int NTO, int OCC = 2, bool ONEPASS = false>
 __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wz_hp_smem[];
+    const long long t_entry = WZ_HP_STAMPS ? __builtin_readcyclecounter() : 0;
     constexpr bool LDSW = CS || OCC > 2;                 // depthwise weights staged in LDS (else: registers, from L2)
     constexpr bool PRE = OCC <= 2;                       // all taps of an output requested before the first is used
     constexpr int ES = 40;                               // unorm16 per row of the chunk buffer: 32 channels + 8 of padding
@@ -86,18 +93,15 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
     // are used (broadcast reads); !CS: they come from L2 into registers at the top of a pass (LDS is the busy unit there)
     float* const wd_l = be_l + a.cmid_pad;                               // CS only: [9][cmid_pad]
 
-    if constexpr (LDSW)
-        for (int i = threadIdx.x; i < 9 * (a.cmid_pad >> 2); i += NW * 64)
-            *reinterpret_cast<float4_t*>(wd_l + i * 4) = *reinterpret_cast<const float4_t*>(wd32 + (size_t)i * 4);
-    for (int i = threadIdx.x; i < (a.cmid_pad >> 2); i += NW * 64) {
-        *reinterpret_cast<float4_t*>(bd_l + i * 4) = *reinterpret_cast<const float4_t*>(a.bd + i * 4);
-        *reinterpret_cast<float4_t*>(be_l + i * 4) = (i * 4 < a.nmid_pad) ? *reinterpret_cast<const float4_t*>(a.be + i * 4)
-                                                                          : (float4_t){0.f, 0.f, 0.f, 0.f};
-    }
+    // Order of the prologue: what has to travel furthest goes first.  The halo pixels and the first expand fragments are requested
+    // (into registers) before the biases and depthwise weights are staged into LDS, whose loads are all issued before the first
+    // of them is stored -- in-kernel stamps (tools/hp_probe.py, profiles/r02zp_*) had the old order (staging loop by loop, then
+    // the index arithmetic with its integer divisions, then the halo) at 4 000 .. 9 500 cycles before the last load was even
+    // issued, 30 .. 40 % of a 19x19 block's launch.
 
-    // ---- the tile of this wave (CS: of this workgroup)
+    // ---- the tile of this wave (CS: of this workgroup); wave-uniform, kept in scalar registers
     const int tiles = a.tiles_x * a.tiles_y;
-    const int wt = CS ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
+    const int wt = CS ? (int)blockIdx.x : (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave);
     const bool live = wt < tiles * a.nb;                  // wave-uniform; dead waves still take the barrier below
     const int wtc = live ? wt : 0;
     const int b = wtc / tiles, t = wtc - b * tiles;
@@ -128,10 +132,11 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
     // ---- halo pixels of this lane: input channels as B fragments, hi and lo
     half8_t xh[MPW][KCI], xl[MPW][KCI];
     bool inimg[MPW];
+    const float rcp_hw = 1.0f / (float)hw_;   // p < 96, hw_ <= 10: floor((p + 0.5) / hw_) is exact in fp32 (no integer division)
 #pragma unroll
     for (int i = 0; i < MPW; ++i) {
         const int p = i * 16 + r16;
-        const int hy = p / hw_, hx = p - hy * hw_;
+        const int hy = (int)(((float)p + 0.5f) * rcp_hw), hx = p - hy * hw_;
         const int iy = iy_base + hy, ix = ix_base + hx;
         const bool ok = live && p < P && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
         inimg[i] = ok;
@@ -195,8 +200,42 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
         }
     };
     if (ps0 < nk32) load_wa(ps0);
+    {   // biases (and, LDSW, depthwise weights) into LDS: every load of a thread in flight before its first store
+        constexpr int NT = NW * 64;
+        constexpr int WD_IT = 3;   // 9 * cmid_pad / 4 float4s over NT threads: at most 3 each (checked by the launcher)
+        const int nb4 = a.cmid_pad >> 2;
+        float4_t sw[WD_IT], sb, se;
+        if constexpr (LDSW) {
+#pragma unroll
+            for (int k = 0; k < WD_IT; ++k) {
+                const int i = (int)threadIdx.x + k * NT;
+                sw[k] = i < 9 * nb4 ? *reinterpret_cast<const float4_t*>(wd32 + (size_t)i * 4) : (float4_t){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        const int ib = (int)threadIdx.x;   // nb4 <= NT: one float4 of each bias per thread
+        const bool hb = ib < nb4;
+        sb = hb ? *reinterpret_cast<const float4_t*>(a.bd + ib * 4) : (float4_t){0.f, 0.f, 0.f, 0.f};
+        se = (hb && ib * 4 < a.nmid_pad) ? *reinterpret_cast<const float4_t*>(a.be + ib * 4) : (float4_t){0.f, 0.f, 0.f, 0.f};
+        if constexpr (LDSW) {
+#pragma unroll
+            for (int k = 0; k < WD_IT; ++k) {
+                const int i = (int)threadIdx.x + k * NT;
+                if (i < 9 * nb4) *reinterpret_cast<float4_t*>(wd_l + i * 4) = sw[k];
+            }
+        }
+        if (hb) {
+            *reinterpret_cast<float4_t*>(bd_l + ib * 4) = sb;
+            *reinterpret_cast<float4_t*>(be_l + ib * 4) = se;
+        }
+    }
+    const long long t_issued = WZ_HP_STAMPS ? __builtin_readcyclecounter() : 0;
     __syncthreads();   // staged biases visible; the only workgroup barrier in front of the loop
     if (!CS && !live) return;
+    long long t_loop = 0, t_first = 0;
+    if (WZ_HP_STAMPS) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (stamped build only: the halo and the first weights have landed)
+        t_loop = __builtin_readcyclecounter();
+    }
 
     for (int ps = ps0; ps < nk32; ps += STEP) {
         const int ce0 = ps * 32;
@@ -349,24 +388,37 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
 #pragma unroll
             for (int nt = 0; nt < NTO; ++nt) acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wph[nt], bh, acc[j][nt], 0, 0, 0);
         }
+        if (WZ_HP_STAMPS && ps == ps0) t_first = __builtin_readcyclecounter();
         if constexpr (ONEPASS) break;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();   // (the next pass's E stores stay behind these reads)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    const long long t_chunks = WZ_HP_STAMPS ? __builtin_readcyclecounter() : 0;
 
-    // ---- epilogue: + bias, + residual (a pair tensor like the input), store as a pair or as one half
+    // ---- epilogue: + bias, + residual (a pair tensor like the input), store as a pair or as one half.  The bias and residual of
+    // every output of a lane are requested before the first one is used (one memory latency, not one per output tile: the
+    // residual blocks' epilogue took 5 500 cycles against 2 000 without a residual, profiles/r02zp_*).
     const int ostride = a.hp_out ? 2 * a.cout : a.cout;
-    auto finish = [&](float4_t v, int op, int n4) {
-        const float4_t bv = *reinterpret_cast<const float4_t*>(a.bp + n4);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += bv[r];
+    struct Side { float4_t bias; half4_t rh, rl; };
+    auto side = [&](int op, int n4) {
+        Side sd;
+        sd.bias = *reinterpret_cast<const float4_t*>(a.bp + n4);
         if (a.res) {
             const half_t* rp = a.res + (size_t)op * (2 * a.cout) + n4;
-            const half4_t rh = *reinterpret_cast<const half4_t*>(rp);
-            const half4_t rl = *reinterpret_cast<const half4_t*>(rp + a.cout);
+            sd.rh = *reinterpret_cast<const half4_t*>(rp);
+            sd.rl = *reinterpret_cast<const half4_t*>(rp + a.cout);
+        } else {
+            sd.rh = sd.rl = (half4_t){0, 0, 0, 0};
+        }
+        return sd;
+    };
+    auto finish = [&](float4_t v, const Side& sd, int op, int n4) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += (float)rh[r] + (float)rl[r];
+        for (int r = 0; r < 4; ++r) v[r] += sd.bias[r];
+        if (a.res) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (float)sd.rh[r] + (float)sd.rl[r];
         }
         half4_t oh, ol;
 #pragma unroll
@@ -380,6 +432,15 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
     };
 
     if constexpr (!CS) {
+        Side sd[MQW][NTO];
+#pragma unroll
+        for (int j = 0; j < MQW; ++j)
+#pragma unroll
+            for (int nt = 0; nt < NTO; ++nt) {
+                const int n4 = nt * 16 + g * 4;
+                const bool on = opix[j] >= 0 && n4 < a.cout;
+                sd[j][nt] = side(on ? opix[j] : 0, on ? n4 : 0);   // (an unused slot reads output 0: valid memory, result dropped)
+            }
 #pragma unroll
         for (int j = 0; j < MQW; ++j) {
             if (opix[j] < 0) continue;
@@ -387,12 +448,29 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
             for (int nt = 0; nt < NTO; ++nt) {
                 const int n4 = nt * 16 + g * 4;
                 if (n4 >= a.cout) continue;
-                finish(acc[j][nt], opix[j], n4);
+                finish(acc[j][nt], sd[j][nt], opix[j], n4);
             }
         }
     } else {
         // the 8 waves' accumulators meet in LDS (over the chunk buffers); tile (j, nt) is summed by wave
         // (j*NTO + nt) % 8 in the order wave 0 .. 7 (deterministic)
+        constexpr int PER = (MQW * NTO + NW - 1) / NW;   // tiles a wave finishes
+        Side sd[PER];
+        int sop[PER], sn4[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {   // their bias and residual: on their way while the accumulators cross LDS
+            const int pr = wave + k * NW;
+            const int j = pr / NTO, nt = pr - j * NTO;
+            int op = -1;
+#pragma unroll
+            for (int jj = 0; jj < MQW; ++jj)
+                if (jj == j) op = opix[jj];
+            const int n4 = nt * 16 + g * 4;
+            const bool on = pr < MQW * NTO && op >= 0 && n4 < a.cout;
+            sop[k] = on ? op : -1;
+            sn4[k] = n4;
+            sd[k] = side(on ? op : 0, on ? n4 : 0);
+        }
         float* const red = reinterpret_cast<float*>(wz_hp_smem);
         __syncthreads();   // every wave is done with its chunk buffer
 #pragma unroll
@@ -401,7 +479,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
             for (int nt = 0; nt < NTO; ++nt)
                 *reinterpret_cast<float4_t*>(red + ((size_t)((wave * MQW + j) * NTO + nt) * 64 + lane) * 4) = acc[j][nt];
         __syncthreads();
-        for (int pr = wave; pr < MQW * NTO; pr += NW) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int pr = wave + k * NW;
+            if (pr >= MQW * NTO) break;
             const int j = pr / NTO, nt = pr - j * NTO;
             float4_t v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -410,14 +491,19 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] += pz[r];
             }
-            int op = -1;
-#pragma unroll
-            for (int jj = 0; jj < MQW; ++jj)
-                if (jj == j) op = opix[jj];
-            const int n4 = nt * 16 + g * 4;
-            if (op < 0 || n4 >= a.cout) continue;
-            finish(v, op, n4);
+            if (sop[k] < 0) continue;
+            finish(v, sd[k], sop[k], sn4[k]);
         }
+    }
+    if (WZ_HP_STAMPS && a.dbg && blockIdx.x == (WZ_HP_STAMP_LAST ? gridDim.x - 1 : 0) && threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const long long t_end = __builtin_readcyclecounter();
+        a.dbg[0] = (unsigned long long)(t_issued - t_entry);   // index math, staging loops, halo + weight loads issued
+        a.dbg[1] = (unsigned long long)(t_loop - t_issued);    // ... landed, workgroup barrier
+        a.dbg[2] = (unsigned long long)(t_first - t_loop);     // first chunk
+        a.dbg[3] = (unsigned long long)(t_chunks - t_loop);    // all chunks of this wave
+        a.dbg[4] = (unsigned long long)(t_end - t_chunks);     // (reduce through LDS,) epilogue, stores landed
+        a.dbg[5] = (unsigned long long)((nk32 - ps0 + STEP - 1) / STEP);
     }
 }
 
@@ -438,6 +524,7 @@ static int wz_hp_launch(WzMbArgs a, int n, hipStream_t s, bool prepare) {
     constexpr int RED = CS ? NW * MQW * NTO * 1024 : 0;
     const size_t region = (size_t)(NW * EB > RED ? NW * EB : RED);
     const size_t lds = region + (size_t)a.cmid_pad * ((CS || OCC > 2) ? 8 + 36 : 8);
+    if ((a.cmid_pad >> 2) > NW * 64 || 9 * (a.cmid_pad >> 2) > 3 * NW * 64) return -1;   // the staging code's fixed trip counts
     auto k = wz_k_mbconv_hp<NW, CS, STEM, MPW, MQW, KCI, NTO, OCC, ONEPASS>;
     if (prepare) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
