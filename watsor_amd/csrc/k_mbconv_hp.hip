@@ -73,7 +73,10 @@ __device__ __forceinline__ void wz_hp_fma8(wz_f32x2_t d[4], const wz_f32x2_t x[4
 // whose waves spend their time waiting rather than issuing).
 // ONEPASS (CS only): the workgroup has at least as many waves as the block has chunks, every wave walks at most ONE -- the
 // halo fragments and the expand weights are then dead after the expand stage and the kernel fits 3 waves per SIMD.
-template <int NW, bool CS, bool STEM, int MPW, int MQW, int KCI, int NTO, int OCC = 2, bool ONEPASS = false>
+// SH (CS only): the halo fragments are fetched ONCE per workgroup -- each wave loads its share of the MPW x KCI x 2 fragments,
+// they meet in LDS, every wave reads all of them back -- instead of once per wave (8 or 12 times the same 13 .. 18 KiB through
+// the vector memory path of one CU: the prologue of the 19x19 blocks was bound by exactly that, profiles/r02zq_*).
+template <int NW, bool CS, bool STEM, int MPW, int MQW, int KCI, int NTO, int OCC = 2, bool ONEPASS = false, bool SH = false>
 __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wz_hp_smem[];
     const long long t_entry = WZ_HP_STAMPS ? __builtin_readcyclecounter() : 0;
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
             const half_t e0l = g == 0 ? v8[4] : g == 1 ? v8[6] : z16, e1l = g == 0 ? v8[5] : z16;
             xh[i][0] = (half8_t){va[0], va[1], va[2], e0h, vb[0], vb[1], vb[2], e1h};
             xl[i][0] = (half8_t){va[4], va[5], va[6], e0l, vb[4], vb[5], vb[6], e1l};
-        } else {
+        } else if constexpr (!SH) {
             const half_t* src = a.in + ((size_t)(b * a.hin + (ok ? iy : 0)) * a.win + (ok ? ix : 0)) * (2 * a.cin0);
 #pragma unroll
             for (int c = 0; c < KCI; ++c) {
@@ -167,6 +170,34 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
                 xh[i][c] = kok ? *reinterpret_cast<const half8_t*>(src + k0) : zero8;
                 xl[i][c] = kok ? *reinterpret_cast<const half8_t*>(src + a.cin0 + k0) : zero8;
             }
+        }
+    }
+    // SH: fragment f = (i * KCI + c) * 2 + (0: hi, 1: lo) is fetched by wave f % NW and parked at f KiB of the halo area
+    constexpr int NFRAG = MPW * KCI * 2;
+    unsigned char* const halo_l = wz_hp_smem + REGION + (size_t)a.cmid_pad * (LDSW ? 44 : 8);
+    if constexpr (SH) {
+        static_assert(!STEM && CS, "shared halo: chunk-split kernels only");
+        constexpr int PERW = (NFRAG + NW - 1) / NW;
+        half8_t part[PERW];
+#pragma unroll
+        for (int k = 0; k < PERW; ++k) {
+            const int f = wave + k * NW;     // wave-uniform
+            part[k] = zero8;
+            if (f < NFRAG) {
+                const int i = f / (KCI * 2), c = (f >> 1) % KCI, lo = f & 1;
+                const int p = i * 16 + r16;
+                const int hy = (int)(((float)p + 0.5f) * rcp_hw), hx = p - hy * hw_;
+                const int iy = iy_base + hy, ix = ix_base + hx;
+                const int k0 = c * 32 + g * 8;
+                const bool kok = live && p < P && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win && k0 < a.cin0;
+                const half_t* src = a.in + ((size_t)(b * a.hin + (kok ? iy : 0)) * a.win + (kok ? ix : 0)) * (2 * a.cin0);
+                if (kok) part[k] = *reinterpret_cast<const half8_t*>(src + (lo ? a.cin0 : 0) + k0);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PERW; ++k) {
+            const int f = wave + k * NW;
+            if (f < NFRAG) *reinterpret_cast<half8_t*>(halo_l + (size_t)f * 1024 + lane * 16) = part[k];
         }
     }
 
@@ -229,8 +260,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
         }
     }
     const long long t_issued = WZ_HP_STAMPS ? __builtin_readcyclecounter() : 0;
-    __syncthreads();   // staged biases visible; the only workgroup barrier in front of the loop
+    __syncthreads();   // staged biases (SH: and halo fragments) visible; the only workgroup barrier in front of the loop
     if (!CS && !live) return;
+
     long long t_loop = 0, t_first = 0;
     if (WZ_HP_STAMPS) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (stamped build only: the halo and the first weights have landed)
@@ -242,12 +274,16 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
         const int coff = ce0 + g * 8;
         // operands of the later phases, in flight under the expand stage: project fragments, depthwise weights
         half8_t wph[NTO], wpl[NTO];
+        auto load_wp = [&]() {
 #pragma unroll
-        for (int nt = 0; nt < NTO; ++nt) {
-            const size_t off = ((size_t)(nt * a.kc + ps) * 64 + lane) * 8;
-            wph[nt] = *reinterpret_cast<const half8_t*>(a.wp + off);
-            wpl[nt] = *reinterpret_cast<const half8_t*>(a.wp_lo + off);
-        }
+            for (int nt = 0; nt < NTO; ++nt) {
+                const size_t off = ((size_t)(nt * a.kc + ps) * 64 + lane) * 8;
+                wph[nt] = *reinterpret_cast<const half8_t*>(a.wp + off);
+                wpl[nt] = *reinterpret_cast<const half8_t*>(a.wp_lo + off);
+            }
+        };
+        constexpr bool WP_LATE = OCC > 2 && CS;   // 3 waves per SIMD: the project fragments are requested behind the expand stage
+        if constexpr (!WP_LATE) load_wp();        // (they have the depthwise stage to land) instead of holding 8 x NTO registers through it
         float4_t wt0[9], wt1[9];   // (LDSW: unused, the weights are read from LDS where they are needed)
         if constexpr (!LDSW) {
 #pragma unroll
@@ -255,6 +291,16 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
                 wt0[tp] = *reinterpret_cast<const float4_t*>(wd32 + (size_t)tp * a.cmid_pad + coff);
                 wt1[tp] = *reinterpret_cast<const float4_t*>(wd32 + (size_t)tp * a.cmid_pad + coff + 4);
             }
+        }
+        if constexpr (SH) {   // the halo fragments come back from LDS for every pass: they are dead behind the expand stage, which is
+                              // what lets a multi-pass wave fit 168 registers (3 waves per SIMD, 12 per tile)
+#pragma unroll
+            for (int i = 0; i < MPW; ++i)
+#pragma unroll
+                for (int c = 0; c < KCI; ++c) {
+                    xh[i][c] = *reinterpret_cast<const half8_t*>(halo_l + (size_t)((i * KCI + c) * 2) * 1024 + lane * 16);
+                    xl[i][c] = *reinterpret_cast<const half8_t*>(halo_l + (size_t)((i * KCI + c) * 2 + 1) * 1024 + lane * 16);
+                }
         }
         __builtin_amdgcn_sched_barrier(0);   // (the loads above stay above: they have the whole expand stage to land)
         // ---- expand: E[p][ce] = in-frame ? unorm16(clamp((sum_k X[p][k] We[k][ce] + be[ce]) / 6, 0, 1)) : 0
@@ -303,6 +349,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
                 }
             }
         }
+        if constexpr (WP_LATE) load_wp();
         if constexpr (!ONEPASS)
             if (ps + STEP < nk32) load_wa(ps + STEP);   // next pass's expand fragments, in flight under the depthwise stage
         // the wave's own LDS writes are ordered before its reads by the LDS queue; keep the compiler from moving the reads up
@@ -513,7 +560,7 @@ static int wz_hp_env(const char* name, int dflt) {
     return (e && e[0] && atoi(e) >= 0) ? atoi(e) : dflt;
 }
 
-template <int NW, bool CS, bool STEM, int MPW, int MQW, int KCI, int NTO, int OCC = 2, bool ONEPASS = false>
+template <int NW, bool CS, bool STEM, int MPW, int MQW, int KCI, int NTO, int OCC = 2, bool ONEPASS = false, bool SH = false>
 static int wz_hp_launch(WzMbArgs a, int n, hipStream_t s, bool prepare) {
     if (ONEPASS && (a.cmid_pad >> 5) > NW) return -1;
     a.nb = n;
@@ -523,9 +570,9 @@ static int wz_hp_launch(WzMbArgs a, int n, hipStream_t s, bool prepare) {
     constexpr int EB = MPW * 16 * 40 * 2;
     constexpr int RED = CS ? NW * MQW * NTO * 1024 : 0;
     const size_t region = (size_t)(NW * EB > RED ? NW * EB : RED);
-    const size_t lds = region + (size_t)a.cmid_pad * ((CS || OCC > 2) ? 8 + 36 : 8);
+    const size_t lds = region + (size_t)a.cmid_pad * ((CS || OCC > 2) ? 8 + 36 : 8) + (SH ? (size_t)MPW * KCI * 2 * 1024 : 0);
     if ((a.cmid_pad >> 2) > NW * 64 || 9 * (a.cmid_pad >> 2) > 3 * NW * 64) return -1;   // the staging code's fixed trip counts
-    auto k = wz_k_mbconv_hp<NW, CS, STEM, MPW, MQW, KCI, NTO, OCC, ONEPASS>;
+    auto k = wz_k_mbconv_hp<NW, CS, STEM, MPW, MQW, KCI, NTO, OCC, ONEPASS, SH>;
     if (prepare) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return lds <= 160 * 1024 ? 0 : -1;
@@ -547,6 +594,12 @@ static int wz_hp_launch(WzMbArgs a, int n, hipStream_t s, bool prepare) {
 int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) {
     static const int cs_max_w = wz_hp_env("WZ_HP_CS_MAX_W", 19);
     static const int cs_few_wgs = wz_hp_env("WZ_HP_CS_FEW_WGS", 64);   // chunk-split when one wave per tile gives at most this many workgroups
+    // WZ_HP_SH (default 1): chunk-split workgroups fetch the halo once and share it through LDS.  Measured at batch 8
+    // (profiles/r02zt_*): the 19x19 blocks 8.0 -> 6.95 us (cmid 384) and 12.3 -> 10.5 us (cmid 576), 45.6 k -> 47.3 k frames/s.
+    // WZ_HP_W12 (default 0): 12 waves per 19x19 tile (3 per SIMD, re-reading the halo from LDS every pass) instead of 8 -- the
+    // cmid-384 blocks 6.95 -> 6.76 us, no gain in frames/s; the cmid-576 shape does not fit 168 registers (spills: 16 us) and stays on 8.
+    static const int sh = wz_hp_env("WZ_HP_SH", 1);
+    static const int w12 = wz_hp_env("WZ_HP_W12", 0);
     const int nto = a0.n_pad / 16;
     WzMbArgs a = a0;
     a.nsplit = 1;
@@ -577,15 +630,20 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
         // round (comment above wz_launch_mbconv_hp).
         const int tiles_s1 = ((a.hout + 3) / 4) * ((a.wout + (a.stride == 1 ? 7 : 3)) / (a.stride == 1 ? 8 : 4));
         const bool few = (tiles_s1 * n + 3) / 4 <= cs_few_wgs;
-        const bool cs = (prepare || a.wout <= cs_max_w || few) && nk32 >= 4 && nk32 <= 6;
+        static const int cs_s1_max_w = wz_hp_env("WZ_HP_CS_S1_MAX_W", 19);   // the same threshold for the stride-1 blocks alone
+        const bool cs = (prepare || a.wout <= cs_max_w || (a.stride == 1 && a.wout <= cs_s1_max_w) || few) && nk32 >= 4 && nk32 <= 6;
         if (a.stride == 1) {        // 4 x 8 tiles, halo 6 x 10 = 60 pixels
             if (prepare) {
                 (void)wz_hp_launch<5, true, false, 4, 2, 1, 2>(a, n, s, true);
                 (void)wz_hp_launch<6, true, false, 4, 2, 1, 2>(a, n, s, true);
+                (void)wz_hp_launch<5, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, true);
+                (void)wz_hp_launch<6, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, true);
                 (void)wz_hp_launch<4, false, false, 4, 2, 1, 2, 3>(a, n, s, true);
                 (void)wz_hp_launch<4, false, false, 4, 2, 1, 2, 4>(a, n, s, true);
                 return wz_hp_launch<4, false, false, 4, 2, 1, 2>(a, n, s, true);
             }
+            if (cs && sh && nk32 <= 5) return wz_hp_launch<5, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, false);
+            if (cs && sh) return wz_hp_launch<6, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, false);
             if (cs && nk32 <= 5) return wz_hp_launch<5, true, false, 4, 2, 1, 2>(a, n, s, false);
             if (cs) return wz_hp_launch<6, true, false, 4, 2, 1, 2>(a, n, s, false);
             if (occ == 3) return wz_hp_launch<4, false, false, 4, 2, 1, 2, 3>(a, n, s, false);
@@ -595,10 +653,12 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
         // stride 2: 4 x 4 tiles, halo 9 x 9 = 81 pixels
         if (prepare) {
             (void)wz_hp_launch<5, true, false, 6, 1, 1, 2>(a, n, s, true);
+            (void)wz_hp_launch<5, true, false, 6, 1, 1, 2, 2, false, true>(a, n, s, true);
             (void)wz_hp_launch<4, false, false, 6, 1, 1, 2, 3>(a, n, s, true);
             (void)wz_hp_launch<4, false, false, 6, 1, 1, 2, 4>(a, n, s, true);
             return wz_hp_launch<4, false, false, 6, 1, 1, 2>(a, n, s, true);
         }
+        if (cs && sh && nk32 <= 5) return wz_hp_launch<5, true, false, 6, 1, 1, 2, 2, false, true>(a, n, s, false);
         if (cs && nk32 <= 5) return wz_hp_launch<5, true, false, 6, 1, 1, 2>(a, n, s, false);
         if (occ == 3) return wz_hp_launch<4, false, false, 6, 1, 1, 2, 3>(a, n, s, false);
         if (occ == 4) return wz_hp_launch<4, false, false, 6, 1, 1, 2, 4>(a, n, s, false);
@@ -606,7 +666,11 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
     }
     if (a.wout > 19) return -1;
     if (a.stride == 2) {
-        if (a.kc0 == 1 && nto == 4) return wz_hp_launch<HP_CS_WAVES, true, false, 6, 1, 1, 4>(a, n, s, prepare);
+        if (a.kc0 == 1 && nto == 4) {
+            if (prepare) (void)wz_hp_launch<HP_CS_WAVES, true, false, 6, 1, 1, 4, 2, false, true>(a, n, s, true);
+            if (sh && !prepare) return wz_hp_launch<HP_CS_WAVES, true, false, 6, 1, 1, 4, 2, false, true>(a, n, s, false);
+            return wz_hp_launch<HP_CS_WAVES, true, false, 6, 1, 1, 4>(a, n, s, prepare);
+        }
         return -1;
     }
     // 12 chunks (cmid 384), WZ_HP_ONEPASS=1: 12 waves with one chunk each instead of 8 waves with up to two.  Measured
@@ -622,7 +686,17 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
                             : wz_hp_launch<12, true, false, 3, 1, 2, 6, 3, true>(a, n, s, false);
         }
     }
-#define HP_CASE(K, N) if (a.kc0 == K && nto == N) return wz_hp_launch<HP_CS_WAVES, true, false, 3, 1, K, N>(a, n, s, prepare)
+#define HP_CASE(K, N)                                                                                         \
+    if (a.kc0 == K && nto == N) {                                                                             \
+        if (prepare) {                                                                                        \
+            (void)wz_hp_launch<HP_CS_WAVES, true, false, 3, 1, K, N, 2, false, true>(a, n, s, true);         \
+            if (K == 2) (void)wz_hp_launch<12, true, false, 3, 1, 2, N, 3, false, true>(a, n, s, true);      \
+            return wz_hp_launch<HP_CS_WAVES, true, false, 3, 1, K, N>(a, n, s, true);                        \
+        }                                                                                                     \
+        if (sh && w12 && K == 2) return wz_hp_launch<12, true, false, 3, 1, 2, N, 3, false, true>(a, n, s, false); \
+        if (sh) return wz_hp_launch<HP_CS_WAVES, true, false, 3, 1, K, N, 2, false, true>(a, n, s, false);    \
+        return wz_hp_launch<HP_CS_WAVES, true, false, 3, 1, K, N>(a, n, s, false);                            \
+    }
     HP_CASE(2, 4);
     HP_CASE(2, 6);
     HP_CASE(3, 6);
