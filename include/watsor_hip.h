@@ -111,6 +111,7 @@ int wz_collect(wz_engine_t* e, int slot, wz_detection_t* const* out, uint8_t* co
 int wz_wait(wz_engine_t* e, int slot);
 const wz_detection_t* wz_slot_rows(wz_engine_t* e, int slot); /* pinned host, [n][100] */
 int wz_sync(wz_engine_t* e);
+int wz_graph_nodes(wz_engine_t* e, int slot);   /* nodes of the hipGraph last replayed on `slot` (kernels + 1 descriptor copy); 0 without graphs */
 int wz_num_slots(wz_engine_t* e);   /* lanes actually created (WZ_SLOTS unless WZ_LANES in the environment says fewer) */
 
 /* ---- per-camera filters on the GPU: ConfidenceFilter / AreaFilter / MaskFilter

@@ -50,6 +50,7 @@ SIGNATURES = {
     "wz_slot_rows": (C.c_void_p, [C.c_void_p, C.c_int]),
     "wz_sync": (C.c_int, [C.c_void_p]),
     "wz_num_slots": (C.c_int, [C.c_void_p]),
+    "wz_graph_nodes": (C.c_int, [C.c_void_p, C.c_int]),
     "wz_set_camera_filter": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, c_f64p, c_f64p, C.c_int,
                                        C.c_void_p, C.c_void_p]),
     "wz_clear_camera_filter": (C.c_int, [C.c_void_p, C.c_int]),

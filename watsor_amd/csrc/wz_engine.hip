@@ -113,6 +113,7 @@ struct wz_engine {
         bool decode_fused = false;           // set by enqueue_network: the grouped head reduce decoded the boxes
         bool cands_listed = false;           // ... and listed the candidates of the NMS kernel's first band
         uint8_t* d_frames = nullptr;         // staging for host frames of this lane [max_batch][frame_stride] (lazy)
+        std::map<int, int> graph_nodes;      // batch size -> nodes of the captured graph (kernels + the descriptor copy)
         WzPostBuffers post;
         void* d_post_scratch = nullptr;      // hist + count (memset per batch)
         WzFrameDesc* h_desc = nullptr;       // pinned
@@ -494,6 +495,8 @@ static int run_batch(wz_engine* e, int slot, int n) {
             HIPCHK(hipStreamBeginCapture(L.stream, hipStreamCaptureModeThreadLocal));
             enqueue_batch(e, L, n, nullptr);
             HIPCHK(hipStreamEndCapture(L.stream, &g));
+            size_t nodes = 0;
+            if (hipGraphGetNodes(g, nullptr, &nodes) == hipSuccess) L.graph_nodes[n] = (int)nodes;
             hipGraphExec_t ge = nullptr;
             HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
             (void)hipGraphDestroy(g);
@@ -935,6 +938,13 @@ extern "C" int wz_collect(wz_engine_t* e, int slot, wz_detection_t* const* out, 
 }
 
 extern "C" int wz_num_slots(wz_engine_t* e) { return e ? e->n_lanes : 0; }
+
+extern "C" int wz_graph_nodes(wz_engine_t* e, int slot) {
+    if (!e || slot < 0 || slot >= e->n_lanes) return 0;
+    const Lane& L = e->lanes[slot];
+    auto it = L.graph_nodes.find(L.n);
+    return it == L.graph_nodes.end() ? 0 : it->second;
+}
 
 extern "C" int wz_sync(wz_engine_t* e) {
     if (!e) return wz_fail(WZ_EINVAL, "wz_sync: null engine");

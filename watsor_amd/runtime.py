@@ -189,6 +189,10 @@ class HipEngine:
         buf = (C.c_uint8 * (72 * MAX_DETECTIONS * n)).from_address(p)
         return np.frombuffer(buf, dtype=ROW_DTYPE).reshape(n, MAX_DETECTIONS)
 
+    def graph_nodes(self, slot: int = 0) -> int:
+        """Nodes of the hipGraph last replayed on lane `slot` (kernel launches + the descriptor copy); 0 when graphs are off."""
+        return int(self._lib.wz_graph_nodes(self._h, slot))
+
     def sync(self) -> None:
         _lib.check(self._lib.wz_sync(self._h))
 
