@@ -402,6 +402,33 @@ def test_detect_end_to_end_matches_oracle_detector(model_dir, synth_weights, fra
             assert got["label"][0] == ref_rows[0].label
 
 
+@pytest.mark.parametrize("seed", [77, 4242])
+def test_score_tolerance_holds_for_other_weights(tmp_path, seed):
+    """The 1e-3 on the scores is a property of the mixed-precision program, not of one set of weights: the error budget behind it
+    (tools/err_budget.py) was worked out on the seed the other tests use.  Two more networks (same architecture, other seeded
+    weights), three frames each: `detect()` vs the oracle on those weights."""
+    from watsor_amd import engine
+    from watsor_amd.detection.hip_gpu import HipObjectDetector
+    from watsor_amd.share import DetectionArray
+    from watsor_amd.synth import synthetic_weights
+    w = synthetic_weights(seed)
+    engine.save_engine(engine.build_engine(w), str(tmp_path / "mi355x.bin"))
+    oracle = odet.OracleObjectDetector(weights=w)
+    frames = [synthetic_frame(640, 480, seed + 1), synthetic_frame(1280, 720, seed + 2), synthetic_frame(1920, 1080, seed + 3)]
+    worst = 0.0
+    with HipObjectDetector(str(tmp_path), 0) as det:
+        for f in frames:
+            rows = DetectionArray()
+            det.detect(f.shape, f, rows)
+            got = np.frombuffer(rows, dtype=ROW_DTYPE)
+            b, c, s, _, _ = oracle.raw(f)
+            ref = odet.rows_as_array(f.shape, b, c, s)
+            every, _ = pu.match_rows(got, ref, min_score=0.0)
+            assert len(every) >= 90
+            worst = max([worst] + [abs(p[3]) for p in every])
+    assert worst <= SCORE_TOL, worst
+
+
 def test_batch_of_mixed_resolutions_equals_single_calls(eng):
     frames = [synthetic_frame(640, 480, 1), synthetic_frame(1920, 1080, 2), synthetic_frame(1280, 720, 3),
               synthetic_frame(640, 480, 4)]

@@ -25,5 +25,7 @@ _lib.check(e._lib.wz_debug_mbconv(e._h, C.c_void_p(out.ctypes.data), C.c_void_p(
 for i, o in enumerate(ops):
     t = out[i].astype(np.int64)
     if o["kind"] == 4 and t[5] > 0 and t[3] > 0:
-        print("%-18s %3dx%-3d s%d cmid %3d | issue %5d  landed+barrier %5d | first chunk %5d  all %2d chunks %6d | epilogue %5d | total %6d cycles"
-              % (o["name"].split("/")[-1], o["hin"], o["win"], o["stride"], o["cmid"], t[0], t[1], t[2], t[5], t[3], t[4], t[0] + t[1] + t[3] + t[4]))
+        n = max(int(t[5]), 1)
+        print("%-18s %3dx%-3d s%d cmid %3d | issue %5d  landed+barrier %5d | first chunk %5d  all %2d chunks %6d (per chunk: expand %4d  depthwise %4d  split+project %4d) | epilogue %5d | total %6d cycles"
+              % (o["name"].split("/")[-1], o["hin"], o["win"], o["stride"], o["cmid"], t[0], t[1], t[2], t[5], t[3], t[6] // n, t[7] // n, t[9] // n,
+                 t[4], t[0] + t[1] + t[3] + t[4]))

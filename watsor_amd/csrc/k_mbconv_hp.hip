@@ -263,13 +263,14 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
     __syncthreads();   // staged biases (SH: and halo fragments) visible; the only workgroup barrier in front of the loop
     if (!CS && !live) return;
 
-    long long t_loop = 0, t_first = 0;
+    long long t_loop = 0, t_first = 0, cy_expand = 0, cy_dw = 0, cy_proj = 0;
     if (WZ_HP_STAMPS) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (stamped build only: the halo and the first weights have landed)
         t_loop = __builtin_readcyclecounter();
     }
 
     for (int ps = ps0; ps < nk32; ps += STEP) {
+        const long long tc0 = WZ_HP_STAMPS ? __builtin_readcyclecounter() : 0;
         const int ce0 = ps * 32;
         const int coff = ce0 + g * 8;
         // operands of the later phases, in flight under the expand stage: project fragments, depthwise weights
@@ -357,6 +358,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+        const long long tc1 = WZ_HP_STAMPS ? __builtin_readcyclecounter() : 0;   // (s_memtime waits lgkmcnt(0): the chunk's LDS stores have landed)
         // ---- depthwise (lane = output pixel x 8 channels), fp32
         const float4_t b0 = *reinterpret_cast<const float4_t*>(bd_l + coff);
         const float4_t b1 = *reinterpret_cast<const float4_t*>(bd_l + coff + 4);
@@ -420,6 +422,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
                 }
             }
         }
+        const long long tc2 = WZ_HP_STAMPS ? __builtin_readcyclecounter() : 0;
         // ---- relu6, split, project: acc += Wlo.dhi + Whi.dlo + Whi.dhi
 #pragma unroll
         for (int j = 0; j < MQW; ++j) {
@@ -435,7 +438,11 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
 #pragma unroll
             for (int nt = 0; nt < NTO; ++nt) acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wph[nt], bh, acc[j][nt], 0, 0, 0);
         }
-        if (WZ_HP_STAMPS && ps == ps0) t_first = __builtin_readcyclecounter();
+        if (WZ_HP_STAMPS) {
+            const long long tc3 = __builtin_readcyclecounter();
+            cy_expand += tc1 - tc0; cy_dw += tc2 - tc1; cy_proj += tc3 - tc2;
+            if (ps == ps0) t_first = tc3;
+        }
         if constexpr (ONEPASS) break;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();   // (the next pass's E stores stay behind these reads)
@@ -551,6 +558,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
         a.dbg[3] = (unsigned long long)(t_chunks - t_loop);    // all chunks of this wave
         a.dbg[4] = (unsigned long long)(t_end - t_chunks);     // (reduce through LDS,) epilogue, stores landed
         a.dbg[5] = (unsigned long long)((nk32 - ps0 + STEP - 1) / STEP);
+        a.dbg[6] = (unsigned long long)cy_expand;   // per-phase sums over this wave's chunks (each stamp is an lgkmcnt(0): phases do not overlap here)
+        a.dbg[7] = (unsigned long long)cy_dw;
+        a.dbg[9] = (unsigned long long)cy_proj;
     }
 }
 
