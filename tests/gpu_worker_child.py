@@ -4,7 +4,7 @@ import traceback
 
 
 def run_worker(model_dir, frame_buffers, payload_batches, fps, inference_time, camera_configs, drop, result_queue,
-               asynchronous=True):
+               asynchronous=True, hip_options=None):
     """What `ObjectDetector._run` does (`watsor/detection/detector.py:84-100`) around `BatchedWorkerMixin._process`:
     construct the plugin IN THIS PROCESS (HIP context after spawn), spin over a queue of payloads, exit."""
     try:
@@ -18,7 +18,7 @@ def run_worker(model_dir, frame_buffers, payload_batches, fps, inference_time, c
                 pass
 
         q = queue.Queue()
-        kwargs = dict(hip_cameras=camera_configs, hip_drop=drop, hip_async=asynchronous, hip_lanes=2)
+        kwargs = dict(hip_cameras=camera_configs, hip_drop=drop, hip_async=asynchronous, hip_lanes=2, hip_options=hip_options)
         opts = hip_detector_options(frame_buffers, kwargs)
         w = Worker()
         with HipObjectDetector(model_dir, 0, opts) as det:

@@ -33,8 +33,8 @@ class Frame:
 
 
 class FrameBuffer:
-    def __init__(self, ctx, maxsize, width, height):
-        self.frames = [Frame(ctx, width, height) for _ in range(maxsize)]
+    def __init__(self, ctx, maxsize, width, height, channels=3):                # share.py:76-81
+        self.frames = [Frame(ctx, width, height, channels) for _ in range(maxsize)]
 
 
 class Gauge:

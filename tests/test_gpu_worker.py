@@ -114,3 +114,36 @@ def test_spawned_worker_runs_the_camera_filters(model_dir):
         np.testing.assert_array_equal(raw["zones"][kept], porch["zones"][kept])
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("asynchronous", [True, False])
+def test_spawned_worker_takes_nv12_frame_buffers(model_dir, asynchronous):
+    """SURVEY 8(f)-3 under the worker: a camera whose decoder writes NV12 has one-"channel" frame buffers of height * 3 / 2 rows
+    (`share.py:37-40`), `hip_options["pixel_format"]` names it, and its rows equal an in-process call on the same bytes."""
+    from oracle import yuv
+    from watsor_amd.runtime import FMT_NV12, FMT_RGB24
+    ctx = shm.spawn_context()
+    cams = {"porch": shm.FrameBuffer(ctx, 2, 640, 480), "yard": shm.FrameBuffer(ctx, 2, 1280, 720 * 3 // 2, channels=1)}
+    images, batches = {}, []
+    for rnd in range(2):
+        rgb = synthetic_frame(640, 480, 70 + rnd)
+        nv = yuv.yuv420_from_rgb(synthetic_frame(1280, 720, 80 + rnd), "nv12")
+        fill(cams["porch"].frames[rnd], rgb)
+        fill(cams["yard"].frames[rnd], nv)
+        images[("porch", rnd)], images[("yard", rnd)] = rgb, nv
+        batches.append([shm.Payload("porch", rnd), shm.Payload("yard", rnd)])
+    run_child(ctx, model_dir, cams, batches, shm.Gauge(ctx), shm.Gauge(ctx), None, False, asynchronous=asynchronous,
+              hip_options={"pixel_format": {"yard": "nv12"}})
+    e = make_engine(model_dir, max_batch=8, max_width=1280, max_height=1080)
+    try:
+        for rnd, batch in enumerate(batches):
+            refs = [np.zeros(100, ROW_DTYPE) for _ in batch]
+            e.detect_batch([images[(p.sender, rnd)] for p in batch], refs, formats=[FMT_RGB24, FMT_NV12])
+            for p, ref in zip(batch, refs):
+                got = rows_of(cams[p.sender].frames[rnd])
+                assert got.tobytes() == ref.tobytes(), (p.sender, rnd)
+            # the NV12 camera's boxes live in its picture's 1280 x 720 pixels, not in the buffer's 1080 rows
+            yard = rows_of(cams["yard"].frames[rnd])
+            assert yard["y_max"].max() <= 719 and yard["x_max"].max() <= 1279 and yard["confidence"][0] > 0
+    finally:
+        e.close()
