@@ -1,4 +1,5 @@
-// The two big SSD heads (and the 5x5 one) as a WIDE implicit GEMM: one workgroup = 128 pixels x up to 320 output channels.
+// The six SSD heads as a WIDE implicit GEMM, one launch: one workgroup = 128 pixels x up to 320 output channels (the heads on the
+// 3x3 ... 1x1 maps fill little of a pixel tile; what they need is their long K loop cut into slices like everybody else's).
 //
 // Why another tile kernel.  wz_k_conv_rs (k_conv_rs.h) gives a wave 128 pixels x 32 channels: per K step (64 input
 // channels of one filter tap) it reads the whole 16 KiB activation tile from LDS for 32 MFMAs, i.e. per workgroup step
