@@ -52,10 +52,14 @@ __device__ __forceinline__ void wz_fetch_rgb(const WzFrameDesc& f, int x, int y,
 // HP: the network input is stored as a hi + lo pair of halves per value (hi = RN16(v), lo = RN16(v - hi), both
 // roundings and the subtraction exact-or-once-rounded fp32 operations): the first blocks of the `-p 16` program take
 // both (k_mbconv_hp.hip), which removes the 2^-11 input rounding from the error budget of the scores.
+// `keep`: where to leave a copy of the frame's descriptor for the kernels behind (wz_k_nms reads sizes and camera ids from it),
+// or nullptr.  With `frames` pointing into page-locked HOST memory this replaces the descriptor copy in front of every batch
+// (a graph node of its own, ~4 us of a batch's latency) by one 32-byte read over PCIe per workgroup, in flight together.
 template <bool HP>
 __global__ __launch_bounds__(256) void wz_k_preprocess(const WzFrameDesc* __restrict__ frames, int size,
-                                                       half_t* __restrict__ out) {
+                                                       half_t* __restrict__ out, WzFrameDesc* __restrict__ keep) {
     const WzFrameDesc f = frames[blockIdx.y];
+    if (keep && blockIdx.x == 0 && threadIdx.x == 0) keep[blockIdx.y] = f;
     const int pix = blockIdx.x * 256 + threadIdx.x;
     if (pix >= size * size) return;
     const int oy = pix / size, ox = pix - oy * size;
@@ -98,10 +102,10 @@ __global__ __launch_bounds__(256) void wz_k_preprocess(const WzFrameDesc* __rest
     }
 }
 
-void wz_launch_preprocess(const WzFrameDesc* d_frames, int n, int size, half_t* out, hipStream_t s, bool hp) {
+void wz_launch_preprocess(const WzFrameDesc* d_frames, int n, int size, half_t* out, hipStream_t s, bool hp, WzFrameDesc* keep) {
     dim3 grid((size * size + 255) / 256, n);
     if (hp)
-        WZ_LAUNCH(wz_k_preprocess<true>, grid, dim3(256), 0, s, d_frames, size, out);
+        WZ_LAUNCH(wz_k_preprocess<true>, grid, dim3(256), 0, s, d_frames, size, out, keep);
     else
-        WZ_LAUNCH(wz_k_preprocess<false>, grid, dim3(256), 0, s, d_frames, size, out);
+        WZ_LAUNCH(wz_k_preprocess<false>, grid, dim3(256), 0, s, d_frames, size, out, keep);
 }

@@ -135,7 +135,8 @@ struct WzCamFilter {
 extern thread_local int wz_launch_repeat;
 #define WZ_LAUNCH(...) do { for (int _wz_r = 0; _wz_r < wz_launch_repeat; ++_wz_r) hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 // hp: the input tensor is a hi + lo pair (8 halves per pixel: r g b 0 | r g b 0)
-void wz_launch_preprocess(const WzFrameDesc* d_frames, int n, int size, half_t* out, hipStream_t s, bool hp = false);
+void wz_launch_preprocess(const WzFrameDesc* d_frames, int n, int size, half_t* out, hipStream_t s, bool hp = false,
+                          WzFrameDesc* keep = nullptr);   // keep: see k_preprocess.hip
 void wz_launch_stem(const half_t* in, const float* w, const float* bias, half_t* out, int n, int hin, int win,
                     int hout, int wout, int pad_t, int pad_l, hipStream_t s);
 void wz_launch_dw(const half_t* in, const half_t* w, const float* bias, half_t* out, int n, int hin, int win,

@@ -80,6 +80,7 @@ struct wz_engine {
     bool conv_wide = true;     // the big SSD heads on the wide tile kernel (k_conv_wide.hip); WZ_CONV_WIDE=0: on wz_k_conv_rs
     int wide_min_m = 1;        // WZ_WIDE_MIN_M=n: heads with fewer output pixels than this (per batch) stay on wz_k_conv_group
     int wide_T = 0;            // WZ_WIDE_T=n: K steps per slice of that kernel (0: chosen per launch by wz_choose_wide_T)
+    bool desc_zero_copy = true;   // the resize kernel reads the frame descriptors from page-locked host memory (WZ_DESC_COPY=1: copied first)
     int num_cus = 256;         // compute units of the device (the wide head kernel sizes its K slices for one round over them)
     bool head_inline = false;  // WZ_HEAD_INLINE=1: ... or inside the head convolutions themselves, by each tile's last K slice.
                                // Bit-identical and one launch less, but measured SLOWER (profiles/r02l_*: heads 76 + 18 us against
@@ -117,6 +118,7 @@ struct wz_engine {
         WzPostBuffers post;
         void* d_post_scratch = nullptr;      // hist + count (memset per batch)
         WzFrameDesc* h_desc = nullptr;       // pinned
+        WzFrameDesc* h_desc_dev = nullptr;   // ... and its address as the device sees it (nullptr: not mapped)
         WzFrameDesc* d_desc = nullptr;
         wz_detection_t* d_rows = nullptr;
         uint8_t* d_pass = nullptr;
@@ -476,10 +478,14 @@ static void enqueue_post(wz_engine* e, Lane& L, bool rows, int n, StageTimer* t,
 static void enqueue_batch(wz_engine* e, Lane& L, int n, StageTimer* t, int inner = 1) {
     hipStream_t s = L.stream;
     if (t) t->mark();   // "(empty)": two event records with nothing between them = the bracket's own cost
-    (void)hipMemcpyAsync(L.d_desc, L.h_desc, sizeof(WzFrameDesc) * n, hipMemcpyHostToDevice, s);
+    // the descriptors: read by the resize kernel straight out of the lane's page-locked host block (and left in d_desc for the
+    // kernels behind it), or -- WZ_DESC_COPY=1, and where the host block has no device address -- copied in front of it
+    const bool zero_copy = e->desc_zero_copy && L.h_desc_dev;
+    if (!zero_copy) (void)hipMemcpyAsync(L.d_desc, L.h_desc, sizeof(WzFrameDesc) * n, hipMemcpyHostToDevice, s);
     if (t) t->mark();
     wz_launch_repeat = inner;
-    wz_launch_preprocess(L.d_desc, n, (int)e->hdr.input_size, L.tptr[input_tensor_index(e)], s, input_is_pair(e));
+    wz_launch_preprocess(zero_copy ? L.h_desc_dev : L.d_desc, n, (int)e->hdr.input_size, L.tptr[input_tensor_index(e)], s,
+                         input_is_pair(e), zero_copy ? L.d_desc : nullptr);
     if (t) t->mark();
     enqueue_network(e, L, n, t);
     wz_launch_repeat = 1;
@@ -638,6 +644,7 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     e->list_cands = !((env = getenv("WZ_LIST_CANDS")) && atoi(env) == 0);
     e->head_inline = (env = getenv("WZ_HEAD_INLINE")) && atoi(env) != 0;
     e->conv_wide = !((env = getenv("WZ_CONV_WIDE")) && atoi(env) == 0);
+    e->desc_zero_copy = !((env = getenv("WZ_DESC_COPY")) && atoi(env) != 0);
     e->wide_T = (env = getenv("WZ_WIDE_T")) ? atoi(env) : 0;
     e->wide_min_m = (env = getenv("WZ_WIDE_MIN_M")) ? atoi(env) : 1;
     {
@@ -786,6 +793,10 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
         CK(hipMalloc((void**)&pb.dbg, (size_t)max_batch * 16 * 8));
         CK(hipMemset(pb.dbg, 0, (size_t)max_batch * 16 * 8));
         CK(hipHostMalloc((void**)&L.h_desc, sizeof(WzFrameDesc) * max_batch, hipHostMallocDefault));
+        if (hipHostGetDevicePointer((void**)&L.h_desc_dev, L.h_desc, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            L.h_desc_dev = nullptr;
+        }
         CK(hipMalloc((void**)&L.d_desc, sizeof(WzFrameDesc) * max_batch));
         CK(hipMalloc((void**)&L.d_rows, sizeof(wz_detection_t) * WZ_MAX_DETECTIONS * max_batch));
         CK(hipMalloc((void**)&L.d_pass, (size_t)WZ_MAX_DETECTIONS * max_batch));
