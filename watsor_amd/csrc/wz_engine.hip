@@ -80,6 +80,7 @@ struct wz_engine {
     bool conv_wide = true;     // the big SSD heads on the wide tile kernel (k_conv_wide.hip); WZ_CONV_WIDE=0: on wz_k_conv_rs
     int wide_min_m = 1;        // WZ_WIDE_MIN_M=n: heads with fewer output pixels than this (per batch) stay on wz_k_conv_group
     int wide_T = 0;            // WZ_WIDE_T=n: K steps per slice of that kernel (0: chosen per launch by wz_choose_wide_T)
+    bool tail_fuse = false;       // WZ_TAIL_FUSE=1: the convolutions on the <= 32-pixel maps in one launch (k_tail.hip); measured slower, off
     bool desc_zero_copy = true;   // the resize kernel reads the frame descriptors from page-locked host memory (WZ_DESC_COPY=1: copied first)
     int num_cus = 256;         // compute units of the device (the wide head kernel sizes its K slices for one round over them)
     bool head_inline = false;  // WZ_HEAD_INLINE=1: ... or inside the head convolutions themselves, by each tile's last K slice.
@@ -278,6 +279,53 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
                 wz_launch_splitk_reduce(r, L.d_ws, s);
             }
         } else {
+            // The extras behind the 5x5 map: a chain of plain convolutions on maps of <= 32 pixels, each reading what the one before it
+            // wrote -- WZ_TAIL_FUSE=1 runs them as ONE launch, a workgroup per frame (k_tail.hip).  Built, bit-compatible within fp32
+            // summation order, and slower than the six launches it replaces (34 us against 23.5 us: DESIGN.md section 10): off by default.
+            if (!f32 && e->tail_fuse && op.out_mode == WZ_OUT_ACT) {
+                WzTailArgs T;
+                T.n = 0;
+                for (uint32_t j = i; j < e->hdr.n_ops && T.n < WZ_TAIL_MAX; ++j) {
+                    const WzOpDesc& oj = e->ops[j];
+                    if (oj.kind == WZ_OP_STEM || oj.kind == WZ_OP_DW || oj.kind == WZ_OP_MBCONV || oj.out_mode != WZ_OUT_ACT) break;
+                    if (j > i && oj.src != e->ops[j - 1].dst) break;
+                    WzConvArgs& c = T.l[T.n];
+                    memset(&c, 0, sizeof(c));
+                    c.in = L.tptr[oj.src];
+                    c.w = (const half_t*)(wbase + oj.w_off);
+                    c.bias = (const float*)(wbase + oj.b_off);
+                    c.res = oj.res >= 0 ? L.tptr[oj.res] : nullptr;
+                    c.out = L.tptr[oj.dst];
+                    c.M = n * oj.hout * oj.wout;
+                    c.hin = oj.hin; c.win = oj.win; c.cin = oj.cin;
+                    c.hout = oj.hout; c.wout = oj.wout; c.cout = oj.cout; c.n_pad = oj.n_pad;
+                    c.ksize = oj.ksize; c.stride = oj.stride; c.pad_t = oj.pad_t; c.pad_l = oj.pad_l; c.kc = oj.kc;
+                    c.act = oj.act; c.out_mode = oj.out_mode;
+                    c.kchunks = oj.ksize * oj.ksize * oj.kc;
+                    c.splitk = 1;
+                    if (!wz_tail_layer_ok(c, n)) break;
+                    ++T.n;
+                }
+                // A layer's output goes to HBM only if somebody outside the chain reads it (the SSD feature maps) -- the others live in
+                // LDS.  They must not be written: tensors with disjoint lifetimes share buffers, the lifetimes are those of a
+                // layer-by-layer execution, and here one frame's workgroup may be at the last layer while another's is at the
+                // first (a dead intermediate written late would land in a live feature map).  With WZ_NO_BUFFER_REUSE every
+                // tensor has its own buffer and all of them are written (tests read them).
+                for (int k = 0; k < T.n; ++k) {
+                    bool read_outside = e->no_reuse;
+                    const int32_t dst = e->ops[i + k].dst;
+                    for (uint32_t j = 0; j < e->hdr.n_ops && !read_outside; ++j)
+                        if ((j < i || j >= i + (uint32_t)T.n) && (e->ops[j].src == dst || e->ops[j].res == dst)) read_outside = true;
+                    if (!read_outside) T.l[k].out = nullptr;
+                }
+                if (T.n >= 2) {
+                    wz_launch_extras_tail(T, n, s);
+                    if (t)
+                        for (int k = 0; k < T.n; ++k) { t->mark(); t->mark(); }   // (the launch is booked on the chain's first layer)
+                    i += (uint32_t)T.n - 1;
+                    continue;
+                }
+            }
             WzConvArgs a;
             memset(&a, 0, sizeof(a));
             a.in = L.tptr[op.src];
@@ -645,6 +693,7 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     e->head_inline = (env = getenv("WZ_HEAD_INLINE")) && atoi(env) != 0;
     e->conv_wide = !((env = getenv("WZ_CONV_WIDE")) && atoi(env) == 0);
     e->desc_zero_copy = !((env = getenv("WZ_DESC_COPY")) && atoi(env) != 0);
+    e->tail_fuse = (env = getenv("WZ_TAIL_FUSE")) && atoi(env) != 0;
     e->wide_T = (env = getenv("WZ_WIDE_T")) ? atoi(env) : 0;
     e->wide_min_m = (env = getenv("WZ_WIDE_MIN_M")) ? atoi(env) : 1;
     {
