@@ -22,7 +22,7 @@ e = HipEngine(path, 0, 8, 640, 480)
 for label, kw in (("14 objects", dict(n_objects=14)), ("40 objects", dict(n_objects=40)), ("3 objects", dict(n_objects=3))):
     for seed in (1, 2):
         be, lg = tg.trained_like_head_outputs(seed, **kw)
-        for _ in range(3):                                              # (the band hint settles)
+        for _ in range(int(os.environ.get("NMS_WARM", "3"))):              # (the band hint settles)
             e.stage_postprocess(be, lg)
         out = np.zeros((8, 16), np.uint64)
         _lib.check(e._lib.wz_debug_nms(e._h, 1, C.c_void_p(out.ctypes.data)))
