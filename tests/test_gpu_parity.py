@@ -470,11 +470,11 @@ def test_submit_host_equals_detect_batch(eng):
         eng.host_unregister(arena)
 
 
-def _engine_with(model_dir, **env):
+def _engine_with(model_dir, max_batch=8, **env):
     saved = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
-        return make_engine(model_dir)
+        return make_engine(model_dir, max_batch=max_batch)
     finally:
         for k, v in saved.items():
             if v is None:
@@ -515,14 +515,15 @@ def test_grouped_head_launches_are_bit_identical_to_separate_ones(eng, model_dir
             base.close()
 
 
-@pytest.mark.parametrize("batch", [1, 3, 8])
+@pytest.mark.parametrize("batch", [1, 3, 8, 21])
 def test_wide_head_kernel_agrees_with_the_tile_kernel(model_dir, batch):
     """The big SSD heads run on wz_k_conv_wide (128 pixels x 288 channels per workgroup, k_conv_wide.hip); `WZ_CONV_WIDE=0` gives
     them back to wz_k_conv_rs.  Same products, other K slices (fp32 summation order): the head outputs agree to fp32 rounding of a
     5 184- / 11 520-term sum, far inside the score tolerance, and the rows match."""
     frames = [synthetic_frame(640, 480, 700 + i) for i in range(batch)]
-    wide = _engine_with(model_dir, WZ_CONV_WIDE="1")
-    narrow = _engine_with(model_dir, WZ_CONV_WIDE="0")
+    cap = 8 if batch <= 8 else 32       # (21 frames: more workgroups than CUs, slices of unequal length, single-slice heads)
+    wide = _engine_with(model_dir, cap, WZ_CONV_WIDE="1")
+    narrow = _engine_with(model_dir, cap, WZ_CONV_WIDE="0")
     try:
         x = np.stack([wide.stage_preprocess(f) for f in frames])
         bw, lw = wide.stage_forward(x)
