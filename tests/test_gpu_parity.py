@@ -449,6 +449,24 @@ def test_batch_of_mixed_resolutions_equals_single_calls(eng):
         assert max(abs(p[3]) for p in pairs) <= SCORE_TOL
 
 
+def test_batch_of_sixteen_cameras_stays_within_the_tolerance(model_dir, synth_weights):
+    """BASELINE configs[4]'s share of a GPU: 16 frames in one batch, 640x480 and 1920x1080 alternating.  Every frame's rows against
+    the ORACLE (not against another batch size): the tolerance holds at the batch size the saturation configs use."""
+    oracle = odet.OracleObjectDetector(weights=synth_weights)
+    e = make_engine(model_dir, max_batch=16)
+    try:
+        frames = [synthetic_frame(*((640, 480) if i % 2 == 0 else (1920, 1080)), 8100 + i) for i in range(16)]
+        rows = [np.zeros(100, ROW_DTYPE) for _ in frames]
+        e.detect_batch(frames, rows)
+        for i in (0, 1, 6, 11, 15):                                  # (the oracle takes ~2 s per frame)
+            b, c, s, _, _ = oracle.raw(frames[i])
+            ref = odet.rows_as_array(frames[i].shape, b, c, s)
+            every, _ = pu.match_rows(rows[i], ref, min_score=0.0)
+            assert len(every) >= 90 and max(abs(p[3]) for p in every) <= SCORE_TOL
+    finally:
+        e.close()
+
+
 def test_submit_host_equals_detect_batch(eng):
     """Asynchronous host-frame path (per-lane staging, optional page-locking) == the synchronous plugin call."""
     frames = [synthetic_frame(640, 480, 11 + i) for i in range(4)]
