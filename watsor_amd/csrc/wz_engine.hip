@@ -105,6 +105,7 @@ struct wz_engine {
     // API is lane i.
     struct Lane {
         hipStream_t stream = nullptr;
+        bool owns_stream = false;            // false: the stream belongs to lane (index mod n_streams)
         std::vector<void*> bufs;             // owned activation buffers
         std::vector<half_t*> tptr;           // tensor index -> device pointer
         float* d_box_enc = nullptr;
@@ -133,6 +134,7 @@ struct wz_engine {
     };
     Lane lanes[WZ_SLOTS];
     int n_lanes = 4;   // default; WZ_LANES overrides (1..WZ_SLOTS)
+    int n_streams = 4; // HIP streams the lanes are spread over (WZ_STREAMS); more than 4 run slower on this stack
 
     std::vector<WzCamFilter> h_cams;
     WzCamFilter* d_cams = nullptr;
@@ -702,6 +704,8 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
             e->num_cus = cus;
     }
     if ((env = getenv("WZ_LANES")) && atoi(env) >= 1 && atoi(env) <= WZ_SLOTS) e->n_lanes = atoi(env);
+    if ((env = getenv("WZ_STREAMS")) && atoi(env) >= 1 && atoi(env) <= WZ_SLOTS) e->n_streams = atoi(env);
+    if (e->n_streams > e->n_lanes) e->n_streams = e->n_lanes;
 
 #define CK(expr)                                                                                        \
     do {                                                                                                \
@@ -764,7 +768,15 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
 
     for (int li = 0; li < e->n_lanes; ++li) {
         Lane& L = e->lanes[li];
-        CK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+        // More lanes than streams (WZ_STREAMS, default 4 = what this stack runs side by side): lane i rides the stream of lane
+        // i mod streams, with buffers, graph and host blocks of its own -- the stream always has the next batch queued behind the one
+        // it is running, so the host's turnaround between a batch's end and the next submit is not idle time on that queue.
+        if (li < e->n_streams) {
+            CK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+            L.owns_stream = true;
+        } else {
+            L.stream = e->lanes[li % e->n_streams].stream;
+        }
         // activation buffers: one per slot (tensors with disjoint lifetimes share), or one per tensor
         L.tptr.assign(h.n_tensors, nullptr);
         if (e->no_reuse) {
@@ -915,7 +927,7 @@ extern "C" void wz_destroy(wz_engine_t* e) {
         if (L.h_rows) (void)hipHostFree(L.h_rows);
         if (L.h_pass) (void)hipHostFree(L.h_pass);
         if (L.done) (void)hipEventDestroy(L.done);
-        if (L.stream) (void)hipStreamDestroy(L.stream);
+        if (L.stream && L.owns_stream) (void)hipStreamDestroy(L.stream);
     }
     delete e;
 }
