@@ -35,6 +35,12 @@ typedef __attribute__((ext_vector_type(2))) unsigned int wz_u32x2_t;
 #ifndef WZ_HP_STAMPS
 #define WZ_HP_STAMPS 0   // 1: cycle counts of the first workgroup's wave 0 into WzMbArgs::dbg (tools/hp_probe.py)
 #endif
+#ifndef WZ_HP_RR3
+#define WZ_HP_RR3 1      // 168-register builds, 4 x 8 tiles: halo rows per tap request group (1, 2 or 4)
+#endif
+#ifndef WZ_HP_ROWS3
+#define WZ_HP_ROWS3 1    // 168-register builds, 4 x 4 tiles: tap rows per request group (1 or 3)
+#endif
 #ifndef WZ_HP_STAMP_LAST
 #define WZ_HP_STAMP_LAST 0   // 1: ... of the LAST workgroup instead (one that starts on a CU another workgroup has run on)
 #endif
@@ -382,7 +388,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
             // rows hp0 .. hp0 + 3 of the halo serve both outputs: row rr is tap row rr of output 0 and rr - 1 of output 1.
             // All 12 taps are requested before the first one is used: one LDS latency instead of twelve.
             const unsigned short* ep = E + hp0[0] * ES + g * 8;
-            constexpr int RR = PRE ? 4 : 1;                 // halo rows requested per group
+            constexpr int RR = PRE ? 4 : WZ_HP_RR3;         // halo rows requested per group (3 waves per SIMD: WZ_HP_RR3)
 #pragma unroll
             for (int r0 = 0; r0 < 4; r0 += RR) {
                 wz_u32x4_t tq[RR * 3];
@@ -404,7 +410,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
             for (int j = 0; j < MQW; ++j) {
                 const unsigned short* ep = E + hp0[j] * ES + g * 8;
                 // the taps are requested ahead of their use, all nine at once where the registers allow it
-                constexpr int ROWS = (KCI >= 3 || !PRE) ? 1 : 3;   // tap rows per request group
+                constexpr int ROWS = KCI >= 3 ? 1 : PRE ? 3 : (CS ? 1 : WZ_HP_ROWS3);   // tap rows per request group
 #pragma unroll
                 for (int k0 = 0; k0 < 3; k0 += ROWS) {
                     wz_u32x4_t tq[ROWS * 3];
