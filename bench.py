@@ -44,6 +44,7 @@ MFMA_PEAK_TFLOPS = 2500.0    # dense fp16/bf16 MFMA
 WIDTH, HEIGHT, BATCH = 640, 480, 8
 SCORE_TOLERANCE = 1e-3       # BASELINE.json north_star: "box scores within 1e-3 of the CPU reference"
 MIN_ROUNDS, MAX_ROUNDS, ROUNDS_BUDGET_S = 25, 400, 1.0
+RING = 5                     # batches of distinct frames the timed loop cycles through (coprime with the 4 lanes)
 PROFILE_INNER = 8            # launches per bracket in the stage profile (wz_profile_stages)
 
 
@@ -359,8 +360,8 @@ def config_legs(engine_path, device, rank):
         legs["frame_300x300_b8"] = r
         # configs[2]: 8 x 1280x720 streams, one camera per GPU -> this GPU's share: ONE camera; its frames arrive one at a
         # time (BalancedQueue holds one queued frame per camera, watsor/stream/sync.py:156-166), so batch = 1 per lane
-        f720 = [eng.upload(synthetic_frame(1280, 720, 600 + i)) for i in range(4)]
-        r = throughput(eng, lambda lane, s: eng.submit_device(lane, [f720[s % 4]], [1280], [720]), 1, steps=300, warm=20)
+        f720 = [eng.upload(synthetic_frame(1280, 720, 600 + i)) for i in range(5)]      # 5 frames over 4 lanes: no lane replays a scene
+        r = throughput(eng, lambda lane, s: eng.submit_device(lane, [f720[s % 5]], [1280], [720]), 1, steps=300, warm=20)
         r["workload"] = "configs[2] share: 1 camera 1280x720, batch 1 on each of %d lanes, frames in HBM" % eng.num_slots
         legs["config3_1x720p_b1"] = r
         # configs[3]: 32 x 1920x1080 cameras with per-camera alpha zone masks, 4 cameras per GPU: one frame of each per step
@@ -462,6 +463,124 @@ def host_legs(engine_path, model_dir, device, host_frames):
                                         workload="HipObjectDetector.detect() of one 640x480 frame in pageable host memory, synchronous "
                                                  "(what the reference's inference_time measures, detector.py:107-109)")
     return legs
+
+
+def host_config_legs(engine_path, device):
+    """BASELINE configs[2..4] as a Watsor install meets them (`watsor/stream/share.py:68-73` hands over HOST views): the
+    cameras' frame buffers in page-locked host memory, described once (`wz_bind_frames`), a step = one frame of every
+    camera, filters on where the config has them.  Per-GPU shares, like `config_legs` (which stages the frames in HBM)."""
+    from watsor_amd.filter.hip_filter import HipCameraFilter
+    from watsor_amd.runtime import HipEngine, ROW_DTYPE, zones_from_alpha
+    from watsor_amd.synth import synthetic_frame, synthetic_zone_mask
+    legs = {}
+    eng = HipEngine(engine_path, device, 16, 1920, 1080)
+    filters = []
+    try:
+        def camera_set(specs, frames_per_cam=3):
+            """specs: [(w, h, cam id or -1, seed)] -> (arena list, table)"""
+            arenas, pix, ws, hs, cams, rows = [], [], [], [], [], []
+            for w, h, cam, seed in specs:
+                a = np.stack([synthetic_frame(w, h, seed + k) for k in range(frames_per_cam)])
+                r = np.zeros((frames_per_cam, 100), ROW_DTYPE)
+                eng.host_register(a)
+                arenas.append((a, r))
+                for k in range(frames_per_cam):
+                    pix.append(a[k].ctypes.data); ws.append(w); hs.append(h); cams.append(cam); rows.append(r[k].ctypes.data)
+            eng.bind_frames(pix, ws, hs, [0] * len(pix), cams, rows)
+            return arenas
+
+        def release(arenas):
+            eng.sync()
+            eng.bind_frames([], [], [], [], [], [])
+            for a, _ in arenas:
+                eng.host_unregister(a)
+
+        def bound_throughput(n_cams, frames_per_cam, **kw):
+            def submit(lane, s):
+                k = s % frames_per_cam
+                eng.submit_bound(lane, [c * frames_per_cam + k for c in range(n_cams)])
+            return throughput(eng, submit, n_cams, **kw)
+
+        # configs[2] share: one 1280x720 camera
+        ar = camera_set([(1280, 720, -1, 600)], 5)
+        r = bound_throughput(1, 5, steps=300, warm=20)
+        r["workload"] = "configs[2] share: 1 camera 1280x720 in page-locked host memory, batch 1 on each of %d lanes" % eng.num_slots
+        legs["config3_1x720p_b1_host"] = r
+        release(ar)
+        # configs[3] share: 4 x 1920x1080 with zone masks + thresholds
+        masks = [synthetic_zone_mask(1920, 1080, 100 + c, 2 + c % 5) for c in range(8)]
+        for c in range(8):
+            nz = zones_from_alpha(masks[c])[0].shape[0]
+            filters.append(HipCameraFilter(eng, c, {"width": 1920, "height": 1080, "detect": sample_detect_config(nz)}, alpha=masks[c]))
+        ar = camera_set([(1920, 1080, c, 700 + 10 * c) for c in range(4)])
+        r = bound_throughput(4, 3, steps=60, warm=8)
+        r["workload"] = "configs[3] share: 4 cameras 1920x1080 RGB24 in page-locked host memory (PCIe inside the step), zone masks + thresholds on, batch 4"
+        legs["config4_4x1080p_masks_b4_host"] = r
+        release(ar)
+        # configs[4] share: 16 mixed cameras, masks + confidence / area
+        small_masks = [synthetic_zone_mask(640, 480, 300 + c, 2 + c % 5) for c in range(8)]
+        for c in range(8):
+            nz = zones_from_alpha(small_masks[c])[0].shape[0]
+            filters.append(HipCameraFilter(eng, 8 + c, {"width": 640, "height": 480, "detect": sample_detect_config(nz)}, alpha=small_masks[c]))
+        specs = []
+        for c in range(8):
+            specs += [(640, 480, 8 + c, 800 + 10 * c), (1920, 1080, c, 700 + 10 * c)]
+        ar = camera_set(specs)
+        r = bound_throughput(16, 3, steps=40, warm=6)
+        r["workload"] = ("configs[4] share: 16 cameras alternating 640x480 / 1920x1080 in page-locked host memory, masks + confidence / area "
+                         "thresholds, batch 16 = one frame of each camera, saturation")
+        legs["config5_16_mixed_filters_b16_host"] = r
+        release(ar)
+    finally:
+        for f in filters:
+            f.close()
+        eng.close()
+    return legs
+
+
+def worker_legs(model_dir):
+    """Frames/s through the detector WORKER LOOP (tools/worker_bench.py): a spawned process running `BatchedWorkerMixin` over
+    shared-memory frame buffers fed through a real multiprocessing.Queue -- `watsor/detection/detector.py:84-112`,
+    `watsor/stream/work.py:25-33`, `watsor/stream/sync.py:144-166`."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import worker_bench
+    legs = {}
+    for cams in (8, 16):
+        try:
+            legs["worker_spawned_%dcams" % cams] = worker_bench.run(model_dir, n_cams=cams, seconds=3.0)
+        except Exception as e:                     # a leg must not take the headline down with it
+            legs["worker_spawned_%dcams" % cams] = dict(error=repr(e))
+    try:
+        legs["worker_spawned_8cams_per_batch_descriptions"] = worker_bench.run(model_dir, n_cams=8, seconds=2.0, frame_table=False)
+    except Exception as e:
+        legs["worker_spawned_8cams_per_batch_descriptions"] = dict(error=repr(e))
+    return legs
+
+
+def busy_scene_leg(frames, rank):
+    """The benchmark's random-init network puts ~170 scores above 0.3 in 4 classes: a light load for `wz_k_nms`.  The same
+    weights with the class logits widened (`synthetic_weights(class_gain=1.3)`): ~800 above 0.3 in ~25 classes, several hundred
+    first-band candidates in same-class clusters -- through the full graph, batch 8, frames in HBM."""
+    from watsor_amd import engine as builder
+    from watsor_amd.runtime import HipEngine
+    from watsor_amd.synth import synthetic_weights
+    d = "/tmp/wz_bench_busy_%d_%d" % (os.getpid(), rank)
+    os.makedirs(d, exist_ok=True)
+    path = os.path.join(d, "mi355x.bin")
+    builder.save_engine(builder.build_engine(synthetic_weights(1234, class_gain=1.3)), path)
+    eng = HipEngine(path, int(os.environ.get("LOCAL_RANK", "0")), BATCH, WIDTH, HEIGHT)
+    try:
+        dfr = [eng.upload(f) for f in frames[:RING * BATCH]]
+        nb = len(dfr) // BATCH
+        r = throughput(eng, lambda lane, s: eng.submit_device(lane, dfr[(s % nb) * BATCH:(s % nb + 1) * BATCH], [WIDTH] * BATCH, [HEIGHT] * BATCH), BATCH)
+        rows = eng.slot_rows(0, BATCH)
+        r["detections_per_frame_above_0.3"] = float((rows["confidence"] > 0.3).sum()) / BATCH
+        r["workload"] = "640x480 frames in HBM, batch 8, class logits widened (class_gain 1.3): a busy scene for the NMS kernel"
+        return r
+    finally:
+        eng.close()
+        os.remove(path)
+        os.rmdir(d)
 
 
 def parity_leg(eng, host_frames, d_frames, weights):
@@ -718,8 +837,9 @@ def main():
     note("engine file built")
     eng = HipEngine(engine_path, local_rank, BATCH, WIDTH, HEIGHT)
     note("engine created on " + eng.device_name)
-    # camera `rank`: a ring of 4 batches of distinct frames, pre-staged in HBM
-    ring = 4
+    # camera `rank`: a ring of 5 batches of distinct frames, pre-staged in HBM.  Coprime with the lane count (4): a lane's frame
+    # slots see a different scene every step, so the NMS kernel's per-slot band hint is never a replay of its last call
+    ring = RING
     host_frames = [synthetic_frame(WIDTH, HEIGHT, 1234 + rank * 1000 + i) for i in range(ring * BATCH if not args.dry_run else 2)]
     if args.dry_run:
         host_frames = (host_frames * (ring * BATCH))[:ring * BATCH]
@@ -751,8 +871,10 @@ def main():
         t0 = time.perf_counter()
         for s in range(args.steps):
             submit(s)
-        barrier()
+        eng.sync()                            # device synchronize: this rank's K steps are done -> stop ITS clock here ...
         el = time.perf_counter() - t0
+        if dist is not None:                  # ... then the barrier, outside the clock (a gloo barrier over TCP costs as much as a step)
+            dist.barrier()
         if dist is not None:
             t = torch.tensor([el], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -845,6 +967,12 @@ def main():
             note("host-frame legs done")
             legs.update(config_legs(engine_path, local_rank, rank))
             note("config legs done")
+            legs.update(host_config_legs(engine_path, local_rank))
+            note("host-memory config legs done")
+            legs["busy_scene_b8"] = busy_scene_leg(host_frames, rank)
+            note("busy-scene leg done")
+            legs.update(worker_legs(model_dir))
+            note("worker legs done")
             out["legs"] = legs
         if world == 1 and not args.no_fp32_leg:
             out["plain_fp16_engine"] = plain_fp16_leg(weights, host_frames, rank)

@@ -29,6 +29,7 @@ extern "C" {
 #define WZ_MAX_DETECTIONS 100 /* Header.detections length, watsor/stream/share.py:31 */
 #define WZ_MAX_ZONES 10       /* Detection.zones length,   watsor/stream/share.py:22 */
 #define WZ_NUM_LABELS 91      /* len(COCO_CLASSES),        watsor/config/coco.py:14-106 */
+#define WZ_MAX_CAMS 256       /* camera ids with a GPU filter (wz_set_camera_filter) per engine: 0 .. WZ_MAX_CAMS - 1 */
 
 #define WZ_OK 0
 #define WZ_EINVAL (-1)   /* bad argument */
@@ -107,6 +108,18 @@ uint64_t wz_frame_bytes(int w, int h, int fmt);   /* bytes of one frame; 0 for a
 int wz_host_register(wz_engine_t* e, void* ptr, uint64_t bytes);
 int wz_host_unregister(wz_engine_t* e, void* ptr);
 int wz_collect(wz_engine_t* e, int slot, wz_detection_t* const* out, uint8_t* const* pass);
+/* ---- the worker's frame table.  The reference worker resolves every payload to `frame_buffers[sender].frames[index]`, asks
+ * the frame for a numpy view of its pixels and hands the frame header's `Detection[100]` array to the plugin
+ * (watsor/detection/detector.py:102-109); pixels, size and rows of a Frame never move after the FrameBuffers are created
+ * (watsor/stream/share.py:27-41,76-81).  So they are described ONCE (entry i = one Frame: pixels, w, h, WZ_FMT_*, camera id or
+ * -1, its rows), a batch is then n table indices, and the rows land in the frames' own headers.  fmt / cam may be NULL (RGB24 /
+ * no camera).  Entries whose pixels lie inside a wz_host_register()ed range are pulled into HBM by one kernel per batch
+ * (csrc/k_preprocess.hip: wz_k_stage_frames, part of the lane's captured graph) instead of one copy per frame; the others
+ * are copied as wz_submit_host copies them.  wz_bind_frames replaces the whole table (waits for the lanes first). */
+int wz_bind_frames(wz_engine_t* e, int n, const uint8_t* const* pixels, const int* w, const int* h, const int* fmt,
+                   const int* cam, wz_detection_t* const* rows);
+int wz_submit_bound(wz_engine_t* e, int slot, int n, const int32_t* entries);
+int wz_collect_bound(wz_engine_t* e, int slot);   /* waits for `slot`, writes its rows into the bound frames' rows */
 /* Wait for `slot` without copying rows out (rows stay readable via wz_slot_rows). */
 int wz_wait(wz_engine_t* e, int slot);
 const wz_detection_t* wz_slot_rows(wz_engine_t* e, int slot); /* pinned host, [n][100] */

@@ -31,7 +31,9 @@ def test_two_ranks_over_gloo():
     assert out["n_gpus"] == 2
     assert out["camera_seeds"] == [1234, 2234]        # every rank serves its own camera (cameras are the shard)
     single = run([sys.executable, "bench.py", "--gpus", "1", "--steps", "40", "--warmup", "4", "--dry-run"])
-    assert 1.5 < out["value"] / single["value"] < 2.5   # whole-job aggregate = frames of all ranks / max time
+    # whole-job aggregate = frames of all ranks / max over ranks of each rank's OWN clock (stopped after its device synchronize,
+    # before the gloo barrier): two replicas are worth two, within 10 %
+    assert 1.8 < out["value"] / single["value"] < 2.2
 
 
 def test_gpus_flag_starts_the_ranks_itself():

@@ -94,7 +94,7 @@ def test_async_batches_over_two_lanes():
     _, cams = setup()
     det, w = ScriptedDetector(), Worker()
     batches = [[shm.Payload("cam%d" % c, i) for c in range(3)] for i in range(4)]
-    fps, it = drive(w, det, cams, batches, hip_lanes=2, hip_cameras={"cam1": {"x": 1}}, hip_drop=True)
+    fps, it = drive(w, det, cams, batches, hip_lanes=2, hip_cameras={"cam1": {"x": 1}}, hip_drop=True, hip_metric_interval=0)
     assert det.log[0] == ("bind", ["cam0", "cam1", "cam2"], {"cam1": {"x": 1}}, True)
     assert [e for e in det.log if e[0] == "submit"] == [("submit", i % 2, 3) for i in range(4)]
     assert det.max_in_flight <= 2 and not det.busy
@@ -103,7 +103,92 @@ def test_async_batches_over_two_lanes():
             f = cams["cam%d" % c].frames[i]
             assert first_row(f) == (1 + 10 * c + i, c)              # right frame, tagged with its camera id
             assert f.latch.steps.value == 1
-    assert fps.count.value == 12 and it.count.value == 12
+    assert fps.count.value == 12 and it.count.value == 4          # fps per frame; inference_time once per batch (its per-frame share)
+
+
+class TableDetector(ScriptedDetector):
+    """... that also takes a frame table, like HipObjectDetector: a batch is then a list of table indices."""
+
+    def bind_frame_table(self, frame_buffers, ids):
+        self.entries, table = [], {}
+        for name in sorted(frame_buffers):
+            table[name] = (len(self.entries), [f.latch.next for f in frame_buffers[name].frames])
+            self.entries += [(f, ids.get(name, -1)) for f in frame_buffers[name].frames]
+        self.log.append(("table", len(self.entries)))
+        return table
+
+    def submit_bound(self, lane, entries):
+        assert lane not in self.busy, "lane reused before it was collected"
+        self.busy[lane] = list(entries)
+        self.max_in_flight = max(self.max_in_flight, len(self.busy))
+        self.log.append(("submit_bound", lane, list(entries)))
+
+    def collect_bound(self, lane):
+        for e in self.busy.pop(lane):
+            f, cam = self.entries[e]
+            self._fill(np.frombuffer(f.image.get_obj(), np.uint8), f.header.get_obj().detections, cam)
+        self.log.append(("collect_bound", lane))
+
+
+def test_bound_frames_travel_as_table_indices():
+    _, cams = setup()
+    det, w = TableDetector(), Worker()
+    batches = [[shm.Payload("cam%d" % c, i) for c in range(3)] for i in range(4)]
+    batches[1].append(shm.Payload("cam1", 9))          # no such frame
+    batches[2].append(shm.Payload("stranger", 0))      # no such camera
+    batches[3].append(shm.Payload("cam0", -1))         # a negative index is not "the last frame"
+    fps, it = drive(w, det, cams, batches, hip_lanes=2)
+    assert ("table", 12) in det.log and not [e for e in det.log if e[0] in ("submit", "sync")]
+    subs = [e for e in det.log if e[0] == "submit_bound"]
+    assert [e[1] for e in subs] == [0, 1, 0, 1] and subs[2][2] == [2, 6, 10]     # cam c, frame i -> 4 c + i
+    assert det.max_in_flight <= 2 and not det.busy
+    for c in range(3):
+        for i in range(4):
+            f = cams["cam%d" % c].frames[i]
+            assert first_row(f) == (1 + 10 * c + i, c) and f.latch.steps.value == 1
+    assert fps.count.value == 12 and 1 <= it.count.value <= 4       # observations folded per 5 ms by default
+
+
+def test_frame_table_can_be_switched_off_and_a_refused_table_falls_back():
+    _, cams = setup()
+    det, w = TableDetector(), Worker()
+    drive(w, det, cams, [[shm.Payload("cam0", 0), shm.Payload("cam1", 0)]], hip_frame_table=False)
+    assert ("submit", 0, 2) in det.log and not [e for e in det.log if e[0] == "table"]
+
+    class Refusing(TableDetector):
+        def bind_frame_table(self, frame_buffers, ids):
+            raise ValueError("camera 'cam1': frame memory smaller than its header says")
+
+    det, w = Refusing(), Worker()
+    drive(w, det, cams, [[shm.Payload("cam0", 1), shm.Payload("cam2", 1)]])
+    assert ("submit", 0, 2) in det.log and first_row(cams["cam2"].frames[1]) == (22, 2)
+
+
+def test_inference_time_is_service_time_not_queueing_latency():
+    """Two batches in flight: the second one's observation starts at the first one's retirement, not at its own submit."""
+    import time
+    _, cams = setup()
+
+    class Slow(TableDetector):
+        max_batch = 2
+
+        def collect_bound(self, lane):
+            time.sleep(0.05)
+            super().collect_bound(lane)
+
+    det, w = Slow(), Worker()
+    batches = [[shm.Payload("cam0", i), shm.Payload("cam1", i)] for i in range(3)]
+    ctx = shm.spawn_context()
+    q = queue.Queue()
+    fps, it = shm.Gauge(ctx), shm.Gauge(ctx)
+    for b in batches:
+        for p in b:
+            q.put(p)
+    while not q.empty():
+        w._process(q, None, cams, fps, it, det, hip_lanes=2, hip_metric_interval=0)
+    w.drain(fps, it)
+    # three batches of two frames, 50 ms each: every observation is ~25 ms per frame; latency-based it would grow (25, 50, ...)
+    assert it.count.value == 3 and 60 < it.total.value < 100
 
 
 def test_sync_path_reports_per_frame_time_and_camera_ids():

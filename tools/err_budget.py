@@ -58,6 +58,9 @@ def quant(x, mode):
         return q32(x)
     if mode == "u":      # unorm16 of x/6 (relu6 outputs only)
         return torch.round(torch.clamp(x, 0.0, 6.0) * (65535.0 / 6.0)) * (6.0 / 65535.0)
+    if mode == "q":      # unorm16 of sqrt(x/6): step 12 sqrt(x/6) / 65535 -- relative precision for small values
+        u = torch.round(torch.sqrt(torch.clamp(x, 0.0, 6.0) / 6.0) * 65535.0) / 65535.0
+        return u * u * 6.0
     raise ValueError(mode)
 
 
@@ -159,6 +162,9 @@ def main():
     mode = sys.argv[1] if len(sys.argv) > 1 else "baseline"
     nfr = int(os.environ.get("NFRAMES", "4"))
     W = synthetic_weights(1234)
+    if os.environ.get("SPREAD"):    # per-channel scales spread over that many decades (watsor_amd/synth.py: spread_channel_scales)
+        from watsor_amd.synth import spread_channel_scales
+        W = spread_channel_scales(W, float(os.environ["SPREAD"]), int(os.environ.get("SPREAD_SEED", "77")))
     net = Net(W)
     x = frames_input(nfr)
     ref, _ = net.forward(x, {})

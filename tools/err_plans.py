@@ -91,3 +91,35 @@ for n in range(2, 17):
     PLANS["hp%d" % n] = hp(n)
     PLANS["hp%dh" % n] = hp(n, dw_in="h")
     PLANS["hp%dx" % n] = hp(n, dw_in="x")
+    PLANS["hp%dq" % n] = hp(n, dw_in="q")
+
+
+def hp_tail(n, exp=("h", "h", "h"), dep=("h", "h", "h"), pro=("h", "h", "h"), dw_in="x", rest=("h", "h", "h")):
+    """hp(n) in front (with an exact depthwise input by default), blocks n+1 .. 16 with the given (weights, MFMA input, stored output)
+    triples per layer kind, `rest` for Conv_1 / extras / heads -- to find which operand of the plain-fp16 tail decides the error."""
+    front = hp(n, dw_in=dw_in)
+
+    def plan(spec, groups):
+        cfg = front(spec, groups)
+        for lab, names in groups.items():
+            i = _idx(lab)
+            for nm in names:
+                if i is not None and i > n:
+                    cfg[nm] = {"exp": exp, "dep": dep, "pro": pro}[lab[4:]]
+                elif i is None and lab != "stem":
+                    cfg[nm] = rest
+        return cfg
+    return plan
+
+
+X, H, S = ("x", "x", "x"), ("h", "h", "h"), ("s", "s", "s")
+PLANS["t_all_x"] = hp_tail(12, X, X, X)                                  # tail blocks exact: what is left is Conv_1 / extras / heads
+PLANS["t_w"] = hp_tail(12, ("h", "x", "x"), ("h", "x", "x"), ("h", "x", "x"))   # only the tail's weights rounded
+PLANS["t_a"] = hp_tail(12, ("x", "h", "x"), ("x", "h", "x"), ("x", "h", "x"))   # only its MFMA / depthwise inputs
+PLANS["t_o"] = hp_tail(12, ("x", "x", "h"), ("x", "x", "h"), ("x", "x", "h"))   # only its stored outputs
+PLANS["t_exp"] = hp_tail(12, H, X, X)
+PLANS["t_dep"] = hp_tail(12, X, H, X)
+PLANS["t_pro"] = hp_tail(12, X, X, H)
+PLANS["t_rest_x"] = hp_tail(12, H, H, H, rest=X)
+PLANS["t_dep_in"] = hp_tail(12, X, ("x", "h", "x"), X)                   # the expanded tensor as fp16 in front of the depthwise conv
+PLANS["t_pro_in"] = hp_tail(12, X, X, ("x", "h", "x"))                   # the depthwise output as fp16 in front of the project conv

@@ -18,6 +18,7 @@ WZ_OK, WZ_EINVAL, WZ_ENOENT, WZ_EFORMAT, WZ_EHIP, WZ_ENODEV, WZ_ELIMIT = 0, -1, 
 WZ_SLOTS = 8
 WZ_FMT_RGB24, WZ_FMT_NV12, WZ_FMT_I420 = 0, 1, 2
 WZ_NUM_LABELS = 91
+WZ_MAX_CAMS = 256
 
 c_u8p = C.POINTER(C.c_uint8)
 c_i32p = C.POINTER(C.c_int32)
@@ -46,6 +47,9 @@ SIGNATURES = {
     "wz_host_register": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "wz_host_unregister": (C.c_int, [C.c_void_p, C.c_void_p]),
     "wz_collect": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "wz_bind_frames": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), c_i32p, c_i32p, c_i32p, c_i32p, C.POINTER(C.c_void_p)]),
+    "wz_submit_bound": (C.c_int, [C.c_void_p, C.c_int, C.c_int, c_i32p]),
+    "wz_collect_bound": (C.c_int, [C.c_void_p, C.c_int]),
     "wz_wait": (C.c_int, [C.c_void_p, C.c_int]),
     "wz_slot_rows": (C.c_void_p, [C.c_void_p, C.c_int]),
     "wz_sync": (C.c_int, [C.c_void_p]),

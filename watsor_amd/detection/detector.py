@@ -24,8 +24,12 @@ differences, all inside the worker process:
     filter-less `HipTrackFilter()` expects;
   * exactly one `frame.latch.next()` per dequeued payload (`detector.py:111-112`), in `finally`, like the reference; a
     batch that fails is retried frame by frame so that one bad frame does not take its neighbours' detections with it;
-  * `inference_time` receives the per-frame share of a batch's time (ms / n): the reference's `/metrics` derives
-    `fps_max = 1000 / inference_time` from it (`watsor/main.py:242-251`).
+  * `inference_time` receives the per-frame share of a batch's SERVICE time (submit, or the previous retirement if later,
+    to collect; ms / n), one observation per batch or per 5 ms of batches: the reference's `/metrics` derives
+    `fps_max = 1000 / inference_time` from it (`watsor/main.py:242-251`) and the gauge is a mean over its observations
+    (`watsor/stream/share.py:225-238`);
+  * with `HipObjectDetector` every Frame of every FrameBuffer is described to the engine once (`wz_bind_frames`), so a
+    batch costs the worker one call with a list of table indices and one call to collect.
 
 This module needs the reference package (`watsor.stream`) at run time -- it is a drop-in for an
 installed Watsor, see INTEGRATION.md.  Everything below `detect_batch()` does not.
@@ -62,14 +66,22 @@ def _require_watsor():
 
 class BatchedWorkerMixin:
     """The batching / camera-binding / asynchronous logic of the worker, independent of the reference's base class
-    (tests drive it with stand-ins for `Frame` / `FrameBuffer` where no Watsor is installed, e.g. on the GPU box)."""
+    (tests drive it with stand-ins for `Frame` / `FrameBuffer` where no Watsor is installed, e.g. on the GPU box).
+
+    Per dequeued payload the worker itself does one dictionary lookup and two list appends: with a detector that offers
+    `bind_frame_table` (HipObjectDetector) every Frame is described to the engine once, a batch is a list of table indices
+    handed over in ONE call (`submit_bound`), the rows land in the frames' own headers in ONE call (`collect_bound`).  What is
+    left per frame is the reference runtime's own: `Queue.get`, `latch.next()`, `fps(value=True)`."""
 
     # -- per-process state, created on the first _process() call inside the worker ------------------------------
     def _hip_state(self, frame_buffers, object_detector, kwargs):
         st = getattr(self, "_hip_worker_state", None)
         if st is not None and st["detector"] is object_detector:
             return st
-        st = dict(detector=object_detector, inflight=deque(), next_lane=0, cams=None, lanes=1, asynchronous=False)
+        st = dict(detector=object_detector, inflight=deque(), next_lane=0, cams=None, lanes=1, asynchronous=False, table=None,
+                  limit=getattr(object_detector, "max_batch", 1) if hasattr(object_detector, "detect_batch") else 1,
+                  last_retire=0.0, acc_ms=0.0, acc_frames=0, last_flush=0.0,
+                  metric_interval=float(kwargs.get("hip_metric_interval", 0.005)))
         bind = getattr(object_detector, "bind_cameras", None)
         if bind is not None:
             st["cams"] = bind(frame_buffers, kwargs.get("hip_cameras"), bool(kwargs.get("hip_drop", False)),
@@ -77,36 +89,42 @@ class BatchedWorkerMixin:
         if hasattr(object_detector, "submit_host") and hasattr(object_detector, "collect"):
             st["asynchronous"] = kwargs.get("hip_async", True)
             st["lanes"] = max(1, min(int(kwargs.get("hip_lanes", 2)), getattr(object_detector, "num_lanes", 1)))
+        if st["asynchronous"] and kwargs.get("hip_frame_table", True) and hasattr(object_detector, "bind_frame_table"):
+            try:
+                st["table"] = object_detector.bind_frame_table(frame_buffers, st["cams"] or {})
+            except ValueError as e:               # a frame buffer the engine cannot take: per-batch descriptions, which skip only its frames
+                self._warn("frame table not bound (%s): frames are described per batch" % (e,))
         self._hip_worker_state = st
         return st
 
     def _process(self, frame_queue, stop_event, frame_buffers, fps, inference_time, object_detector, *args, **kwargs):
-        st = self._hip_state(frame_buffers, object_detector, kwargs)
+        st = getattr(self, "_hip_worker_state", None)
+        if st is None or st["detector"] is not object_detector:
+            st = self._hip_state(frame_buffers, object_detector, kwargs)
+        inflight = st["inflight"]
         payloads = []
         try:
             # block for a frame only when nothing is in flight: a batch on the GPU is retired as soon as the queue runs dry
-            first = frame_queue.get(timeout=1) if not st["inflight"] else frame_queue.get_nowait()
+            first = frame_queue.get(timeout=1) if not inflight else frame_queue.get_nowait()
             if first is not None:
                 payloads.append(first)
+                get_nowait, limit = frame_queue.get_nowait, st["limit"]
+                while len(payloads) < limit:
+                    nxt = get_nowait()
+                    if nxt is not None:
+                        payloads.append(nxt)
         except Empty:
             pass
-        if payloads and hasattr(object_detector, "detect_batch"):
-            limit = getattr(object_detector, "max_batch", 1)
-            while len(payloads) < limit:
-                try:
-                    nxt = frame_queue.get_nowait()
-                except Empty:
-                    break
-                if nxt is not None:
-                    payloads.append(nxt)
         if payloads:
             if st["asynchronous"]:
                 self._submit_frames(st, payloads, frame_buffers, fps, inference_time, object_detector)
             else:
                 self._next_frames(payloads, stop_event, frame_buffers, fps, inference_time, object_detector, st)
-        if st["inflight"] and (not payloads or len(st["inflight"]) >= st["lanes"]):
+        if inflight and (not payloads or len(inflight) >= st["lanes"]):
             self._retire_oldest(st, fps, inference_time, object_detector)
         elif not payloads:
+            if st["acc_frames"]:
+                self._observe(st, inference_time, 0.0, 0, perf_counter(), flush=True)
             return self._no_frame(stop_event, frame_buffers, fps, inference_time, object_detector, *args, **kwargs)
 
     # -- synchronous path (any plugin with detect(); detect_batch() when it has one) --------------------------------
@@ -116,6 +134,8 @@ class BatchedWorkerMixin:
         out = []
         for p in payloads:
             try:
+                if p.frame_index < 0:
+                    raise IndexError(p.frame_index)
                 out.append((p, frame_buffers[p.sender].frames[p.frame_index]))
             except (KeyError, IndexError, TypeError):
                 self._warn("payload of unknown sender / frame %r dropped" % (p,))
@@ -177,36 +197,74 @@ class BatchedWorkerMixin:
 
     # -- asynchronous path: submit now, retire later ------------------------------------------------------------------
     def _submit_frames(self, st, payloads, frame_buffers, fps, inference_time, object_detector):
-        resolved = self._resolve(payloads, frame_buffers)
-        if not resolved:
+        table = st["table"]
+        frames = None
+        if table is not None:
+            # bound frames: payload -> table index; nothing of the frame itself is touched here
+            kept, entries, latches = [], [], []
+            for p in payloads:
+                try:
+                    base, nexts = table[p.sender]
+                    i = p.frame_index
+                    if i < 0:
+                        raise IndexError(i)
+                    latches.append(nexts[i])
+                    entries.append(base + i)
+                    kept.append(p)
+                except (KeyError, IndexError, TypeError):
+                    self._warn("payload of unknown sender / frame %r dropped" % (p,))
+            payloads = kept
+        else:
+            resolved = self._resolve(payloads, frame_buffers)
+            payloads = [p for p, _ in resolved]
+            frames = [f for _, f in resolved]
+            latches = [f.latch.next for f in frames]
+        if not payloads:
             return
-        payloads = [p for p, _ in resolved]
-        frames = [f for _, f in resolved]
         try:
-            images = [f.get_numpy_image(uint8)[1] for f in frames]
             lane = st["next_lane"]
             t0 = perf_counter()
-            object_detector.submit_host(lane, images, self._camera_ids(st, payloads))
+            if frames is None:
+                object_detector.submit_bound(lane, entries)
+            else:
+                object_detector.submit_host(lane, [f.get_numpy_image(uint8)[1] for f in frames], self._camera_ids(st, payloads))
         except Exception as e:                    # nothing was enqueued for this batch: synchronous retry, frame by frame
             self._warn("asynchronous submit of %d frames failed (%s), falling back to synchronous calls" % (len(payloads), e))
             # (the lane this batch would have used may still hold an older batch: retire everything first, in order)
             while st["inflight"]:
                 self._retire_oldest(st, fps, inference_time, object_detector)
             return self._next_frames(payloads, None, frame_buffers, fps, inference_time, object_detector, st)
-        st["inflight"].append((lane, frames, t0))
+        st["inflight"].append((lane, latches, t0, frames))
         st["next_lane"] = (lane + 1) % st["lanes"]
 
     def _retire_oldest(self, st, fps, inference_time, object_detector):
-        lane, frames, t0 = st["inflight"].popleft()
+        lane, latches, t0, frames = st["inflight"].popleft()
         try:
-            object_detector.collect(lane, [f.header.detections for f in frames])
-            ms = (perf_counter() - t0) * 1000.0
-            for _ in frames:
-                inference_time(value=ms / len(frames))
+            if frames is None:
+                object_detector.collect_bound(lane)
+            else:
+                object_detector.collect(lane, [f.header.detections for f in frames])
+            now = perf_counter()
+            # the batch's SERVICE time: from its submit, or from the previous retirement when it was queued behind another
+            # lane's batch until then -- what `fps_max = 1000 / inference_time` (watsor/main.py:242-251) should be derived from
+            self._observe(st, inference_time, (now - max(t0, st["last_retire"])) * 1000.0, len(latches), now)
+            st["last_retire"] = now
+            for _ in latches:
                 fps(value=True)
         finally:
-            for f in frames:
-                f.latch.next()
+            for step in latches:                  # one latch step per dequeued payload, whatever happened above
+                step()
+
+    @staticmethod
+    def _observe(st, inference_time, ms, n, now, flush=False):
+        """`inference_time` is a mean over its observations (`watsor/stream/share.py:225-238` -- a Python loop over 100 shared
+        cells per call, ~120 us): n frames of one batch would be n identical observations, and back-to-back batches are folded
+        into one observation of their mean per `hip_metric_interval` seconds (default 5 ms; 0: one per batch)."""
+        st["acc_ms"] += ms
+        st["acc_frames"] += n
+        if st["acc_frames"] and (flush or now - st["last_flush"] >= st["metric_interval"]):
+            inference_time(value=st["acc_ms"] / st["acc_frames"])
+            st["acc_ms"], st["acc_frames"], st["last_flush"] = 0.0, 0, now
 
     def drain(self, fps=None, inference_time=None):
         """Retire everything still in flight (worker shutdown)."""
@@ -214,6 +272,8 @@ class BatchedWorkerMixin:
         noop = lambda **kw: None                                                  # noqa: E731
         while st is not None and st["inflight"]:
             self._retire_oldest(st, fps or noop, inference_time or noop, st["detector"])
+        if st is not None and st["acc_frames"]:
+            self._observe(st, inference_time or noop, 0.0, 0, perf_counter(), flush=True)
 
 
 def _batched_object_detector():
@@ -256,7 +316,9 @@ def hip_detector_options(frame_buffers, kwargs):
     for fb in frame_buffers.values():
         for frame in fb.frames[:1]:
             widths.append(int(frame.header.width))
-            heights.append(int(frame.header.height))
+            # a one-"channel" buffer holds the (H * 3 / 2, W) bytes of an NV12 / yuv420p picture: the engine is sized for H
+            planar = int(frame.header.channels) == 1 and int(frame.header.height) % 3 == 0
+            heights.append(int(frame.header.height) // 3 * 2 if planar else int(frame.header.height))
     if widths:
         opts.setdefault("max_width", max(widths))
         opts.setdefault("max_height", max(heights))
@@ -274,7 +336,9 @@ def create_object_detectors(delegate_class, stop_event, log_queue, frame_queue, 
       hip_drop     True: rows failing those filters come back as all-zero rows (for `hip_detection_sieve()`)
       hip_options  dict(max_batch=, max_width=, max_height=) overriding what is derived from the frame buffers;
                    pixel_format= "rgb24" | "nv12" | "yuv420p" (or {camera name: ...}): what the decoders write (hip_gpu.py)
-      hip_lanes    batches kept in flight per GPU by the worker (default 2)"""
+      hip_lanes    batches kept in flight per GPU by the worker (default 2)
+      hip_metric_interval  seconds of batches folded into one `inference_time` observation (default 0.005; 0: one per batch)
+      hip_frame_table      False: describe the frames of every batch to the engine instead of binding them once"""
     _ref = _require_watsor()
     detectors = []
     if kwargs is None:

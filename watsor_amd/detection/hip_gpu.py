@@ -115,14 +115,22 @@ class HipObjectDetector:
         return self.__engine.num_slots
 
     def bind_cameras(self, frame_buffers, camera_configs=None, drop: bool = False, logger=None):
-        """Called once in the worker process.  Gives every camera (key of `frame_buffers`) an id, registers the GPU
-        filters of the cameras whose (normalised) configuration is given -- `HipCameraFilter`, i.e. the reference's
-        ConfidenceFilter / AreaFilter / MaskFilter constructors (`watsor/filter/{confidence,area,mask}.py`) -- and
-        page-locks every `Frame.image` array (`watsor/stream/share.py:35-41`) so that `submit_host` moves pixels by DMA.
-        Returns {camera name: id}."""
+        """Called once in the worker process.  Gives an id to every camera (key of `frame_buffers`) that needs one -- a
+        configured GPU filter or a pixel format of its own; the others are -1, "no camera", so that any number of plain
+        cameras fits beside the engine's 256 filter slots -- registers the GPU filters of the cameras whose (normalised)
+        configuration is given -- `HipCameraFilter`, i.e. the reference's ConfidenceFilter / AreaFilter / MaskFilter
+        constructors (`watsor/filter/{confidence,area,mask}.py`) -- and page-locks every `Frame.image` array
+        (`watsor/stream/share.py:35-41`) so that frames travel without a host-side copy.  Returns {camera name: id}."""
         from ..filter.hip_filter import HipCameraFilter
-        ids = {name: i for i, name in enumerate(sorted(frame_buffers, key=str))}
-        self.__fmt_by_cam = {i: self.__fmt_by_name.get(str(name), self.__fmt_default) for name, i in ids.items()}
+        from .._lib import WZ_MAX_CAMS
+        names = sorted(frame_buffers, key=str)
+        need = [n for n in names if n in (camera_configs or {}) or str(n) in self.__fmt_by_name]
+        if len(need) > WZ_MAX_CAMS:
+            raise ValueError("%d cameras with GPU filters / pixel formats of their own on one detector: the engine has %d slots"
+                             % (len(need), WZ_MAX_CAMS))
+        ids = {name: -1 for name in names}
+        ids.update({name: i for i, name in enumerate(need)})
+        self.__fmt_by_cam = {i: self.__fmt_by_name.get(str(name), self.__fmt_default) for name, i in ids.items() if i >= 0}
         for name, cfg in (camera_configs or {}).items():
             if name in ids:
                 self.__filters.append(HipCameraFilter(self.__engine, ids[name], cfg, drop=drop))
@@ -138,6 +146,45 @@ class HipObjectDetector:
                     if logger is not None:
                         logger.warning("frame memory at 0x%x could not be page-locked: %s" % (addr, e))
         return ids
+
+    def bind_frame_table(self, frame_buffers, ids):
+        """Called once in the worker process, after `bind_cameras`: describes every Frame of every FrameBuffer to the engine
+        (`wz_bind_frames`: pixels, size, pixel format, camera id, the address of `header.detections`) -- what the reference
+        worker looks up and rebuilds per payload (`watsor/detection/detector.py:104-106`, `share.py:68-73`) never changes
+        after the buffers exist.  Returns {camera name: (index of its frame 0 in the table, [frame.latch.next, ...])}."""
+        import ctypes
+        pix, ws, hs, fmts, cams, rows, table = [], [], [], [], [], [], {}
+        yuv = next((f for f in [self.__fmt_default] + list(self.__fmt_by_cam.values()) if f != FMT_RGB24), FMT_NV12)
+        for name in sorted(frame_buffers, key=str):
+            cam = ids.get(name, -1)
+            fmt0 = self.__fmt_by_cam.get(cam, self.__fmt_default) if cam >= 0 else self.__fmt_default
+            latches = []
+            table[name] = (len(pix), latches)
+            for frame in frame_buffers[name].frames:
+                hdr = frame.header.get_obj() if hasattr(frame.header, "get_obj") else frame.header
+                obj = frame.image.get_obj() if hasattr(frame.image, "get_obj") else frame.image
+                w, h, fmt = int(hdr.width), int(hdr.height), fmt0
+                if fmt == FMT_RGB24 and int(hdr.channels) == 1:      # a planar buffer read as RGB24: the configured YUV format
+                    fmt = yuv
+                if fmt != FMT_RGB24:                                 # (H * 3 / 2, W) bytes of a W x H picture
+                    if int(hdr.channels) != 1 or h % 3 or w % 2 or (h // 3 * 2) % 2:
+                        raise ValueError("camera %r: an NV12 / I420 frame buffer must be (H*3/2, W, 1) with even H and W" % (name,))
+                    h = h // 3 * 2
+                elif int(hdr.channels) != 3:
+                    raise ValueError("camera %r: an RGB24 frame buffer must have 3 channels" % (name,))
+                if ctypes.sizeof(obj) < (w * h * 3 if fmt == FMT_RGB24 else w * h * 3 // 2):
+                    raise ValueError("camera %r: frame memory smaller than its header says" % (name,))
+                pix.append(ctypes.addressof(obj))
+                ws.append(w)
+                hs.append(h)
+                fmts.append(fmt)
+                cams.append(cam)
+                rows.append(ctypes.addressof(hdr.detections))
+                latches.append(frame.latch.next)
+        self.__engine.bind_frames(pix, ws, hs, fmts, cams, rows)
+        self.submit_bound = self.__engine.submit_bound      # (the worker calls these once per batch: no wrapper frames in between)
+        self.collect_bound = self.__engine.collect_bound
+        return table
 
     def submit_host(self, lane: int, images: Sequence[np.ndarray], cameras: Optional[Sequence[int]] = None) -> None:
         """Asynchronous `detect_batch`: the frames (views of shared memory, unchanged until `collect`) are enqueued on `lane`."""

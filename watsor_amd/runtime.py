@@ -174,6 +174,34 @@ class HipEngine:
     def host_unregister_address(self, address: int) -> None:
         _lib.check(self._lib.wz_host_unregister(self._h, C.c_void_p(address)))
 
+    # -- the worker's frame table (include/watsor_hip.h: wz_bind_frames) ----------------------------
+    def bind_frames(self, pixel_addresses: Sequence[int], widths: Sequence[int], heights: Sequence[int],
+                    formats: Sequence[int], cams: Sequence[int], row_addresses: Sequence[int]) -> None:
+        """Describe every frame of every frame buffer once: entry i = (address of its pixels, width, height, WZ_FMT_*, camera id
+        or -1, address of its `Detection[100]` rows).  Replaces the previous table."""
+        n = len(pixel_addresses)
+        _lib.check(self._lib.wz_bind_frames(
+            self._h, n, (C.c_void_p * n)(*pixel_addresses), (C.c_int32 * n)(*widths), (C.c_int32 * n)(*heights),
+            (C.c_int32 * n)(*[int(f) for f in formats]), (C.c_int32 * n)(*[int(c) for c in cams]),
+            (C.c_void_p * n)(*row_addresses)))
+        self._bound_arrays = {}
+
+    def submit_bound(self, slot: int, entries: Sequence[int]) -> None:
+        """Asynchronous detect of the frames with these table indices on lane `slot` (one C call, no per-frame work here)."""
+        n = len(entries)
+        arr_t = self._bound_arrays.get(n)
+        if arr_t is None:
+            arr_t = self._bound_arrays[n] = C.c_int32 * n
+        rc = self._lib.wz_submit_bound(self._h, slot, n, arr_t(*entries))
+        if rc:
+            _lib.check(rc)
+
+    def collect_bound(self, slot: int) -> None:
+        """Waits for lane `slot`; its rows are written into the bound frames' own `Detection[100]` arrays."""
+        rc = self._lib.wz_collect_bound(self._h, slot)
+        if rc:
+            _lib.check(rc)
+
     def collect(self, slot: int, out_rows: Sequence, out_pass: Optional[Sequence[np.ndarray]] = None) -> None:
         n = len(out_rows)
         outs = (C.c_void_p * n)(*[self._addr(r) for r in out_rows])

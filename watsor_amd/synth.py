@@ -16,7 +16,10 @@ import numpy as np
 from . import arch
 
 
-def synthetic_weights(seed: int = 1234, program: "arch.Program | None" = None) -> Dict[str, np.ndarray]:
+def synthetic_weights(seed: int = 1234, program: "arch.Program | None" = None, class_gain: float = 1.0) -> Dict[str, np.ndarray]:
+    """class_gain > 1 widens the class logits (the ClassPredictor weights are scaled after the draw, so every other tensor is
+    that of class_gain = 1): 1.3 gives ~800 scores above 0.3 per frame in ~25 classes -- a busy scene for the NMS kernel --
+    against ~170 in 4 classes (bench.py's `busy_scene` leg)."""
     prog = program or arch.build(fuse=False)   # one op per layer: the draw order of the RNG is part of the seed
     rng = np.random.Generator(np.random.PCG64(seed))
     W: Dict[str, np.ndarray] = {}
@@ -59,7 +62,59 @@ def synthetic_weights(seed: int = 1234, program: "arch.Program | None" = None) -
             else:
                 b = normal((op.cout,), 0.05)
             W[op.scope + "/biases"] = b.astype(np.float32)
+    if class_gain != 1.0:
+        for k in W:
+            if k.endswith("ClassPredictor/weights"):
+                W[k] = (W[k] * np.float32(class_gain)).astype(np.float32)
     return W
+
+
+def spread_channel_scales(W: Dict[str, np.ndarray], decades: float = 2.5, seed: int = 77) -> Dict[str, np.ndarray]:
+    """A copy of `W` (MobileNet-v2 backbone variables) whose per-channel dynamic ranges are spread over `decades` decades, the
+    way folding a TRAINED network's BatchNorm spreads them -- He-initialised weights keep every channel of a tensor at the same
+    scale, which flatters fixed-point and fp16 storage.  Three families of per-channel factors in
+    (10^-decades, 1], drawn log-uniformly:
+      * the expanded tensor (expand conv's / the stem's BatchNorm gamma and beta times a_c, the depthwise filter of channel c
+        divided by a_c -- exactly what a BatchNorm behind the depthwise conv does to a small-amplitude input channel);
+      * the depthwise output (its BatchNorm gamma and beta times a'_c, row c of the project weights divided by a'_c);
+      * the bottleneck tensors (project BatchNorm gamma and beta times s_c, row c of the consumers' weights divided by s_c; one
+        s per residual stage, so the skip connections still add like with like).
+    Apart from where ReLU6 clips, the network computes the same function; it is simply another random network."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    W = {k: v.copy() for k, v in W.items()}
+    fe = arch.FE
+
+    def factors(c):
+        return np.power(10.0, -decades * rng.random(c)).astype(np.float32)
+
+    def scale_bn(scope, f):
+        W[scope + "/BatchNorm/gamma"] = W[scope + "/BatchNorm/gamma"] * f
+        W[scope + "/BatchNorm/beta"] = W[scope + "/BatchNorm/beta"] * f
+
+    idx = 0
+    prev_scale = None           # factors of the tensor the next expand conv reads
+    for t, c, n, stride in arch._INVERTED_RESIDUAL:
+        s_stage = factors(c)
+        for j in range(n):
+            name = fe + arch._blk(idx)
+            mid = W[name + "/depthwise/depthwise_weights"].shape[2]
+            if t != 1:
+                if prev_scale is not None:
+                    W[name + "/expand/weights"] = W[name + "/expand/weights"] / prev_scale[None, None, :, None]
+                a = factors(mid)
+                scale_bn(name + "/expand", a)
+            else:                       # block 0: the depthwise conv reads the stem's output
+                a = factors(mid)
+                scale_bn(fe + "Conv", a)
+            W[name + "/depthwise/depthwise_weights"] = W[name + "/depthwise/depthwise_weights"] / a[None, None, :, None]
+            a2 = factors(mid)
+            scale_bn(name + "/depthwise", a2)
+            W[name + "/project/weights"] = W[name + "/project/weights"] / a2[None, None, :, None]
+            scale_bn(name + "/project", s_stage)
+            prev_scale = s_stage
+            idx += 1
+    W[fe + "Conv_1/weights"] = W[fe + "Conv_1/weights"] / prev_scale[None, None, :, None]
+    return {k: v.astype(np.float32) for k, v in W.items()}
 
 
 def synthetic_frame(width: int, height: int, seed: int, n_shapes: int = 4) -> np.ndarray:
