@@ -113,9 +113,8 @@ int wz_collect(wz_engine_t* e, int slot, wz_detection_t* const* out, uint8_t* co
  * (watsor/detection/detector.py:102-109); pixels, size and rows of a Frame never move after the FrameBuffers are created
  * (watsor/stream/share.py:27-41,76-81).  So they are described ONCE (entry i = one Frame: pixels, w, h, WZ_FMT_*, camera id or
  * -1, its rows), a batch is then n table indices, and the rows land in the frames' own headers.  fmt / cam may be NULL (RGB24 /
- * no camera).  Entries whose pixels lie inside a wz_host_register()ed range are pulled into HBM by one kernel per batch
- * (csrc/k_preprocess.hip: wz_k_stage_frames, part of the lane's captured graph) instead of one copy per frame; the others
- * are copied as wz_submit_host copies them.  wz_bind_frames replaces the whole table (waits for the lanes first). */
+ * no camera).  The pixels travel as wz_submit_host moves them (one copy per frame on the lane's stream: DMA from
+ * wz_host_register()ed memory).  wz_bind_frames replaces the whole table (waits for the lanes first). */
 int wz_bind_frames(wz_engine_t* e, int n, const uint8_t* const* pixels, const int* w, const int* h, const int* fmt,
                    const int* cam, wz_detection_t* const* rows);
 int wz_submit_bound(wz_engine_t* e, int slot, int n, const int32_t* entries);

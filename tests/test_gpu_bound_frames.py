@@ -1,6 +1,5 @@
 """The worker's frame table on the GPU (`wz_bind_frames` / `wz_submit_bound` / `wz_collect_bound`, include/watsor_hip.h): frames
-described once, batches as table indices, pixels pulled out of page-locked host memory by the batch's first kernel
-(`wz_k_stage_frames`) -- rows bit-identical to the synchronous `detect_batch` of the same frames, whatever the alignment of
+described once, batches as table indices -- rows bit-identical to the synchronous `detect_batch` of the same frames, whatever the alignment of
 the frame memory and whether it is page-locked or not."""
 import numpy as np
 import pytest

@@ -12,7 +12,7 @@ import os
 from .share import Detection
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwatsor_hip.so")
+LIB_PATH = os.environ.get("WATSOR_HIP_LIBRARY") or os.path.join(_HERE, "libwatsor_hip.so")   # (the variable: measurement builds, tools/)
 
 WZ_OK, WZ_EINVAL, WZ_ENOENT, WZ_EFORMAT, WZ_EHIP, WZ_ENODEV, WZ_ELIMIT = 0, -1, -2, -3, -4, -5, -6
 WZ_SLOTS = 8

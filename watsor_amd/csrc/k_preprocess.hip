@@ -102,40 +102,6 @@ __global__ __launch_bounds__(256) void wz_k_preprocess(const WzFrameDesc* __rest
     }
 }
 
-// Host frames -> the lane's staging area in ONE launch (the worker's bound-frame path, wz_submit_bound): the frames lie in
-// page-locked host memory (`wz_host_register` of the reference's FrameBuffer arenas, watsor/stream/share.py:35-41) and are read
-// here through their device-mapped addresses with 16-byte loads, four in flight per lane -- one graph node instead of one
-// hipMemcpyAsync call (and one SDMA transfer with its own start-up) per frame.  dst is chosen congruent to src mod 16 by the
-// host (the multiprocessing heap aligns to 8), so the body is aligned on both sides; head and tail bytes go one by one.
-// A descriptor with src == nullptr is a frame that was staged by a copy (pageable memory): skipped.
-__global__ __launch_bounds__(256) void wz_k_stage_frames(const WzStageDesc* __restrict__ st) {
-    const WzStageDesc d = st[blockIdx.y];
-    if (!d.src) return;
-    const unsigned long long s0 = (unsigned long long)d.src;
-    unsigned long long head = (16 - (s0 & 15)) & 15;
-    if (head > d.bytes) head = d.bytes;
-    const unsigned long long body = (d.bytes - head) >> 4, tail = d.bytes - head - (body << 4);
-    if (blockIdx.x == 0) {
-        if (threadIdx.x < head) d.dst[threadIdx.x] = d.src[threadIdx.x];
-        if (threadIdx.x < tail) d.dst[head + (body << 4) + threadIdx.x] = d.src[head + (body << 4) + threadIdx.x];
-    }
-    typedef __attribute__((ext_vector_type(4))) unsigned int u4;
-    const u4* __restrict__ s = reinterpret_cast<const u4*>(d.src + head);
-    u4* __restrict__ t = reinterpret_cast<u4*>(d.dst + head);
-    const unsigned long long stride = (unsigned long long)gridDim.x * 256;
-    unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < body; i += 4 * stride) {
-        const u4 a = __builtin_nontemporal_load(s + i), b = __builtin_nontemporal_load(s + i + stride);
-        const u4 c = __builtin_nontemporal_load(s + i + 2 * stride), e = __builtin_nontemporal_load(s + i + 3 * stride);
-        t[i] = a; t[i + stride] = b; t[i + 2 * stride] = c; t[i + 3 * stride] = e;
-    }
-    for (; i < body; i += stride) t[i] = __builtin_nontemporal_load(s + i);
-}
-
-void wz_launch_stage_frames(const WzStageDesc* st, int n, int wgs_per_frame, hipStream_t s) {
-    WZ_LAUNCH(wz_k_stage_frames, dim3(wgs_per_frame, n), dim3(256), 0, s, st);
-}
-
 void wz_launch_preprocess(const WzFrameDesc* d_frames, int n, int size, half_t* out, hipStream_t s, bool hp, WzFrameDesc* keep) {
     dim3 grid((size * size + 255) / 256, n);
     if (hp)

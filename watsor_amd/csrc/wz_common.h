@@ -36,14 +36,6 @@ struct WzFrameDesc {
     int32_t fmt;              // WZ_FMT_* (include/watsor_hip.h)
 };
 
-// one frame of wz_k_stage_frames: `bytes` bytes from page-locked host memory (device-mapped address) into the staging area
-struct WzStageDesc {
-    const uint8_t* src;   // nullptr: nothing to do for this frame
-    uint8_t* dst;         // congruent to src mod 16
-    uint64_t bytes;
-    uint64_t pad_;
-};
-
 struct WzConvArgs {
     const half_t* in;
     const half_t* w;
@@ -145,7 +137,6 @@ extern thread_local int wz_launch_repeat;
 // hp: the input tensor is a hi + lo pair (8 halves per pixel: r g b 0 | r g b 0)
 void wz_launch_preprocess(const WzFrameDesc* d_frames, int n, int size, half_t* out, hipStream_t s, bool hp = false,
                           WzFrameDesc* keep = nullptr);   // keep: see k_preprocess.hip
-void wz_launch_stage_frames(const WzStageDesc* st, int n, int wgs_per_frame, hipStream_t s);   // k_preprocess.hip
 void wz_launch_stem(const half_t* in, const float* w, const float* bias, half_t* out, int n, int hin, int win,
                     int hout, int wout, int pad_t, int pad_l, hipStream_t s);
 void wz_launch_dw(const half_t* in, const half_t* w, const float* bias, half_t* out, int n, int hin, int win,

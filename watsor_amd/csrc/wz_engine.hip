@@ -127,21 +127,16 @@ struct wz_engine {
         uint8_t* h_pass = nullptr;
         wz_detection_t* m_rows = nullptr;    // device addresses of h_rows / h_pass
         uint8_t* m_pass = nullptr;
-        WzStageDesc* h_stage = nullptr;      // pinned: what wz_k_stage_frames copies for the batch in flight (bound-frame path)
-        WzStageDesc* h_stage_dev = nullptr;
         std::vector<int32_t> bound_idx;      // frame-table entries of the batch in flight (empty: not a bound batch)
         hipEvent_t done = nullptr;
         int n = 0;
-        std::map<int, hipGraphExec_t> graphs;    // key = batch size (+ 65536: with the staging kernel in front)
+        std::map<int, hipGraphExec_t> graphs;    // key = batch size
     };
     Lane lanes[WZ_SLOTS];
     int n_lanes = 4;   // default; WZ_LANES overrides (1..WZ_SLOTS)
     int n_streams = 4; // HIP streams the lanes are spread over (WZ_STREAMS); more than 4 run slower on this stack
 
-    // page-locked host ranges (wz_host_register) with the address the device sees them at, and the worker's frame table
-    // (wz_bind_frames): one entry per Frame of every FrameBuffer, described once instead of once per batch
-    struct HostRange { uintptr_t base; size_t bytes; uint8_t* dev; };
-    std::vector<HostRange> host_ranges;
+    // the worker's frame table (wz_bind_frames): one entry per Frame of every FrameBuffer, described once instead of once per batch
     struct BoundFrame {
         const uint8_t* host;   // the frame's pixels (host address)
         int32_t w, h, fmt, cam;
@@ -149,7 +144,6 @@ struct wz_engine {
         wz_detection_t* rows;  // Header.detections of that frame (host), written by wz_collect_bound
     };
     std::vector<BoundFrame> bound;
-    bool stage_kernel = true;  // WZ_STAGE_KERNEL=0: bound frames travel by one hipMemcpyAsync each, like wz_submit_host
 
     std::vector<WzCamFilter> h_cams;
     WzCamFilter* d_cams = nullptr;
@@ -540,10 +534,8 @@ static void enqueue_post(wz_engine* e, Lane& L, bool rows, int n, StageTimer* t,
 
 // everything between "descriptors are in h_desc[slot]" and "rows are in h_rows[slot]"
 // inner > 1 (profiling only): every kernel of the pre-processing and the network is enqueued `inner` times back to back
-static void enqueue_batch(wz_engine* e, Lane& L, int n, StageTimer* t, int inner = 1, bool stage = false) {
+static void enqueue_batch(wz_engine* e, Lane& L, int n, StageTimer* t, int inner = 1) {
     hipStream_t s = L.stream;
-    // bound frames in page-locked host memory: one kernel pulls them into the lane's staging area (k_preprocess.hip)
-    if (stage) wz_launch_stage_frames(L.h_stage_dev, n, 32, s);
     if (t) t->mark();   // "(empty)": two event records with nothing between them = the bracket's own cost
     // the descriptors: read by the resize kernel straight out of the lane's page-locked host block (and left in d_desc for the
     // kernels behind it), or -- WZ_DESC_COPY=1, and where the host block has no device address -- copied in front of it
@@ -559,26 +551,25 @@ static void enqueue_batch(wz_engine* e, Lane& L, int n, StageTimer* t, int inner
     enqueue_post(e, L, true, n, t, L.decode_fused, L.cands_listed);
 }
 
-static int run_batch(wz_engine* e, int slot, int n, bool stage = false) {
+static int run_batch(wz_engine* e, int slot, int n) {
     Lane& L = e->lanes[slot];
     if (e->use_graph) {
-        const int key = n + (stage ? 65536 : 0);
-        auto it = L.graphs.find(key);
+        auto it = L.graphs.find(n);
         if (it == L.graphs.end()) {
             hipGraph_t g = nullptr;
             HIPCHK(hipStreamBeginCapture(L.stream, hipStreamCaptureModeThreadLocal));
-            enqueue_batch(e, L, n, nullptr, 1, stage);
+            enqueue_batch(e, L, n, nullptr);
             HIPCHK(hipStreamEndCapture(L.stream, &g));
             size_t nodes = 0;
             if (hipGraphGetNodes(g, nullptr, &nodes) == hipSuccess) L.graph_nodes[n] = (int)nodes;
             hipGraphExec_t ge = nullptr;
             HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
             (void)hipGraphDestroy(g);
-            it = L.graphs.emplace(key, ge).first;
+            it = L.graphs.emplace(n, ge).first;
         }
         HIPCHK(hipGraphLaunch(it->second, L.stream));
     } else {
-        enqueue_batch(e, L, n, nullptr, 1, stage);
+        enqueue_batch(e, L, n, nullptr);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(L.done, L.stream));
@@ -714,7 +705,6 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     e->conv_wide = !((env = getenv("WZ_CONV_WIDE")) && atoi(env) == 0);
     e->desc_zero_copy = !((env = getenv("WZ_DESC_COPY")) && atoi(env) != 0);
     e->tail_fuse = (env = getenv("WZ_TAIL_FUSE")) && atoi(env) != 0;
-    e->stage_kernel = !((env = getenv("WZ_STAGE_KERNEL")) && atoi(env) == 0);
     e->wide_T = (env = getenv("WZ_WIDE_T")) ? atoi(env) : 0;
     e->wide_min_m = (env = getenv("WZ_WIDE_MIN_M")) ? atoi(env) : 1;
     {
@@ -766,7 +756,7 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     CK(hipMemset(e->d_zeros, 0, 4096));
     CK(hipMalloc((void**)&e->d_anchors, (size_t)h.num_anchors * 16));
     CK(hipMemcpy(e->d_anchors, e->blob.data() + h.anchors_off, (size_t)h.num_anchors * 16, hipMemcpyHostToDevice));
-    e->frame_stride = (((size_t)max_width * max_height * 3 + 255) & ~(size_t)255) + 256;   // + room for a source's offset within its 16 bytes
+    e->frame_stride = ((size_t)max_width * max_height * 3 + 255) & ~(size_t)255;
     CK(hipMalloc((void**)&e->d_frames, e->frame_stride * max_batch));
 
     e->pc.num_anchors = h.num_anchors;
@@ -877,11 +867,6 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
             (void)hipGetLastError();
             L.h_desc_dev = nullptr;
         }
-        CK(hipHostMalloc((void**)&L.h_stage, sizeof(WzStageDesc) * max_batch, hipHostMallocDefault));
-        if (hipHostGetDevicePointer((void**)&L.h_stage_dev, L.h_stage, 0) != hipSuccess) {
-            (void)hipGetLastError();
-            L.h_stage_dev = nullptr;
-        }
         CK(hipMalloc((void**)&L.d_desc, sizeof(WzFrameDesc) * max_batch));
         CK(hipMalloc((void**)&L.d_rows, sizeof(wz_detection_t) * WZ_MAX_DETECTIONS * max_batch));
         CK(hipMalloc((void**)&L.d_pass, (size_t)WZ_MAX_DETECTIONS * max_batch));
@@ -948,7 +933,6 @@ extern "C" void wz_destroy(wz_engine_t* e) {
         for (void* p : lp)
             if (p) (void)hipFree(p);
         if (L.h_desc) (void)hipHostFree(L.h_desc);
-        if (L.h_stage) (void)hipHostFree(L.h_stage);
         if (L.h_rows) (void)hipHostFree(L.h_rows);
         if (L.h_pass) (void)hipHostFree(L.h_pass);
         if (L.done) (void)hipEventDestroy(L.done);
@@ -1085,26 +1069,14 @@ extern "C" int wz_detect_batch_fmt(wz_engine_t* e, int n, const uint8_t* const* 
 // ------------------------------------------------------------------------------------------------
 // host frames, asynchronously: H2D of batch k+1 (DMA engine) under the kernels of batch k
 // ------------------------------------------------------------------------------------------------
-// the device-mapped address of host bytes [p, p + bytes) if they lie inside a registered range, else nullptr
-static const uint8_t* mapped_address(const wz_engine* e, const uint8_t* p, uint64_t bytes) {
-    const uintptr_t a = (uintptr_t)p;
-    for (const auto& r : e->host_ranges)
-        if (r.dev && a >= r.base && a + bytes <= r.base + r.bytes) return r.dev + (a - r.base);
-    return nullptr;
-}
-
-// Frame i of the batch going onto lane L: from page-locked memory it is left to wz_k_stage_frames (one launch per batch, in
-// the lane's graph), from pageable memory it is copied now (the runtime stages it).  Returns where the resize kernel finds it.
-static int stage_frame(wz_engine* e, Lane& L, int i, const uint8_t* host, uint64_t bytes, bool* staged, const uint8_t** where) {
-    const uint8_t* src = (e->stage_kernel && L.h_stage_dev) ? mapped_address(e, host, bytes) : nullptr;
-    uint8_t* dst = L.d_frames + e->frame_stride * i + ((uintptr_t)(src ? src : host) & 15);
-    if (src) {
-        L.h_stage[i] = {src, dst, bytes, 0};
-        *staged = true;
-    } else {
-        if (L.h_stage) L.h_stage[i] = {nullptr, dst, 0, 0};
-        HIPCHK(hipMemcpyAsync(dst, host, bytes, hipMemcpyHostToDevice, L.stream));
-    }
+// Frame i of the batch going onto lane L: one copy into the lane's staging area, on the lane's stream.  From page-locked memory
+// (wz_host_register) that is one SDMA transfer at PCIe rate; pageable memory is staged by the runtime.  (A copy KERNEL reading
+// the frames through their device-mapped addresses -- one graph node per batch instead of one call per frame -- reaches
+// 55 GB/s on its own, tools/micro/h2d_streams.hip, but only 23 GB/s beside the other lanes' kernels against the copies'
+// 29 GB/s: profiles/r03_host_path_*.)
+static int stage_frame(wz_engine* e, Lane& L, int i, const uint8_t* host, uint64_t bytes, const uint8_t** where) {
+    uint8_t* dst = L.d_frames + e->frame_stride * i;
+    HIPCHK(hipMemcpyAsync(dst, host, bytes, hipMemcpyHostToDevice, L.stream));
     *where = dst;
     return WZ_OK;
 }
@@ -1122,22 +1094,21 @@ extern "C" int wz_submit_host_fmt(wz_engine_t* e, int slot, int n, const uint8_t
     Lane& L = e->lanes[slot];
     HIPCHK(hipEventSynchronize(L.done));   // the lane's previous batch (and its reads of the staging area) drained
     if (!L.d_frames) return wz_fail(WZ_EINVAL, "wz_submit_host: lane %d has no staging area", slot);
-    bool staged = false;
     std::vector<const uint8_t*> dptr(n);
     for (int i = 0; i < n; ++i) {
         if (!rgb[i] || w[i] < 1 || h[i] < 1) return wz_fail(WZ_EINVAL, "frame %d: bad pointer or size", i);
-        if (w[i] > e->max_w || h[i] > e->max_h || (size_t)w[i] * h[i] * 3 + 256 > e->frame_stride)
+        if (w[i] > e->max_w || h[i] > e->max_h || (size_t)w[i] * h[i] * 3 > e->frame_stride)
             return wz_fail(WZ_ELIMIT, "frame %d is %dx%d, engine was created for at most %dx%d", i, w[i], h[i],
                            e->max_w, e->max_h);
         const uint64_t bytes = wz_frame_bytes(w[i], h[i], fmt ? fmt[i] : WZ_FMT_RGB24);
         if (!bytes) return wz_fail(WZ_EINVAL, "frame %d: pixel format %d at %dx%d (NV12 / I420 need even sides)", i, fmt[i], w[i], h[i]);
-        // pageable source: the runtime stages it (slow, synchronous); registered / pinned source: pulled in by the batch's first kernel
-        int rc = stage_frame(e, L, i, rgb[i], bytes, &staged, &dptr[i]);
+        // pageable source: the runtime stages it (slow, synchronous); registered / pinned source: one DMA
+        int rc = stage_frame(e, L, i, rgb[i], bytes, &dptr[i]);
         if (rc != WZ_OK) return rc;
     }
     int rc = fill_desc(e, slot, n, dptr.data(), w, h, fmt, cam);
     if (rc != WZ_OK) return rc;
-    return run_batch(e, slot, n, staged);
+    return run_batch(e, slot, n);
 }
 
 // Page-lock a host range (e.g. a FrameBuffer arena, watsor/stream/share.py:35-41) so that frames inside it go to
@@ -1146,24 +1117,12 @@ extern "C" int wz_host_register(wz_engine_t* e, void* ptr, uint64_t bytes) {
     if (!e || !ptr || !bytes) return wz_fail(WZ_EINVAL, "wz_host_register: bad argument");
     HIPCHK(hipSetDevice(e->device));
     HIPCHK(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
-    void* dev = nullptr;   // where kernels see the range (wz_k_stage_frames reads bound frames through it); none: copies only
-    if (hipHostGetDevicePointer(&dev, ptr, 0) != hipSuccess) {
-        (void)hipGetLastError();
-        dev = nullptr;
-    }
-    e->host_ranges.push_back({(uintptr_t)ptr, (size_t)bytes, (uint8_t*)dev});
     return WZ_OK;
 }
 extern "C" int wz_host_unregister(wz_engine_t* e, void* ptr) {
     if (!e || !ptr) return wz_fail(WZ_EINVAL, "wz_host_unregister: bad argument");
     HIPCHK(hipSetDevice(e->device));
-    for (size_t i = 0; i < e->host_ranges.size(); ++i)
-        if (e->host_ranges[i].base == (uintptr_t)ptr) {
-            // a batch in flight may still be reading the range through its mapped address
-            (void)sync_all(e);
-            e->host_ranges.erase(e->host_ranges.begin() + i);
-            break;
-        }
+    (void)sync_all(e);   // a copy in flight may still be reading the range
     HIPCHK(hipHostUnregister(ptr));
     return WZ_OK;
 }
@@ -1186,7 +1145,7 @@ extern "C" int wz_bind_frames(wz_engine_t* e, int n, const uint8_t* const* pixel
         if (!pixels[i] || !rows[i] || w[i] < 1 || h[i] < 1) return wz_fail(WZ_EINVAL, "frame-table entry %d: bad pointer or size", i);
         const uint64_t bytes = wz_frame_bytes(w[i], h[i], pf);
         if (!bytes) return wz_fail(WZ_EINVAL, "frame-table entry %d: pixel format %d at %dx%d (NV12 / I420 need even sides)", i, pf, w[i], h[i]);
-        if (w[i] > e->max_w || h[i] > e->max_h || (size_t)w[i] * h[i] * 3 + 256 > e->frame_stride)
+        if (w[i] > e->max_w || h[i] > e->max_h || (size_t)w[i] * h[i] * 3 > e->frame_stride)
             return wz_fail(WZ_ELIMIT, "frame-table entry %d is %dx%d, engine was created for at most %dx%d", i, w[i], h[i], e->max_w, e->max_h);
         if (c >= WZ_MAX_CAMS) return wz_fail(WZ_ELIMIT, "camera id %d >= %d", c, WZ_MAX_CAMS);
         tbl[i] = {pixels[i], w[i], h[i], pf, c < 0 ? -1 : c, bytes, rows[i]};
@@ -1207,19 +1166,18 @@ extern "C" int wz_submit_bound(wz_engine_t* e, int slot, int n, const int32_t* e
     Lane& L = e->lanes[slot];
     HIPCHK(hipEventSynchronize(L.done));   // the lane's previous batch (and its reads of the staging area) drained
     if (!L.d_frames) return wz_fail(WZ_EINVAL, "wz_submit_bound: lane %d has no staging area", slot);
-    bool stage = false;
     std::vector<const uint8_t*> dptr(n);
     std::vector<int> ws(n), hs(n), fmts(n), cams(n);
     for (int i = 0; i < n; ++i) {
         const wz_engine::BoundFrame& f = e->bound[entries[i]];
         // (the filter of the frame's camera may have been set for another size since the table was built: fill_desc checks)
-        int rc = stage_frame(e, L, i, f.host, f.bytes, &stage, &dptr[i]);
+        int rc = stage_frame(e, L, i, f.host, f.bytes, &dptr[i]);
         if (rc != WZ_OK) return rc;
         ws[i] = f.w; hs[i] = f.h; fmts[i] = f.fmt; cams[i] = f.cam;
     }
     int rc = fill_desc(e, slot, n, dptr.data(), ws.data(), hs.data(), fmts.data(), cams.data());
     if (rc != WZ_OK) return rc;
-    rc = run_batch(e, slot, n, stage);
+    rc = run_batch(e, slot, n);
     if (rc != WZ_OK) return rc;
     L.bound_idx.assign(entries, entries + n);
     return WZ_OK;
@@ -1229,7 +1187,7 @@ extern "C" int wz_collect_bound(wz_engine_t* e, int slot) {
     int rc = wz_wait(e, slot);
     if (rc != WZ_OK) return rc;
     Lane& L = e->lanes[slot];
-    if ((int)L.bound_idx.size() != L.n) return wz_fail(WZ_EINVAL, "wz_collect_bound: lane %d holds no bound batch", slot);
+    if (L.bound_idx.empty() || (int)L.bound_idx.size() != L.n) return wz_fail(WZ_EINVAL, "wz_collect_bound: lane %d holds no bound batch", slot);
     for (int i = 0; i < L.n; ++i)
         memcpy(e->bound[L.bound_idx[i]].rows, L.h_rows + (size_t)i * WZ_MAX_DETECTIONS, sizeof(wz_detection_t) * WZ_MAX_DETECTIONS);
     L.bound_idx.clear();
