@@ -919,9 +919,14 @@ def main():
         if not args.no_parity:
             parity = parity_leg(eng, host_frames, d_frames, weights)
             note("parity: max |dscore| %.6f over %d rows" % (parity["max_dscore"], parity["rows_compared"]))
-        ops = eng.ops()
-        stages = eng.profile_device(d_frames[:BATCH], ws, hs, reps=10, inner=PROFILE_INNER)
-        single = eng.profile_device(d_frames[:BATCH], ws, hs, reps=10, inner=1)
+        # per-kernel durations: HIP events around every launch (wz_profile_stages) -- an entry point of the DEVELOPMENT library
+        # (the same sources built with -DWZ_DEV_BUILD; the headline above was timed on libwatsor_hip.so, which has no such hooks)
+        prof = HipEngine(engine_path, local_rank, BATCH, WIDTH, HEIGHT, dev=True)
+        pd = [prof.upload(f) for f in host_frames[:BATCH]]
+        ops = prof.ops()
+        stages = prof.profile_device(pd, ws, hs, reps=10, inner=PROFILE_INNER)
+        single = prof.profile_device(pd, ws, hs, reps=10, inner=1)
+        prof.close()
         note("stage profiles done")
         table, overhead = aggregate_stages(stages, ops, BATCH, WIDTH * HEIGHT * 3, eng.input_size, eng.hp_blocks, PROFILE_INNER)
         single_table, _ = aggregate_stages(single, ops, BATCH, WIDTH * HEIGHT * 3, eng.input_size, eng.hp_blocks, 1)

@@ -123,7 +123,7 @@ int wz_collect_bound(wz_engine_t* e, int slot);   /* waits for `slot`, writes it
 int wz_wait(wz_engine_t* e, int slot);
 const wz_detection_t* wz_slot_rows(wz_engine_t* e, int slot); /* pinned host, [n][100] */
 int wz_sync(wz_engine_t* e);
-int wz_graph_nodes(wz_engine_t* e, int slot);   /* nodes of the hipGraph last replayed on `slot` (kernels + 1 descriptor copy); 0 without graphs */
+int wz_graph_nodes(wz_engine_t* e, int slot);   /* nodes of the hipGraph last replayed on `slot` (kernel launches; no copy node unless the lane's descriptor block has no device address); 0 without graphs */
 int wz_num_slots(wz_engine_t* e);   /* lanes actually created (WZ_SLOTS unless WZ_LANES in the environment says fewer) */
 
 /* ---- per-camera filters on the GPU: ConfidenceFilter / AreaFilter / MaskFilter
@@ -174,24 +174,39 @@ int wz_tracker_update(wz_tracker_t* t, const wz_detection_t* rows, int n, const 
 /* DetectionSieve._incoming_frame (watsor/filter/sieve.py:21-33,44-56) with one TrackFilter, in place on the
  * frame header's rows: results first, the remaining rows zeroed. */
 int wz_tracker_sieve(wz_tracker_t* t, wz_detection_t* rows, int n, const uint8_t* pass, int* suspicious);
+/* ---- what the engine file holds (read once by HipEngine.__init__) */
+int wz_input_size(wz_engine_t* e);
+int wz_num_anchors(wz_engine_t* e);
+int wz_num_classes(wz_engine_t* e);
+int wz_precision(wz_engine_t* e);   /* 16: fp16 storage / fp16 MFMA; 32: fp32 storage / exact-fp32 MFMA (engine built with -p 32) */
+/* leading inverted-residual blocks that run with split (hi + lo) matrix operands; 0 = plain fp16 program
+ * (`python -m watsor_amd.engine --plain-fp16`), whose scores miss the 1e-3 tolerance */
+int wz_hp_blocks(wz_engine_t* e);
+
+/* ---- device memory helpers so callers need no other GPU runtime binding */
+int wz_dev_alloc(wz_engine_t* e, uint64_t bytes, void** d_ptr);
+int wz_dev_free(wz_engine_t* e, void* d_ptr);
+int wz_dev_upload(wz_engine_t* e, void* d_dst, const void* h_src, uint64_t bytes);
+int wz_dev_download(wz_engine_t* e, void* h_dst, const void* d_src, uint64_t bytes);
+
+/* ======================================================================================================================
+ * Development library only (`make dev` -> libwatsor_hip_dev.so, compiled with -DWZ_DEV_BUILD): stage-level entry points of the
+ * parity tests, per-kernel profiling for bench.py's roofline, diagnostics, and -- inside the library -- the WZ_* tuning knobs and
+ * the kernel variants that lost their A/B.  libwatsor_hip.so exports nothing below this line and reads
+ * only WZ_LANES, WZ_STREAMS and WZ_GRAPH from the environment.
+ * ====================================================================================================================== */
+#ifdef WZ_DEV_BUILD
 /* Test hooks for the CPython-set emulation: iteration order after adding keys[0..n) / of
  * `set(range(n)).difference(used)`; both return the number of values written to out. */
 int wz_debug_pyset_order(const int32_t* keys, int n, int32_t* out);
 int wz_debug_unused_order(int n, const uint8_t* used, int32_t* out);
 
-/* ---- introspection used by the engine CLI, bench.py (roofline) and the parity tests */
-int wz_input_size(wz_engine_t* e);
-int wz_num_anchors(wz_engine_t* e);
-int wz_num_classes(wz_engine_t* e);
+/* ---- introspection used by bench.py (roofline) and the parity tests */
 int wz_num_tensors(wz_engine_t* e);
 int wz_tensor_info(wz_engine_t* e, int idx, char* name, int namelen, int* h, int* w, int* c);
-int wz_precision(wz_engine_t* e);   /* 16: fp16 storage / fp16 MFMA; 32: fp32 storage / exact-fp32 MFMA (engine built with -p 32) */
 /* bit 0: the tensor is stored as a hi + lo pair of halves per value (2c halves per pixel: c hi, then c lo) --
  * the tensors between the split-operand blocks of the `-p 16` program (csrc/k_mbconv_hp.hip) */
 int wz_tensor_flags(wz_engine_t* e, int idx);
-/* leading inverted-residual blocks that run with split (hi + lo) matrix operands; 0 = plain fp16 program
- * (`python -m watsor_amd.engine --plain-fp16`), whose scores miss the 1e-3 tolerance */
-int wz_hp_blocks(wz_engine_t* e);
 int wz_num_ops(wz_engine_t* e);
 /* dims[12] = kind,cin,cout,ksize,stride,hin,win,hout,wout,n_pad,kc,splitk */
 int wz_op_info(wz_engine_t* e, int idx, char* name, int namelen, int* dims);
@@ -214,12 +229,6 @@ int wz_debug_nms(wz_engine_t* e, int n, uint64_t* out);
  * workgroup of every fused inverted-residual block, out[n_ops][16]; groups[n_ops] = channel groups launched. */
 int wz_debug_mbconv(wz_engine_t* e, uint64_t* out, int32_t* groups);
 
-/* ---- device memory helpers so callers need no other GPU runtime binding */
-int wz_dev_alloc(wz_engine_t* e, uint64_t bytes, void** d_ptr);
-int wz_dev_free(wz_engine_t* e, void* d_ptr);
-int wz_dev_upload(wz_engine_t* e, void* d_dst, const void* h_src, uint64_t bytes);
-int wz_dev_download(wz_engine_t* e, void* h_dst, const void* d_src, uint64_t bytes);
-
 /* ---- stage-level entry points for the parity tests (host in, host out, synchronous) */
 /* resize + normalise of one frame -> half[size*size*4] (x,y,z,0 per pixel); when the input tensor is a pair
  * (wz_tensor_flags) half[size*size*8]: (x,y,z,0) hi then (x,y,z,0) lo per pixel */
@@ -239,6 +248,8 @@ int wz_stage_postprocess(wz_engine_t* e, int n, const float* box_enc, const floa
 /* row fill (tensorflow_cpu.py:79-90) for caller-provided detections of one frame of size w x h */
 int wz_stage_rows(wz_engine_t* e, int w, int h, const float* boxes, const float* scores,
                   const int32_t* classes, wz_detection_t* rows);
+
+#endif /* WZ_DEV_BUILD */
 
 #ifdef __cplusplus
 }

@@ -100,6 +100,8 @@ def frames_640():
     return [synthetic_frame(640, 480, SEED + i) for i in range(4)]
 
 
-def make_engine(model_dir, max_batch=8, max_width=1920, max_height=1080, device=0):
+def make_engine(model_dir, max_batch=8, max_width=1920, max_height=1080, device=0, dev=False):
+    """dev=True: on libwatsor_hip_dev.so (stage-level entry points, WZ_* knobs) -- the stage-by-stage parity tests; the product
+    path's tests (plugin, worker, filters, bound frames) run on libwatsor_hip.so."""
     from watsor_amd.runtime import HipEngine
-    return HipEngine(os.path.join(model_dir, "mi355x.bin"), device, max_batch, max_width, max_height)
+    return HipEngine(os.path.join(model_dir, "mi355x.bin"), device, max_batch, max_width, max_height, dev=dev)

@@ -19,7 +19,14 @@ import numpy as np
 import pytest
 
 import parity_utils as pu
-from conftest import make_engine
+import conftest
+
+
+def make_engine(*args, **kwargs):
+    """Stage-level entry points and WZ_* knobs live in the development library (include/watsor_hip.h, WZ_DEV_BUILD section)."""
+    kwargs.setdefault("dev", True)
+    return conftest.make_engine(*args, **kwargs)
+
 from oracle import detect as odet
 from oracle import preprocess as pre
 from watsor_amd.runtime import ROW_DTYPE
@@ -616,8 +623,27 @@ def test_extras_chain_in_one_launch_matches_the_layer_by_layer_path(model_dir):
         six.close()
 
 
+def test_product_and_development_libraries_write_the_same_rows(model_dir, eng):
+    """Two builds of one source tree: libwatsor_hip.so (what ships) and libwatsor_hip_dev.so (what the stage tests above drive)."""
+    prod = conftest.make_engine(model_dir, dev=False)
+    try:
+        assert not prod.dev and eng.dev
+        with pytest.raises(AttributeError):
+            prod.stage_forward(np.zeros((1, 300, 300, 4), np.float16))
+        frames = [synthetic_frame(640, 480, 3100 + i) for i in range(8)] + [synthetic_frame(1280, 720, 3200)]
+        for batch in (frames[:8], frames[8:], frames[2:5]):
+            a = [np.zeros(100, ROW_DTYPE) for _ in batch]
+            b = [np.zeros(100, ROW_DTYPE) for _ in batch]
+            prod.detect_batch(batch, a)
+            eng.detect_batch(batch, b)
+            for x, y in zip(a, b):
+                assert x.tobytes() == y.tobytes() and x["label"][0] >= 1
+    finally:
+        prod.close()
+
+
 def test_limits_and_errors(model_dir):
-    e = make_engine(model_dir, max_batch=2, max_width=640, max_height=480)
+    e = conftest.make_engine(model_dir, max_batch=2, max_width=640, max_height=480)
     try:
         f = synthetic_frame(640, 480, 5)
         rows = [np.zeros(100, ROW_DTYPE) for _ in range(3)]

@@ -70,9 +70,11 @@ def test_plugin_in_a_spawned_worker_writes_the_same_rows(model_dir, asynchronous
         e.close()
     for fb in cams.values():                                        # exactly one latch step per dequeued payload
         assert [f.latch.steps.value for f in fb.frames] == [1, 1, 1]
-    assert fps.count.value == 15 and inference_time.count.value == 15
-    # inference_time is the per-frame share of a batch, not the batch time once per frame
-    assert 0 < inference_time.total.value / 15 < 50
+    # fps: one observation per frame.  inference_time: the per-frame share of a batch's service time -- per frame on the synchronous
+    # path, one observation per batch (or per 5 ms of batches) on the asynchronous one (watsor_amd/detection/detector.py)
+    assert fps.count.value == 15
+    assert inference_time.count.value == 15 if not asynchronous else 1 <= inference_time.count.value <= 3
+    assert 0 < inference_time.total.value / inference_time.count.value < 50
 
 
 def test_spawned_worker_runs_the_camera_filters(model_dir):

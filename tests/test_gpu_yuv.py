@@ -4,7 +4,14 @@ on those bytes."""
 import numpy as np
 import pytest
 
-from conftest import make_engine
+import conftest
+
+
+def make_engine(*args, **kwargs):
+    """Stage-level entry points and WZ_* knobs live in the development library (include/watsor_hip.h, WZ_DEV_BUILD section)."""
+    kwargs.setdefault("dev", True)
+    return conftest.make_engine(*args, **kwargs)
+
 from oracle import yuv
 from watsor_amd.runtime import FMT_I420, FMT_NV12, FMT_RGB24, ROW_DTYPE
 from watsor_amd.synth import synthetic_frame

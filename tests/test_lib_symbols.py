@@ -1,7 +1,9 @@
-"""The C-ABI library loads and exports every symbol include/watsor_hip.h declares (no GPU needed)."""
+"""The C-ABI libraries load and export exactly what include/watsor_hip.h declares (no GPU needed): libwatsor_hip.so the part above
+the WZ_DEV_BUILD section -- and nothing else that starts with wz_ --, libwatsor_hip_dev.so all of it."""
 import ctypes
 import os
 import re
+import subprocess
 
 from watsor_amd import _lib
 
@@ -9,32 +11,63 @@ HEADER = os.path.join(os.path.dirname(__file__), "..", "include", "watsor_hip.h"
 
 
 def declared_symbols():
+    """(product, development-only) function names of the header."""
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(wz_[a-z_0-9]+)\s*\(", src)))
+    a, b = src.index("#ifdef WZ_DEV_BUILD"), src.index("#endif /* WZ_DEV_BUILD */") if "#endif /* WZ_DEV_BUILD */" in src else None
+    if b is None:                                  # (the comment was stripped with the others: the section ends at its #endif)
+        b = src.index("#endif", a)
+    names = lambda text: sorted(set(re.findall(r"\b(wz_[a-z_0-9]+)\s*\(", text)))      # noqa: E731
+    return names(src[:a] + src[b:]), names(src[a:b])
 
 
-def test_library_exports_every_declared_symbol():
-    names = declared_symbols()
-    assert len(names) >= 30
-    lib = ctypes.CDLL(_lib.LIB_PATH)
-    for n in names:
-        assert hasattr(lib, n), "libwatsor_hip.so does not export %s" % n
+def exported(path):
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return sorted(l.split()[-1] for l in out.splitlines() if " T wz_" in l)
+
+
+def test_product_library_exports_exactly_the_documented_abi():
+    product, dev_only = declared_symbols()
+    assert len(product) >= 30 and len(dev_only) >= 15 and not set(product) & set(dev_only)
+    assert exported(_lib.LIB_PATH) == product
+    assert exported(_lib.DEV_LIB_PATH) == sorted(product + dev_only)
 
 
 def test_binding_covers_header():
-    assert sorted(_lib.SIGNATURES) == declared_symbols()
+    product, dev_only = declared_symbols()
+    assert sorted(_lib.SIGNATURES) == product
+    assert sorted(_lib.DEV_SIGNATURES) == dev_only
     _lib.load()
+    _lib.load(dev=True)
+
+
+def test_product_library_reads_three_environment_settings():
+    """WZ_LANES, WZ_STREAMS, WZ_GRAPH (+ GPU_MAX_HW_QUEUES, which it sets for the HIP runtime): every tuning knob the sources read
+    through wz_dev_getenv() exists in the development build only -- its name is not even in the product binary."""
+    import glob
+    csrc = os.path.join(os.path.dirname(HEADER), "..", "watsor_amd", "csrc")
+    text = "".join(open(f).read() for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.cpp")) +
+                   glob.glob(os.path.join(csrc, "*.h")))
+    read_directly = set(re.findall(r'[^_]getenv\("([A-Z0-9_]+)"\)', text))
+    assert read_directly == {"WZ_GRAPH", "WZ_LANES", "WZ_STREAMS"}, read_directly
+    knobs = set(re.findall(r'"(WZ_[A-Z0-9_]+)"', text)) - read_directly
+    assert len(knobs) >= 40
+    product, dev = open(_lib.LIB_PATH, "rb").read(), open(_lib.DEV_LIB_PATH, "rb").read()
+    assert all(k.encode() in product for k in read_directly)
+    leaked = sorted(k for k in knobs if k.encode() + b"\0" in product)
+    assert not leaked, leaked
+    assert sum(k.encode() + b"\0" in dev for k in knobs) >= 40
 
 
 def test_no_gpu_calls_fail_cleanly():
-    lib = _lib.load()
-    assert lib.wz_device_count() >= 0
-    h = ctypes.c_void_p()
-    rc = lib.wz_create(b"/nonexistent/mi355x.bin", 0, 1, 64, 64, ctypes.byref(h))
-    assert rc == _lib.WZ_ENOENT and "not found" in _lib.last_error()
-    try:
-        _lib.check(rc)
-        assert False
-    except FileNotFoundError:
-        pass
+    for dev in (False, True):
+        lib = _lib.load(dev=dev)
+        assert lib.wz_device_count() >= 0
+        h = ctypes.c_void_p()
+        rc = lib.wz_create(b"/nonexistent/mi355x.bin", 0, 1, 64, 64, ctypes.byref(h))
+        assert rc == _lib.WZ_ENOENT and "not found" in _lib.last_error(lib)
+        try:
+            _lib.check(rc, lib=lib)
+            assert False
+        except FileNotFoundError:
+            pass

@@ -10,6 +10,7 @@ time per step, the achieved GB/s / TFLOP/s under SURVEY 8(d)'s per-layer rule an
 import argparse
 import json
 import os
+os.environ.setdefault("WATSOR_HIP_DEV", "1")   # tools run on the development library (stage entry points, knobs, profiling)
 import subprocess
 import sys
 import time

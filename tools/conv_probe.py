@@ -2,6 +2,7 @@
 
 Run with WZ_LDS_RS=0 (the default kernel is the register-staged one, see tools/rs_probe.py)."""
 import os, sys, ctypes as C
+os.environ.setdefault("WATSOR_HIP_DEV", "1")   # tools run on the development library (stage entry points, knobs, profiling)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 os.environ["WZ_MB_DEBUG"] = "1"

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import json
 import os
+os.environ.setdefault("WATSOR_HIP_DEV", "1")   # tools run on the development library (stage entry points, knobs, profiling)
 import sys
 import time
 import traceback

@@ -5,6 +5,7 @@ FrameBuffer mmap, watsor/detection/detector.py:104-106), batch = 8, 640x480 (and
 """
 import json
 import os
+os.environ.setdefault("WATSOR_HIP_DEV", "1")   # tools run on the development library (stage entry points, knobs, profiling)
 import sys
 import time
 

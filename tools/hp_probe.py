@@ -6,6 +6,7 @@ The counters are compiled in only with -DWZ_HP_STAMPS=1:
  spread over the first chunk).
 """
 import os, sys, ctypes as C
+os.environ.setdefault("WATSOR_HIP_DEV", "1")   # tools run on the development library (stage entry points, knobs, profiling)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -6,6 +6,7 @@ flight, p50 of a synchronous step.  hp_upto = -1 is the --plain-fp16 program; 12
 """
 import argparse
 import os
+os.environ.setdefault("WATSOR_HIP_DEV", "1")   # tools run on the development library (stage entry points, knobs, profiling)
 import sys
 import time
 

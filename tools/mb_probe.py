@@ -1,5 +1,6 @@
 """Phase timestamps of the fused inverted-residual block kernels (first / last workgroup), batch 8."""
 import os, sys, ctypes as C
+os.environ.setdefault("WATSOR_HIP_DEV", "1")   # tools run on the development library (stage entry points, knobs, profiling)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 os.environ["WZ_MB_DEBUG"] = "1"

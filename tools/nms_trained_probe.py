@@ -3,6 +3,7 @@ trained_like_head_outputs) -- the random-init network of the benchmark yields ~2
 a trained one yields clusters of overlapping same-class anchors, saturated ties, and every logit above the score threshold."""
 import ctypes as C
 import os
+os.environ.setdefault("WATSOR_HIP_DEV", "1")   # tools run on the development library (stage entry points, knobs, profiling)
 import sys
 
 import numpy as np

@@ -4,6 +4,7 @@ The counters are compiled in only with -DWZ_RS_STAMPS=1:
     make -C watsor_amd/csrc clean && make -C watsor_amd/csrc CXXFLAGS_EXTRA=-DWZ_RS_STAMPS=1
 """
 import os, sys, ctypes as C
+os.environ.setdefault("WATSOR_HIP_DEV", "1")   # tools run on the development library (stage entry points, knobs, profiling)
 import numpy as np
 sys.path.insert(0, "/root/repo")
 os.environ["WZ_MB_DEBUG"] = "1"; os.environ.setdefault("WZ_GRAPH", "0")

@@ -7,6 +7,7 @@ sync = `s_waitcnt lgkmcnt(0)` + `s_barrier`.  (s_memtime needs an lgkmcnt(0) of 
 before its first MFMA when stamped, which they need not be otherwise.)
 """
 import os, sys, ctypes as C
+os.environ.setdefault("WATSOR_HIP_DEV", "1")   # tools run on the development library (stage entry points, knobs, profiling)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

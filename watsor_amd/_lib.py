@@ -12,7 +12,10 @@ import os
 from .share import Detection
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("WATSOR_HIP_LIBRARY") or os.path.join(_HERE, "libwatsor_hip.so")   # (the variable: measurement builds, tools/)
+LIB_PATH = os.path.join(_HERE, "libwatsor_hip.so")
+# the development build (-DWZ_DEV_BUILD): stage-level entry points, profiling hooks, tuning knobs; WATSOR_HIP_DEV_LIBRARY points
+# tools at a measurement build of it (e.g. one compiled with -DWZ_HP_STAMPS=1)
+DEV_LIB_PATH = os.environ.get("WATSOR_HIP_DEV_LIBRARY") or os.path.join(_HERE, "libwatsor_hip_dev.so")
 
 WZ_OK, WZ_EINVAL, WZ_ENOENT, WZ_EFORMAT, WZ_EHIP, WZ_ENODEV, WZ_ELIMIT = 0, -1, -2, -3, -4, -5, -6
 WZ_SLOTS = 8
@@ -67,17 +70,25 @@ SIGNATURES = {
     "wz_tracker_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                     C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "wz_tracker_sieve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
-    "wz_debug_pyset_order": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
-    "wz_debug_unused_order": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
     "wz_zones_from_alpha": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "wz_input_size": (C.c_int, [C.c_void_p]),
     "wz_precision": (C.c_int, [C.c_void_p]),
     "wz_num_anchors": (C.c_int, [C.c_void_p]),
     "wz_num_classes": (C.c_int, [C.c_void_p]),
+    "wz_hp_blocks": (C.c_int, [C.c_void_p]),
+    "wz_dev_alloc": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "wz_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "wz_dev_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "wz_dev_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+}
+
+# ... and what only the development library (libwatsor_hip_dev.so, `make dev`) exports on top of them
+DEV_SIGNATURES = {
+    "wz_debug_pyset_order": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "wz_debug_unused_order": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
     "wz_num_tensors": (C.c_int, [C.c_void_p]),
     "wz_tensor_info": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, c_i32p, c_i32p, c_i32p]),
     "wz_tensor_flags": (C.c_int, [C.c_void_p, C.c_int]),
-    "wz_hp_blocks": (C.c_int, [C.c_void_p]),
     "wz_num_ops": (C.c_int, [C.c_void_p]),
     "wz_op_info": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, c_i32p]),
     "wz_num_stages": (C.c_int, [C.c_void_p]),
@@ -86,10 +97,6 @@ SIGNATURES = {
     "wz_profile_stages": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), c_i32p, c_i32p, C.c_int, C.c_int, c_f32p]),
     "wz_debug_nms": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "wz_debug_mbconv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
-    "wz_dev_alloc": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
-    "wz_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
-    "wz_dev_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
-    "wz_dev_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "wz_stage_preprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "wz_stage_preprocess_fmt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "wz_stage_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -100,39 +107,54 @@ SIGNATURES = {
 }
 
 _lib = None
+_dev_lib = None
 
 
 class HipLibraryMissing(ImportError):
     pass
 
 
-def load():
-    """dlopen the library once and attach prototypes.  Raises instead of falling back."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.isfile(LIB_PATH):
+def _open(path, signatures):
+    if not os.path.isfile(path):
         raise HipLibraryMissing(
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            "(or `make -C watsor_amd/csrc`).  There is no CPU fallback." % LIB_PATH)
-    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
-    for name, (res, args) in SIGNATURES.items():
+            "(or `make -C watsor_amd/csrc`).  There is no CPU fallback." % path)
+    lib = C.CDLL(path, mode=C.RTLD_LOCAL)       # (local: the product and the development library define the same symbols)
+    for name, (res, args) in signatures.items():
         fn = getattr(lib, name)         # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
     return lib
 
 
-def last_error() -> str:
-    return load().wz_last_error().decode("utf-8", "replace")
+def load(dev: bool = False):
+    """dlopen the library once and attach prototypes.  Raises instead of falling back.  dev=True: the development library."""
+    global _lib, _dev_lib
+    if dev:
+        if _dev_lib is None:
+            _dev_lib = _open(DEV_LIB_PATH, {**SIGNATURES, **DEV_SIGNATURES})
+        return _dev_lib
+    if _lib is None:
+        _lib = _open(LIB_PATH, SIGNATURES)
+    return _lib
 
 
-def check(rc: int, what: str = "") -> None:
-    """Map a WZ_E* return code to the exception the reference's worker expects (detector.py:97-100)."""
+def last_error(lib=None) -> str:
+    """The message of the calling thread's last failure in `lib` (default: whichever of the two libraries is loaded and has one)."""
+    libs = [lib] if lib is not None else [l for l in (_lib, _dev_lib) if l is not None] or [load()]
+    for l in libs:
+        msg = l.wz_last_error().decode("utf-8", "replace")
+        if msg:
+            return msg
+    return ""
+
+
+def check(rc: int, what: str = "", lib=None) -> None:
+    """Map a WZ_E* return code to the exception the reference's worker expects (detector.py:97-100).  `lib`: the library the
+    call went to (its message is the one to show)."""
     if rc == WZ_OK:
         return
-    msg = last_error() or what
+    msg = last_error(lib) or what
     if rc == WZ_ENOENT:
         raise FileNotFoundError(msg)
     if rc in (WZ_EINVAL, WZ_ELIMIT):

@@ -779,7 +779,7 @@ __global__ __launch_bounds__(256, 2) void wz_k_conv_rs_group(const WzConvGroup g
 }
 
 static int wz_env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
+    const char* e = wz_dev_getenv(name);
     return (e && atoi(e) >= 0 && e[0]) ? atoi(e) : dflt;
 }
 
@@ -825,8 +825,8 @@ int wz_choose_splitk(int M, int n_pad, int kchunks) {
     const bool big = wz_conv_big(M, n_pad, kchunks);
     const int tm = big ? 64 : 32, tn = big ? 64 : 32;
     const long waves = (long)((M + tm - 1) / tm) * (n_pad / tn);
-    static const int target = [] { const char* e = getenv("WZ_SPLITK_WAVES"); return (e && atoi(e) > 0) ? atoi(e) : 1024; }();
-    static const int max_split = [] { const char* e = getenv("WZ_SPLITK_MAX"); return (e && atoi(e) > 0) ? atoi(e) : 16; }();
+    static const int target = [] { const char* e = wz_dev_getenv("WZ_SPLITK_WAVES"); return (e && atoi(e) > 0) ? atoi(e) : 1024; }();
+    static const int max_split = [] { const char* e = wz_dev_getenv("WZ_SPLITK_MAX"); return (e && atoi(e) > 0) ? atoi(e) : 16; }();
     if (kchunks < 32 || waves >= target) return 1;
     int s = (int)(target / (waves > 0 ? waves : 1));
     const int max_by_k = kchunks / 8;

@@ -317,7 +317,7 @@ __global__ __launch_bounds__(512) void wz_k_conv_ws_f32(const WzConvArgs a) {
 }
 
 bool wz_conv_ws_f32_applies(const WzConvArgs& a) {
-    static const bool on = [] { const char* e = getenv("WZ_CONV_WS"); return !(e && atoi(e) == 0); }();
+    static const bool on = [] { const char* e = wz_dev_getenv("WZ_CONV_WS"); return !(e && atoi(e) == 0); }();
     return on && a.out_mode == WZ_OUT_ACT && a.M <= 1024 && a.kchunks >= 16 && a.n_pad % 32 == 0;
 }
 void wz_launch_conv_ws_f32(const WzConvArgs& a, hipStream_t s) {
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void wz_k_conv_rs_f32(const WzConvArgs a) {
 
 // whole 64-column tiles, whole 32-channel K steps, enough pixels and a K loop long enough to pay for the tile
 bool wz_conv_f32_use_rs(const WzConvArgs& a) {
-    static const bool on = [] { const char* e = getenv("WZ_F32_RS"); return !(e && atoi(e) == 0); }();
+    static const bool on = [] { const char* e = wz_dev_getenv("WZ_F32_RS"); return !(e && atoi(e) == 0); }();
     // (channel tiles past n_pad read zeros and are never stored: n_pad need not be a multiple of the tile)
     return on && a.kc % 2 == 0 && a.cin % 32 == 0 && a.M >= 128 && a.kchunks >= 8;
 }
@@ -380,7 +380,7 @@ bool wz_conv_f32_use_rs(const WzConvArgs& a) {
 // This variant is MFMA-bound (4 096 cycles of fp32 MFMA per step against ~1 000 of loads and LDS traffic).  Measured
 // targets 256 / 512 / 768 workgroups: 12.2 / 12.1 / 11.9 k frames/s -- a second workgroup per CU does not pay.
 int wz_choose_splitk_rs_f32(int M, int n_pad, int kchunks) {
-    static const int target = [] { const char* e = getenv("WZ_F32_WGS"); return (e && atoi(e) > 0) ? atoi(e) : 256; }();
+    static const int target = [] { const char* e = wz_dev_getenv("WZ_F32_WGS"); return (e && atoi(e) > 0) ? atoi(e) : 256; }();
     const int tn = wz_lds_nw(M, n_pad, kchunks) * 32;
     const int wgs = ((M + WZ_RS_TM - 1) / WZ_RS_TM) * ((n_pad + tn - 1) / tn);
     const int nsteps = kchunks / 2;

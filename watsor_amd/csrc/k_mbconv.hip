@@ -330,7 +330,7 @@ struct MbCfg {
 };
 
 static int wz_mb_env(const char* name, int dflt) {
-    const char* e = getenv(name);
+    const char* e = wz_dev_getenv(name);
     return (e && atoi(e) > 0) ? atoi(e) : dflt;
 }
 

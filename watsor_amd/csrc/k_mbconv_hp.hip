@@ -572,7 +572,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
 
 // ---------------------------------------------------------------------------------------------
 static int wz_hp_env(const char* name, int dflt) {
-    const char* e = getenv(name);
+    const char* e = wz_dev_getenv(name);
     return (e && e[0] && atoi(e) >= 0) ? atoi(e) : dflt;
 }
 

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256, 4) void wz_k_mbconv_wave(const WzMbArgs a) {
 
 // ---------------------------------------------------------------------------------------------
 static int wz_mbw_env(const char* name, int dflt) {
-    const char* e = getenv(name);
+    const char* e = wz_dev_getenv(name);
     return (e && atoi(e) > 0) ? atoi(e) : dflt;
 }
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/watsor_hip.h"
 #include "wz_program.h"
@@ -133,6 +134,18 @@ struct WzCamFilter {
 // back to back (all of them are pure functions of their inputs): the bracket around a stage then holds N launches and
 // their N - 1 in-stream boundaries, and the one-off cost of the event pair is amortised instead of estimated.
 extern thread_local int wz_launch_repeat;
+// Tuning and A/B knobs (the WZ_* variables named next to the code they steer) exist in the DEVELOPMENT build only
+// (`make dev`: -DWZ_DEV_BUILD, libwatsor_hip_dev.so -- what tools/ and the stage-level parity tests load).  The product library
+// takes every default and reads exactly three operator settings from the environment: WZ_LANES, WZ_STREAMS, WZ_GRAPH.
+static inline const char* wz_dev_getenv(const char* name) {
+#ifdef WZ_DEV_BUILD
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 #define WZ_LAUNCH(...) do { for (int _wz_r = 0; _wz_r < wz_launch_repeat; ++_wz_r) hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 // hp: the input tensor is a hi + lo pair (8 halves per pixel: r g b 0 | r g b 0)
 void wz_launch_preprocess(const WzFrameDesc* d_frames, int n, int size, half_t* out, hipStream_t s, bool hp = false,

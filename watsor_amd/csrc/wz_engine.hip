@@ -293,6 +293,7 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
             // The extras behind the 5x5 map: a chain of plain convolutions on maps of <= 32 pixels, each reading what the one before it
             // wrote -- WZ_TAIL_FUSE=1 runs them as ONE launch, a workgroup per frame (k_tail.hip).  Built, bit-compatible within fp32
             // summation order, and slower than the six launches it replaces (34 us against 23.5 us: DESIGN.md section 10): off by default.
+#ifdef WZ_DEV_BUILD
             if (!f32 && e->tail_fuse && op.out_mode == WZ_OUT_ACT) {
                 WzTailArgs T;
                 T.n = 0;
@@ -337,6 +338,7 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
                     continue;
                 }
             }
+#endif
             WzConvArgs a;
             memset(&a, 0, sizeof(a));
             a.in = L.tptr[op.src];
@@ -694,19 +696,19 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     e->max_w = max_width;
     e->max_h = max_height;
     const char* env;
-    e->no_reuse = (env = getenv("WZ_NO_BUFFER_REUSE")) && atoi(env) != 0;
+    e->no_reuse = (env = wz_dev_getenv("WZ_NO_BUFFER_REUSE")) && atoi(env) != 0;
     e->use_graph = !((env = getenv("WZ_GRAPH")) && atoi(env) == 0);
-    e->use_splitk = !((env = getenv("WZ_SPLITK")) && atoi(env) == 0);
-    e->defer_heads = !((env = getenv("WZ_DEFER_HEADS")) && atoi(env) == 0);
-    e->fuse_decode = !((env = getenv("WZ_FUSE_DECODE")) && atoi(env) == 0);
-    e->post_self = !((env = getenv("WZ_POST_SELF")) && atoi(env) == 0);
-    e->list_cands = !((env = getenv("WZ_LIST_CANDS")) && atoi(env) == 0);
-    e->head_inline = (env = getenv("WZ_HEAD_INLINE")) && atoi(env) != 0;
-    e->conv_wide = !((env = getenv("WZ_CONV_WIDE")) && atoi(env) == 0);
-    e->desc_zero_copy = !((env = getenv("WZ_DESC_COPY")) && atoi(env) != 0);
-    e->tail_fuse = (env = getenv("WZ_TAIL_FUSE")) && atoi(env) != 0;
-    e->wide_T = (env = getenv("WZ_WIDE_T")) ? atoi(env) : 0;
-    e->wide_min_m = (env = getenv("WZ_WIDE_MIN_M")) ? atoi(env) : 1;
+    e->use_splitk = !((env = wz_dev_getenv("WZ_SPLITK")) && atoi(env) == 0);
+    e->defer_heads = !((env = wz_dev_getenv("WZ_DEFER_HEADS")) && atoi(env) == 0);
+    e->fuse_decode = !((env = wz_dev_getenv("WZ_FUSE_DECODE")) && atoi(env) == 0);
+    e->post_self = !((env = wz_dev_getenv("WZ_POST_SELF")) && atoi(env) == 0);
+    e->list_cands = !((env = wz_dev_getenv("WZ_LIST_CANDS")) && atoi(env) == 0);
+    e->head_inline = (env = wz_dev_getenv("WZ_HEAD_INLINE")) && atoi(env) != 0;
+    e->conv_wide = !((env = wz_dev_getenv("WZ_CONV_WIDE")) && atoi(env) == 0);
+    e->desc_zero_copy = !((env = wz_dev_getenv("WZ_DESC_COPY")) && atoi(env) != 0);
+    e->tail_fuse = (env = wz_dev_getenv("WZ_TAIL_FUSE")) && atoi(env) != 0;
+    e->wide_T = (env = wz_dev_getenv("WZ_WIDE_T")) ? atoi(env) : 0;
+    e->wide_min_m = (env = wz_dev_getenv("WZ_WIDE_MIN_M")) ? atoi(env) : 1;
     {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
@@ -747,7 +749,7 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     const WzBlobHeader& h = e->hdr;
     CK(hipMalloc((void**)&e->d_weights, h.weights_bytes));
     CK(hipMemcpy(e->d_weights, e->blob.data() + h.weights_off, h.weights_bytes, hipMemcpyHostToDevice));
-    if ((env = getenv("WZ_MB_DEBUG")) && atoi(env) != 0) {
+    if ((env = wz_dev_getenv("WZ_MB_DEBUG")) && atoi(env) != 0) {
         CK(hipMalloc((void**)&e->d_mbdbg, (size_t)h.n_ops * 16 * 8));
         CK(hipMemset(e->d_mbdbg, 0, (size_t)h.n_ops * 16 * 8));
         e->mb_groups.assign(h.n_ops, 0);
@@ -1288,6 +1290,9 @@ extern "C" int wz_input_size(wz_engine_t* e) { return e ? (int)e->hdr.input_size
 extern "C" int wz_precision(wz_engine_t* e) { return e ? (int)e->hdr.precision : 0; }
 extern "C" int wz_num_anchors(wz_engine_t* e) { return e ? (int)e->hdr.num_anchors : 0; }
 extern "C" int wz_num_classes(wz_engine_t* e) { return e ? (int)e->hdr.num_classes : 0; }
+extern "C" int wz_hp_blocks(wz_engine_t* e) { return e ? (int)e->hdr.hp_blocks : 0; }
+
+#ifdef WZ_DEV_BUILD   // ---- everything below this line exists in libwatsor_hip_dev.so only (include/watsor_hip.h, last section)
 extern "C" int wz_num_tensors(wz_engine_t* e) { return e ? (int)e->hdr.n_tensors : 0; }
 extern "C" int wz_num_ops(wz_engine_t* e) { return e ? (int)e->hdr.n_ops : 0; }
 
@@ -1306,7 +1311,6 @@ extern "C" int wz_tensor_flags(wz_engine_t* e, int idx) {
     return e->tensors[idx].flags;
 }
 
-extern "C" int wz_hp_blocks(wz_engine_t* e) { return e ? (int)e->hdr.hp_blocks : 0; }
 
 extern "C" int wz_op_info(wz_engine_t* e, int idx, char* name, int namelen, int* dims) {
     if (!e || idx < 0 || idx >= (int)e->hdr.n_ops) return wz_fail(WZ_EINVAL, "op index %d", idx);
@@ -1380,6 +1384,8 @@ extern "C" int wz_profile_stages(wz_engine_t* e, int n, const uint8_t* const* d_
     return WZ_OK;
 }
 
+#endif   // WZ_DEV_BUILD
+
 // ------------------------------------------------------------------------------------------------
 // device memory helpers
 // ------------------------------------------------------------------------------------------------
@@ -1408,6 +1414,7 @@ extern "C" int wz_dev_download(wz_engine_t* e, void* h_dst, const void* d_src, u
     return WZ_OK;
 }
 
+#ifdef WZ_DEV_BUILD
 // ------------------------------------------------------------------------------------------------
 // stage-level entry points (parity tests)
 // ------------------------------------------------------------------------------------------------
@@ -1505,3 +1512,4 @@ extern "C" int wz_stage_rows(wz_engine_t* e, int w, int h, const float* boxes, c
     HIPCHK(hipMemcpy(rows, e->lanes[0].d_rows, sizeof(wz_detection_t) * WZ_MAX_DETECTIONS, hipMemcpyDeviceToHost));
     return WZ_OK;
 }
+#endif   // WZ_DEV_BUILD

@@ -324,6 +324,7 @@ int wz_tracker_sieve(wz_tracker_t* t, wz_detection_t* rows, int n, const uint8_t
     return 0;
 }
 
+#ifdef WZ_DEV_BUILD   // test hooks of the CPython-set emulation: development library only
 int wz_debug_pyset_order(const int32_t* keys, int n, int32_t* out) {
     if (n < 0 || (n > 0 && (!keys || !out))) return wz_set_error(WZ_EINVAL, "wz_debug_pyset_order: bad argument");
     PySmallIntSet s;
@@ -346,5 +347,6 @@ int wz_debug_unused_order(int n, const uint8_t* used, int32_t* out) {
     for (size_t i = 0; i < o.size(); ++i) out[i] = o[i];
     return (int)o.size();
 }
+#endif
 
 }  // extern "C"

@@ -32,12 +32,18 @@ def device_name(device: int) -> str:
 
 class HipEngine:
     def __init__(self, engine_path: str, device: int = 0, max_batch: int = 8, max_width: int = 1920,
-                 max_height: int = 1080):
-        self._lib = _lib.load()
+                 max_height: int = 1080, dev: Optional[bool] = None):
+        """dev=True: on the DEVELOPMENT library (libwatsor_hip_dev.so: stage-level entry points, per-kernel profiling, the WZ_*
+        tuning knobs) -- parity tests, bench.py's roofline table and tools/; the product path never asks for it.  Default: the
+        product library, unless WATSOR_HIP_DEV=1 is set (how tools/ switch every engine they create)."""
+        if dev is None:
+            dev = os.environ.get("WATSOR_HIP_DEV", "0") not in ("", "0")
+        self.dev = bool(dev)
+        self._lib = _lib.load(dev=self.dev)
         self._h = C.c_void_p()
         self.max_batch = max_batch
         rc = self._lib.wz_create(os.fsencode(engine_path), device, max_batch, max_width, max_height, C.byref(self._h))
-        _lib.check(rc, "wz_create")
+        self._ck(rc, "wz_create")
         self.input_size = self._lib.wz_input_size(self._h)
         self.precision = self._lib.wz_precision(self._h)
         self.num_anchors = self._lib.wz_num_anchors(self._h)
@@ -45,6 +51,14 @@ class HipEngine:
         self.num_slots = self._lib.wz_num_slots(self._h)
         self.hp_blocks = self._lib.wz_hp_blocks(self._h)   # leading blocks with split (hi + lo) matrix operands
         self._dev_allocs: List[int] = []
+
+    def _ck(self, rc: int, what: str = "") -> None:
+        if rc:
+            _lib.check(rc, what, self._lib)
+
+    def _dev_only(self, what: str) -> None:
+        if not self.dev:
+            raise AttributeError("%s needs the development library: HipEngine(..., dev=True) (libwatsor_hip_dev.so, `make dev`)" % what)
 
     # -- lifecycle ------------------------------------------------------------------------------
     def close(self) -> None:
@@ -128,7 +142,7 @@ class HipEngine:
         if out_pass is not None:
             passv = (C.c_void_p * n)(*[p.ctypes.data for p in out_pass])
         ms = (C.c_float * n)()
-        _lib.check(self._lib.wz_detect_batch_fmt(self._h, n, ptrs, ws, hs, fmtv, camv, outs, passv, ms))
+        self._ck(self._lib.wz_detect_batch_fmt(self._h, n, ptrs, ws, hs, fmtv, camv, outs, passv, ms))
         return float(ms[0])
 
     def submit_device(self, slot: int, d_frames: Sequence[int], widths: Sequence[int], heights: Sequence[int],
@@ -139,7 +153,7 @@ class HipEngine:
         hs = (C.c_int32 * n)(*heights)
         camv = (C.c_int32 * n)(*cams) if cams is not None else None
         fmtv = (C.c_int32 * n)(*[int(x) for x in formats]) if formats is not None else None
-        _lib.check(self._lib.wz_submit_device_fmt(self._h, slot, n, ptrs, ws, hs, fmtv, camv))
+        self._ck(self._lib.wz_submit_device_fmt(self._h, slot, n, ptrs, ws, hs, fmtv, camv))
 
     def submit_host(self, slot: int, frames: Sequence[np.ndarray], cams: Optional[Sequence[int]] = None,
                     formats: Optional[Sequence[int]] = None) -> None:
@@ -158,21 +172,21 @@ class HipEngine:
         ptrs = (C.c_void_p * n)(*[f.ctypes.data for f in frames])
         camv = (C.c_int32 * n)(*cams) if cams is not None else None
         fmtv = (C.c_int32 * n)(*[int(x) for x in formats]) if formats is not None else None
-        _lib.check(self._lib.wz_submit_host_fmt(self._h, slot, n, ptrs, ws, hs, fmtv, camv))
+        self._ck(self._lib.wz_submit_host_fmt(self._h, slot, n, ptrs, ws, hs, fmtv, camv))
 
     def host_register(self, arr: np.ndarray) -> None:
         """Page-lock the memory behind `arr` (frames handed over from it then travel by DMA)."""
-        _lib.check(self._lib.wz_host_register(self._h, C.c_void_p(arr.ctypes.data), arr.nbytes))
+        self._ck(self._lib.wz_host_register(self._h, C.c_void_p(arr.ctypes.data), arr.nbytes))
 
     def host_unregister(self, arr: np.ndarray) -> None:
-        _lib.check(self._lib.wz_host_unregister(self._h, C.c_void_p(arr.ctypes.data)))
+        self._ck(self._lib.wz_host_unregister(self._h, C.c_void_p(arr.ctypes.data)))
 
     def host_register_address(self, address: int, nbytes: int) -> None:
         """The same for raw memory, e.g. a `multiprocessing.sharedctypes` array shared with other processes."""
-        _lib.check(self._lib.wz_host_register(self._h, C.c_void_p(address), nbytes))
+        self._ck(self._lib.wz_host_register(self._h, C.c_void_p(address), nbytes))
 
     def host_unregister_address(self, address: int) -> None:
-        _lib.check(self._lib.wz_host_unregister(self._h, C.c_void_p(address)))
+        self._ck(self._lib.wz_host_unregister(self._h, C.c_void_p(address)))
 
     # -- the worker's frame table (include/watsor_hip.h: wz_bind_frames) ----------------------------
     def bind_frames(self, pixel_addresses: Sequence[int], widths: Sequence[int], heights: Sequence[int],
@@ -180,7 +194,7 @@ class HipEngine:
         """Describe every frame of every frame buffer once: entry i = (address of its pixels, width, height, WZ_FMT_*, camera id
         or -1, address of its `Detection[100]` rows).  Replaces the previous table."""
         n = len(pixel_addresses)
-        _lib.check(self._lib.wz_bind_frames(
+        self._ck(self._lib.wz_bind_frames(
             self._h, n, (C.c_void_p * n)(*pixel_addresses), (C.c_int32 * n)(*widths), (C.c_int32 * n)(*heights),
             (C.c_int32 * n)(*[int(f) for f in formats]), (C.c_int32 * n)(*[int(c) for c in cams]),
             (C.c_void_p * n)(*row_addresses)))
@@ -194,22 +208,22 @@ class HipEngine:
             arr_t = self._bound_arrays[n] = C.c_int32 * n
         rc = self._lib.wz_submit_bound(self._h, slot, n, arr_t(*entries))
         if rc:
-            _lib.check(rc)
+            self._ck(rc)
 
     def collect_bound(self, slot: int) -> None:
         """Waits for lane `slot`; its rows are written into the bound frames' own `Detection[100]` arrays."""
         rc = self._lib.wz_collect_bound(self._h, slot)
         if rc:
-            _lib.check(rc)
+            self._ck(rc)
 
     def collect(self, slot: int, out_rows: Sequence, out_pass: Optional[Sequence[np.ndarray]] = None) -> None:
         n = len(out_rows)
         outs = (C.c_void_p * n)(*[self._addr(r) for r in out_rows])
         passv = (C.c_void_p * n)(*[p.ctypes.data for p in out_pass]) if out_pass is not None else None
-        _lib.check(self._lib.wz_collect(self._h, slot, outs, passv))
+        self._ck(self._lib.wz_collect(self._h, slot, outs, passv))
 
     def wait(self, slot: int) -> None:
-        _lib.check(self._lib.wz_wait(self._h, slot))
+        self._ck(self._lib.wz_wait(self._h, slot))
 
     def slot_rows(self, slot: int, n: int) -> np.ndarray:
         """View (no copy) of the pinned result rows of `slot`: ROW_DTYPE [n,100]."""
@@ -222,20 +236,20 @@ class HipEngine:
         return int(self._lib.wz_graph_nodes(self._h, slot))
 
     def sync(self) -> None:
-        _lib.check(self._lib.wz_sync(self._h))
+        self._ck(self._lib.wz_sync(self._h))
 
     # -- device memory --------------------------------------------------------------------------
     def upload(self, arr: np.ndarray) -> int:
         arr = np.ascontiguousarray(arr)
         p = C.c_void_p()
-        _lib.check(self._lib.wz_dev_alloc(self._h, arr.nbytes, C.byref(p)))
+        self._ck(self._lib.wz_dev_alloc(self._h, arr.nbytes, C.byref(p)))
         self._dev_allocs.append(p.value)
-        _lib.check(self._lib.wz_dev_upload(self._h, p, C.c_void_p(arr.ctypes.data), arr.nbytes))
+        self._ck(self._lib.wz_dev_upload(self._h, p, C.c_void_p(arr.ctypes.data), arr.nbytes))
         return p.value
 
     def free(self, d_ptr: int) -> None:
         self._dev_allocs.remove(d_ptr)
-        _lib.check(self._lib.wz_dev_free(self._h, C.c_void_p(d_ptr)))
+        self._ck(self._lib.wz_dev_free(self._h, C.c_void_p(d_ptr)))
 
     # -- filters --------------------------------------------------------------------------------
     def set_camera_filter(self, cam: int, width: int, height: int, conf_thr: np.ndarray, area_thr: np.ndarray,
@@ -256,98 +270,107 @@ class HipEngine:
                 zone_allow = np.ascontiguousarray(zone_allow, np.uint8)
                 assert zone_allow.shape == (_lib.WZ_NUM_LABELS, nz)
                 allow_p = C.c_void_p(zone_allow.ctypes.data)
-        _lib.check(self._lib.wz_set_camera_filter(
+        self._ck(self._lib.wz_set_camera_filter(
             self._h, cam, width, height, conf.ctypes.data_as(_lib.c_f64p), area.ctypes.data_as(_lib.c_f64p),
             nz, allow_p, fill_p))
 
     def set_camera_drop(self, cam: int, drop: bool) -> None:
         """Rows of camera `cam` that fail its filters are written as all-zero rows (include/watsor_hip.h)."""
-        _lib.check(self._lib.wz_set_camera_drop(self._h, cam, 1 if drop else 0))
+        self._ck(self._lib.wz_set_camera_drop(self._h, cam, 1 if drop else 0))
 
     def clear_camera_filter(self, cam: int) -> None:
-        _lib.check(self._lib.wz_clear_camera_filter(self._h, cam))
+        self._ck(self._lib.wz_clear_camera_filter(self._h, cam))
 
     def filter_rows(self, cam: int, rows) -> np.ndarray:
         """Runs Confidence/Area/Mask of camera `cam` on 100 rows in place; returns pass[100] (uint8)."""
         out = np.zeros(MAX_DETECTIONS, np.uint8)
-        _lib.check(self._lib.wz_filter_rows(self._h, cam, C.c_void_p(self._addr(rows)), C.c_void_p(out.ctypes.data)))
+        self._ck(self._lib.wz_filter_rows(self._h, cam, C.c_void_p(self._addr(rows)), C.c_void_p(out.ctypes.data)))
         return out
 
     # -- introspection / profiling ---------------------------------------------------------------
     def tensors(self):
+        self._dev_only("tensors()")
         out = []
         name = C.create_string_buffer(64)
         h, w, c = C.c_int32(), C.c_int32(), C.c_int32()
         for i in range(self._lib.wz_num_tensors(self._h)):
-            _lib.check(self._lib.wz_tensor_info(self._h, i, name, 64, C.byref(h), C.byref(w), C.byref(c)))
+            self._ck(self._lib.wz_tensor_info(self._h, i, name, 64, C.byref(h), C.byref(w), C.byref(c)))
             out.append((name.value.decode(), h.value, w.value, c.value))
         return out
 
     def ops(self):
+        self._dev_only("ops()")
         out = []
         name = C.create_string_buffer(80)
         dims = (C.c_int32 * 12)()
         keys = ("kind", "cin", "cout", "ksize", "stride", "hin", "win", "hout", "wout", "n_pad", "kc", "cmid")
         for i in range(self._lib.wz_num_ops(self._h)):
-            _lib.check(self._lib.wz_op_info(self._h, i, name, 80, dims))
+            self._ck(self._lib.wz_op_info(self._h, i, name, 80, dims))
             d = dict(zip(keys, list(dims)))
             d["name"] = name.value.decode()
             out.append(d)
         return out
 
     def stage_names(self) -> List[str]:
+        self._dev_only("stage_names()")
         name = C.create_string_buffer(96)
         out = []
         for i in range(self._lib.wz_num_stages(self._h)):
-            _lib.check(self._lib.wz_stage_name(self._h, i, name, 96))
+            self._ck(self._lib.wz_stage_name(self._h, i, name, 96))
             out.append(name.value.decode())
         return out
 
     def profile_device(self, d_frames: Sequence[int], widths: Sequence[int], heights: Sequence[int], reps: int = 10,
                        inner: int = 1):
         """[(stage name, ms of its event bracket)]; inner > 1: every network kernel `inner` times back to back in its bracket."""
+        self._dev_only("profile_device()")
         n = len(d_frames)
         ns = self._lib.wz_num_stages(self._h)
         ms = (C.c_float * ns)()
-        _lib.check(self._lib.wz_profile_stages(self._h, n, (C.c_void_p * n)(*d_frames), (C.c_int32 * n)(*widths),
+        self._ck(self._lib.wz_profile_stages(self._h, n, (C.c_void_p * n)(*d_frames), (C.c_int32 * n)(*widths),
                                                (C.c_int32 * n)(*heights), reps, inner, ms))
         return list(zip(self.stage_names(), [float(x) for x in ms]))
 
     # -- stage-level entry points (parity tests) --------------------------------------------------
     def tensor_is_pair(self, idx: int) -> bool:
+        self._dev_only("tensor_is_pair()")
         return bool(self._lib.wz_tensor_flags(self._h, idx) & 1)
 
     def stage_preprocess(self, frame: np.ndarray, fmt: int = FMT_RGB24) -> np.ndarray:
         """(S,S,4) float16; for a pair input tensor (S,S,8): hi (r,g,b,0) then lo (r,g,b,0)."""
+        self._dev_only("stage_preprocess()")
         frame = np.ascontiguousarray(frame, np.uint8)
         w, h = self.frame_geometry(frame, fmt)
         S = self.input_size
         out = np.empty((S, S, 8 if self.tensor_is_pair(0) else 4), np.float16)
-        _lib.check(self._lib.wz_stage_preprocess_fmt(self._h, C.c_void_p(frame.ctypes.data), w, h, int(fmt),
+        self._ck(self._lib.wz_stage_preprocess_fmt(self._h, C.c_void_p(frame.ctypes.data), w, h, int(fmt),
                                                      C.c_void_p(out.ctypes.data)))
         return out
 
     def stage_forward(self, x_half: np.ndarray):
         """x_half float16 [n,S,S,4] -> (box_enc float32 [n,A,4], logits float32 [n,A,C])."""
+        self._dev_only("stage_forward()")
         x = np.ascontiguousarray(x_half, np.float16)
         n = x.shape[0]
         be = np.empty((n, self.num_anchors, 4), np.float32)
         lg = np.empty((n, self.num_anchors, self.num_classes), np.float32)
-        _lib.check(self._lib.wz_stage_forward(self._h, n, C.c_void_p(x.ctypes.data), C.c_void_p(be.ctypes.data),
+        self._ck(self._lib.wz_stage_forward(self._h, n, C.c_void_p(x.ctypes.data), C.c_void_p(be.ctypes.data),
                                               C.c_void_p(lg.ctypes.data)))
         return be, lg
 
     def stage_read_tensor(self, idx: int, frame: int = 0) -> np.ndarray:
         """(h,w,c) array as stored; a pair tensor comes back as float32 hi + lo."""
+        self._dev_only("stage_read_tensor()")
         name, h, w, c = self.tensors()[idx]
         pair = self.tensor_is_pair(idx)
         out = np.empty((h, w, 2 * c if pair else c), np.float16 if (self.precision == 16 or name == "input") else np.float32)
-        _lib.check(self._lib.wz_stage_read_tensor(self._h, idx, frame, C.c_void_p(out.ctypes.data)))
+        self._ck(self._lib.wz_stage_read_tensor(self._h, idx, frame, C.c_void_p(out.ctypes.data)))
         if pair:
             return out[..., :c].astype(np.float32) + out[..., c:].astype(np.float32)
         return out
 
     def stage_postprocess(self, box_enc: np.ndarray, logits: np.ndarray):
+        self._dev_only("stage_postprocess()")
         be = np.ascontiguousarray(box_enc, np.float32)
         lg = np.ascontiguousarray(logits, np.float32)
         n = be.shape[0]
@@ -355,17 +378,18 @@ class HipEngine:
         scores = np.empty((n, MAX_DETECTIONS), np.float32)
         classes = np.empty((n, MAX_DETECTIONS), np.int32)
         num = np.empty((n,), np.int32)
-        _lib.check(self._lib.wz_stage_postprocess(
+        self._ck(self._lib.wz_stage_postprocess(
             self._h, n, C.c_void_p(be.ctypes.data), C.c_void_p(lg.ctypes.data), C.c_void_p(boxes.ctypes.data),
             C.c_void_p(scores.ctypes.data), C.c_void_p(classes.ctypes.data), C.c_void_p(num.ctypes.data)))
         return boxes, scores, classes, num
 
     def stage_rows(self, width: int, height: int, boxes: np.ndarray, scores: np.ndarray, classes: np.ndarray):
+        self._dev_only("stage_rows()")
         b = np.ascontiguousarray(boxes, np.float32)
         s = np.ascontiguousarray(scores, np.float32)
         c = np.ascontiguousarray(classes, np.int32)
         rows = np.zeros(MAX_DETECTIONS, ROW_DTYPE)
-        _lib.check(self._lib.wz_stage_rows(self._h, width, height, C.c_void_p(b.ctypes.data),
+        self._ck(self._lib.wz_stage_rows(self._h, width, height, C.c_void_p(b.ctypes.data),
                                            C.c_void_p(s.ctypes.data), C.c_void_p(c.ctypes.data),
                                            C.c_void_p(rows.ctypes.data)))
         return rows
