@@ -57,10 +57,13 @@ class OracleObjectDetector:
     """CPU restatement of `TensorFlowObjectDetector` (tensorflow_cpu.py:10-121) on explicit weights."""
 
     def __init__(self, model_path=None, weights: Optional[Dict[str, np.ndarray]] = None, size: int = 300,
-                 fast_post: bool = False):
+                 fast_post: bool = False, half_pixel_centers: bool = False, clip_after_nms: bool = False, post_config: Optional[dict] = None):
         """fast_post: post-process in one global score order (`postprocess.multiclass_nms_global_order`, held equal to the
         literal class-by-class version by tests) -- for the CPU baseline of bench.py; the checker uses the literal one."""
         self._fast_post = fast_post
+        # the two steps that differ between exporter generations (oracle/preprocess.py, oracle/postprocess.py) and the
+        # post-processing constants a graph may carry (score_thr, iou_thr, max_per_class, max_total)
+        self._half_pixel, self._clip_after, self._post = half_pixel_centers, clip_after_nms, dict(post_config or {})
         if weights is None:
             import os
             path = os.path.join(model_path, "oracle.npz")
@@ -84,9 +87,10 @@ class OracleObjectDetector:
 
     def raw(self, image_np: np.ndarray):
         """(boxes[100,4], classes[100] 1-based float, scores[100], box_enc, logits) for one frame."""
-        x = pre.preprocess(image_np, self._size)[None]
+        x = pre.preprocess(image_np, self._size, self._half_pixel)[None]
         be, cl, _ = self._net.forward(x)
-        b, s, c, _ = post.postprocess(be[0], cl[0], self._anchors, fast=self._fast_post)
+        b, s, c, _ = post.postprocess(be[0], cl[0], self._anchors, fast=self._fast_post and not self._clip_after,
+                                      clip_after_nms=self._clip_after, **self._post)
         return b, c, s, be[0], cl[0]
 
     def detect(self, image_shape, image_np, detections) -> float:

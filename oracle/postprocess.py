@@ -197,6 +197,48 @@ def multiclass_nms(boxes: np.ndarray, scores: np.ndarray,
     return out_b, out_s, out_c, nd
 
 
+def multiclass_nms_clip_after(boxes: np.ndarray, scores: np.ndarray,
+                              score_thr: float = SCORE_THRESHOLD, iou_thr: float = IOU_THRESHOLD,
+                              max_per_class: int = MAX_PER_CLASS, max_total: int = MAX_TOTAL
+                              ) -> Tuple[np.ndarray, np.ndarray, np.ndarray, int]:
+    """The OTHER order of the same steps (SURVEY App. B.5 "verify"): later exporters of the Object Detection API run the
+    per-class NMS on the UNCLIPPED decoded boxes and clip what it selected afterwards
+    (`post_processing.multiclass_non_max_suppression`: concatenate -> sort by score -> `_clip_window_prune_boxes` -> first
+    max_total).  Per class: keep score > thr (no area test: `tf.image.non_max_suppression` takes degenerate boxes, their IoU
+    is 0), greedy NMS on the boxes as decoded, <= max_per_class; concatenate in class order, stable sort by score; clip to
+    [0,1]; boxes left without area are pruned (they still suppressed their neighbours and used a slot of their class);
+    the first max_total remain.  An engine built with `clip_after_nms` computes this (csrc/k_post.hip), literal twin of
+    `multiclass_nms` above."""
+    n, c = scores.shape
+    sel_boxes, sel_scores, sel_classes = [], [], []
+    for cls in range(c):
+        s = scores[:, cls]
+        idx = np.nonzero(s > F32(score_thr))[0]
+        if idx.size == 0:
+            continue
+        b = boxes[idx]
+        keep = nms_single_class(b, s[idx], min(max_per_class, idx.size), iou_thr)
+        for k in keep:
+            sel_boxes.append(b[k])
+            sel_scores.append(s[idx[k]])
+            sel_classes.append(cls)
+    out_b = np.zeros((max_total, 4), np.float32)
+    out_s = np.zeros((max_total,), np.float32)
+    out_c = np.zeros((max_total,), np.float32)
+    nd = 0
+    if sel_scores:
+        order = sorted(range(len(sel_scores)), key=lambda i: (-float(sel_scores[i]), i))
+        for i in order:
+            cb = clip_to_unit_window(np.asarray(sel_boxes[i], np.float32)[None])[0]
+            if not area(cb[None])[0] > F32(0.0):
+                continue
+            out_b[nd], out_s[nd], out_c[nd] = cb, sel_scores[i], sel_classes[i]
+            nd += 1
+            if nd == max_total:
+                break
+    return out_b, out_s, out_c, nd
+
+
 def multiclass_nms_global_order(boxes: np.ndarray, scores: np.ndarray,
                                 score_thr: float = SCORE_THRESHOLD, iou_thr: float = IOU_THRESHOLD,
                                 max_per_class: int = MAX_PER_CLASS, max_total: int = MAX_TOTAL
@@ -250,13 +292,17 @@ def multiclass_nms_global_order(boxes: np.ndarray, scores: np.ndarray,
     return out_b, out_s, out_c, nd
 
 
-def postprocess(box_enc: np.ndarray, cls_logits: np.ndarray, anchors_cs: np.ndarray, fast: bool = False, **kw):
+def postprocess(box_enc: np.ndarray, cls_logits: np.ndarray, anchors_cs: np.ndarray, fast: bool = False,
+                clip_after_nms: bool = False, **kw):
     """One frame: raw head outputs -> (detection_boxes[100,4], scores[100], classes[100] 1-based, n).
 
     `classes` carries the exporter's label offset (+1) on *every* row including the zero padding,
-    which is why padded rows read class 1.
+    which is why padded rows read class 1.  clip_after_nms: `multiclass_nms_clip_after`.
     """
     boxes = decode_boxes(box_enc.astype(np.float32), anchors_cs)
     scores = sigmoid(cls_logits)[:, 1:]
+    if clip_after_nms:
+        b, s, c, nd = multiclass_nms_clip_after(boxes, scores, **kw)
+        return b, s, (c + F32(1.0)).astype(np.float32), nd
     b, s, c, nd = (multiclass_nms_global_order if fast else multiclass_nms)(boxes, scores, **kw)
     return b, s, (c + F32(1.0)).astype(np.float32), nd

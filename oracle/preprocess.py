@@ -16,11 +16,16 @@ import numpy as np
 F32 = np.float32
 
 
-def interpolation_weights(out_size: int, in_size: int):
-    """lower, upper (int64) and lerp (float32) per output index."""
+def interpolation_weights(out_size: int, in_size: int, half_pixel_centers: bool = False):
+    """lower, upper (int64) and lerp (float32) per output index.  half_pixel_centers: the scaler of graphs exported with
+    `ResizeBilinear(half_pixel_centers=True)` (TF >= 1.14 / TF2 exporters; `HalfPixelScaler` of image_resizer_state.h:
+    (out + 0.5) * scale - 0.5, three roundings), instead of the legacy out * scale of the 2018 graph the README names."""
     scale = F32(in_size) / F32(out_size)                 # CalculateResizeScale, align_corners=False
     i = np.arange(out_size, dtype=np.float32)
-    src = (i * scale).astype(np.float32)                 # legacy scaler: out * scale
+    if half_pixel_centers:
+        src = (((i + F32(0.5)).astype(np.float32) * scale).astype(np.float32) - F32(0.5)).astype(np.float32)
+    else:
+        src = (i * scale).astype(np.float32)             # legacy scaler: out * scale
     lo_f = np.floor(src)
     lower = np.maximum(lo_f.astype(np.int64), 0)
     upper = np.minimum(np.ceil(src).astype(np.int64), in_size - 1)
@@ -28,11 +33,11 @@ def interpolation_weights(out_size: int, in_size: int):
     return lower, upper, lerp
 
 
-def resize_bilinear(image_u8: np.ndarray, out_h: int = 300, out_w: int = 300) -> np.ndarray:
+def resize_bilinear(image_u8: np.ndarray, out_h: int = 300, out_w: int = 300, half_pixel_centers: bool = False) -> np.ndarray:
     """(H,W,3) uint8 -> (out_h,out_w,3) float32 (values 0..255)."""
     h, w, _ = image_u8.shape
-    yl, yu, yf = interpolation_weights(out_h, h)
-    xl, xu, xf = interpolation_weights(out_w, w)
+    yl, yu, yf = interpolation_weights(out_h, h, half_pixel_centers)
+    xl, xu, xf = interpolation_weights(out_w, w, half_pixel_centers)
     img = image_u8.astype(np.float32)
     tl = img[yl][:, xl]
     tr = img[yl][:, xu]
@@ -50,11 +55,11 @@ def normalise(x: np.ndarray) -> np.ndarray:
     return ((F32(2.0 / 255.0) * x).astype(np.float32) - F32(1.0)).astype(np.float32)
 
 
-def preprocess(image_u8: np.ndarray, size: int = 300) -> np.ndarray:
+def preprocess(image_u8: np.ndarray, size: int = 300, half_pixel_centers: bool = False) -> np.ndarray:
     """Full-resolution RGB24 frame -> normalised float32 (size,size,3) network input."""
-    return normalise(resize_bilinear(image_u8, size, size))
+    return normalise(resize_bilinear(image_u8, size, size, half_pixel_centers))
 
 
-def preprocess_fp16(image_u8: np.ndarray, size: int = 300) -> np.ndarray:
+def preprocess_fp16(image_u8: np.ndarray, size: int = 300, half_pixel_centers: bool = False) -> np.ndarray:
     """What the fp16 engine must store: the float32 result rounded to nearest-even fp16."""
-    return preprocess(image_u8, size).astype(np.float16)
+    return preprocess(image_u8, size, half_pixel_centers).astype(np.float16)

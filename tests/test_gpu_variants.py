@@ -1,0 +1,134 @@
+"""The engine-file options for the two steps that differ between exporter generations,
+on the GPU against their oracle twins: `resize` = legacy | half_pixel (ResizeBilinear's coordinate rule) and `clip_after_nms`
+(per-class NMS on the boxes as decoded, clipping afterwards).  Both settings of both options, stage by stage and end to end."""
+import numpy as np
+import pytest
+
+import conftest
+import parity_utils as pu
+from oracle import detect as odet
+from oracle import postprocess as post
+from oracle import preprocess as pre
+from watsor_amd import engine
+from watsor_amd.runtime import ROW_DTYPE
+from watsor_amd.synth import synthetic_frame
+
+pytestmark = pytest.mark.gpu
+
+
+def build(tmp_path_factory, synth_weights, name, **options):
+    d = tmp_path_factory.mktemp(name)
+    engine.save_engine(engine.build_engine(synth_weights, options=options), str(d / "mi355x.bin"))
+    return str(d)
+
+
+@pytest.fixture(scope="module")
+def dir_half_pixel(tmp_path_factory, synth_weights):
+    return build(tmp_path_factory, synth_weights, "half_pixel", resize="half_pixel")
+
+
+@pytest.fixture(scope="module")
+def dir_clip_after(tmp_path_factory, synth_weights):
+    return build(tmp_path_factory, synth_weights, "clip_after", clip_after_nms=True)
+
+
+@pytest.mark.parametrize("wh", [(640, 480), (1920, 1080), (300, 300), (301, 299), (150, 100), (64, 48)])
+def test_half_pixel_resize_bit_exact(dir_half_pixel, wh):
+    e = conftest.make_engine(dir_half_pixel, max_batch=1, dev=True)
+    try:
+        f = synthetic_frame(wh[0], wh[1], 11 + wh[0])
+        got = e.stage_preprocess(f)
+        ref32 = pre.preprocess(f, half_pixel_centers=True)
+        ref = ref32.astype(np.float16)
+        np.testing.assert_array_equal(got[..., :3].view(np.uint16), ref.view(np.uint16))
+        lo = (ref32 - ref.astype(np.float32)).astype(np.float16)
+        np.testing.assert_array_equal(got[..., 4:7].view(np.uint16), lo.view(np.uint16))
+        assert np.abs(ref32 - pre.preprocess(f)).max() > 1e-3 or wh == (300, 300)     # the two rules really differ (except at scale 1)
+    finally:
+        e.close()
+
+
+def outside_heavy_head_outputs(seed):
+    """Head outputs whose decoded boxes are large and often reach (or lie) beyond the image, with a trained-like score
+    distribution: where clipping first and clipping last give different rows."""
+    rng = np.random.default_rng(seed)
+    be = (rng.standard_normal((2, 1917, 4)) * np.array([6.0, 6.0, 3.0, 3.0])).astype(np.float32)    # centres far off, sizes x e^(0.6)
+    lg = (rng.standard_normal((2, 1917, 91)) * 2.0 - 5.0).astype(np.float32)
+    hot = rng.integers(0, 1917, 300)
+    lg[:, hot, rng.integers(1, 91, 300)] += 6.0
+    return be, lg
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_clip_after_nms_matches_its_oracle_twin(dir_clip_after, model_dir, seed):
+    be, lg = outside_heavy_head_outputs(seed)
+    after = conftest.make_engine(dir_clip_after, max_batch=2, dev=True)
+    before = conftest.make_engine(model_dir, max_batch=2, dev=True)
+    try:
+        differ = 0
+        for eng, kw in ((after, dict(clip_after_nms=True)), (before, {})):
+            B, S, C, N = eng.stage_postprocess(be, lg)
+            rB, rS, rC, rN = pu.oracle_postprocess(be, lg, **kw)
+            np.testing.assert_array_equal(N, rN)
+            np.testing.assert_array_equal(C, rC)
+            np.testing.assert_allclose(S, rS, rtol=0, atol=1e-6)
+            np.testing.assert_allclose(B, rB, rtol=0, atol=2e-6)
+            assert (B >= 0).all() and (B <= 1).all()
+            differ += 1 if kw else 0
+        a = pu.oracle_postprocess(be, lg, clip_after_nms=True)
+        b = pu.oracle_postprocess(be, lg)
+        assert (a[1] != b[1]).any() or (a[0] != b[0]).any()           # the inputs do tell the two orders apart
+    finally:
+        after.close()
+        before.close()
+
+
+def test_clip_after_known_answers_on_the_gpu(dir_clip_after):
+    """tests/test_oracle_variants.py's hand-made cases through the kernel: encodings chosen so that anchor a decodes to box a."""
+    anchors = pu.anchors_cs()                                           # (yc, xc, h, w)
+    e = conftest.make_engine(dir_clip_after, max_batch=1, dev=True)
+    try:
+        def encode(boxes):
+            be = np.zeros((1, 1917, 4), np.float32)
+            be[0, :, 2:] = -40.0                                        # every other anchor: a box of no size
+            lg = np.full((1, 1917, 91), -30.0, np.float32)
+            for i, (bx, sc) in enumerate(boxes):
+                a = 1000 + 7 * i
+                yc, xc, h, w = (bx[0] + bx[2]) / 2, (bx[1] + bx[3]) / 2, bx[2] - bx[0], bx[3] - bx[1]
+                ay, ax, ah, aw = anchors[a]
+                be[0, a] = [(yc - ay) / ah * 10, (xc - ax) / aw * 10, np.log(h / ah) * 5, np.log(w / aw) * 5]
+                lg[0, a, 1] = np.log(sc / (1 - sc))
+            return be, lg
+
+        cases = [([([-1.0, -1.0, 1.0, 1.0], 0.9), ([0.0, 0.0, 1.0, 1.0], 0.8)], 2),
+                 ([([1.2, 0.0, 1.6, 0.4], 0.9), ([1.15, 0.0, 1.6, 0.4], 0.8), ([0.9, 0.0, 1.6, 0.4], 0.7)], 1)]
+        for boxes, want in cases:
+            be, lg = encode(boxes)
+            B, S, C, N = e.stage_postprocess(be, lg)
+            rB, rS, rC, rN = pu.oracle_postprocess(be, lg, clip_after_nms=True)
+            assert int(N[0]) == int(rN[0]) == want
+            np.testing.assert_array_equal(C, rC)
+            np.testing.assert_allclose(S, rS, rtol=0, atol=1e-6)
+            np.testing.assert_allclose(B, rB, rtol=0, atol=2e-6)
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("which", ["half_pixel", "clip_after"])
+def test_end_to_end_with_each_option(request, synth_weights, which):
+    from watsor_amd.detection.hip_gpu import HipObjectDetector
+    from watsor_amd.share import DetectionArray
+    d = request.getfixturevalue("dir_" + which)
+    oracle = odet.OracleObjectDetector(weights=synth_weights, half_pixel_centers=which == "half_pixel",
+                                       clip_after_nms=which == "clip_after")
+    with HipObjectDetector(d, 0, max_batch=1, max_width=1280, max_height=720) as det:
+        for f in (synthetic_frame(640, 480, 2024), synthetic_frame(1280, 720, 2025)):
+            rows = DetectionArray()
+            det.detect(f.shape, f, rows)
+            got = np.frombuffer(rows, dtype=ROW_DTYPE)
+            b, c, s, _, _ = oracle.raw(f)
+            ref = odet.rows_as_array(f.shape, b, c, s)
+            pairs, missing = pu.match_rows(got, ref, min_score=0.1)
+            n_ref = int((ref["confidence"] > 0.1).sum())
+            assert n_ref > 0 and len(missing) <= max(1, n_ref // 20)
+            assert max(abs(p[3]) for p in pairs) <= 1e-3

@@ -12,18 +12,27 @@ from __future__ import annotations
 import numpy as np
 
 
+def ssd_box_specs(levels=6, min_scale=0.2, max_scale=0.95, aspect_ratios=(1.0, 2.0, 0.5, 3.0, 0.3333)):
+    """[(scale, aspect ratio), ...] per feature map, as `create_ssd_anchors(reduce_boxes_in_lowest_layer=True)` lists them: what the
+    graph's MultipleGridAnchorGenerator holds as constants (`watsor_amd/frozen_graph.py` checks an imported graph against it)."""
+    scales = [min_scale + (max_scale - min_scale) * k / (levels - 1) for k in range(levels)] + [1.0]
+    specs = []
+    for k in range(levels):
+        if k == 0:
+            specs.append([(0.1, 1.0), (scales[0], 2.0), (scales[0], 0.5)])
+        else:
+            specs.append([(scales[k], r) for r in aspect_ratios] + [(float(np.sqrt(scales[k] * scales[k + 1])), 1.0)])
+    return specs
+
+
 def ssd_anchor_table(grid_sizes, anchors_per_location, min_scale=0.2, max_scale=0.95,
                      aspect_ratios=(1.0, 2.0, 0.5, 3.0, 0.3333)) -> np.ndarray:
     """float32 [A, 4] rows (y_center, x_center, height, width), ordered layer, row, column, anchor."""
     f32 = np.float32
-    levels = len(grid_sizes)
-    scales = [min_scale + (max_scale - min_scale) * k / (levels - 1) for k in range(levels)] + [1.0]
+    specs = ssd_box_specs(len(grid_sizes), min_scale, max_scale, aspect_ratios)
     table = []
     for k, grid in enumerate(grid_sizes):
-        if k == 0:
-            spec = [(0.1, 1.0), (scales[0], 2.0), (scales[0], 0.5)]
-        else:
-            spec = [(scales[k], r) for r in aspect_ratios] + [(float(np.sqrt(scales[k] * scales[k + 1])), 1.0)]
+        spec = specs[k]
         assert len(spec) == anchors_per_location[k]
         sc = np.array([s for s, _ in spec], f32)
         rs = np.sqrt(np.array([r for _, r in spec], f32)).astype(f32)

@@ -176,6 +176,11 @@ __device__ __forceinline__ void wz_decode_anchor(const float4_t e, const float4_
     const float xc = tx * an[3] + an[1];
     const float hh = h / 2.0f, hw = w / 2.0f;
     float ymin = yc - hh, xmin = xc - hw, ymax = yc + hh, xmax = xc + hw;
+    if (k.clip_after) {   // the NMS takes the boxes as decoded; every anchor is a candidate (wz_k_nms clips what it keeps)
+        *reinterpret_cast<float4_t*>(box_out) = (float4_t){ymin, xmin, ymax, xmax};
+        *valid_out = 1;
+        return;
+    }
     ymin = fminf(fmaxf(ymin, 0.0f), 1.0f);
     xmin = fminf(fmaxf(xmin, 0.0f), 1.0f);
     ymax = fminf(fmaxf(ymax, 0.0f), 1.0f);

@@ -44,6 +44,11 @@ __global__ __launch_bounds__(256) void wz_k_decode(WzPostBuffers b, WzPostConsts
     const float xc = tx * an[3] + an[1];
     const float hh = h / 2.0f, hw = w / 2.0f;
     float ymin = yc - hh, xmin = xc - hw, ymax = yc + hh, xmax = xc + hw;
+    if (k.clip_after) {   // the NMS takes the boxes as decoded; every anchor is a candidate (wz_k_nms clips what it keeps)
+        *reinterpret_cast<float4_t*>(b.boxes + (size_t)i * 4) = (float4_t){ymin, xmin, ymax, xmax};
+        b.valid[i] = 1;
+        return;
+    }
     ymin = fminf(fmaxf(ymin, 0.0f), 1.0f);
     xmin = fminf(fmaxf(xmin, 0.0f), 1.0f);
     ymax = fminf(fmaxf(ymax, 0.0f), 1.0f);
@@ -687,14 +692,22 @@ __device__ uint32_t wz_nms_scan_band(NmsShared* S, const WzPostBuffers& b, const
 
 // frames != nullptr: the kernel also writes the frame's 100 Detection rows (what wz_k_rows does from the det_* arrays) --
 // one launch less per batch
-__global__ __launch_bounds__(NMS_THREADS) void wz_k_nms(WzPostBuffers b, WzPostConsts k,
+// Clip-after-NMS programs (WzPostConsts::clip_after, oracle/postprocess.py: multiclass_nms_clip_after): the walk runs on the boxes as
+// decoded and keeps up to NMS_KEEP_MAX of them -- a kept box that lies outside the image still suppresses its neighbours and
+// uses a slot of its class, but is no row --, then the kept boxes are clipped and the first max_total that still have an area are
+// the rows.  `status[f]` = 1 if the kept list filled up before max_total rows with an area were found (more than
+// NMS_KEEP_MAX - max_total selected boxes entirely outside the image: the frame's rows may be short; wz_collect reports it).
+__global__ __launch_bounds__(NMS_THREADS) void wz_k_nms(WzPostBuffers b, WzPostConsts kc,
                                                         const WzFrameDesc* __restrict__ frames,
                                                         const WzCamFilter* __restrict__ cams,
                                                         wz_detection_t* __restrict__ rows, uint8_t* __restrict__ pass,
-                                                        int self_scan, int listed) {
+                                                        int self_scan, int listed, uint32_t* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     NmsShared* S = reinterpret_cast<NmsShared*>(smem);
     const int f = blockIdx.x, tid = threadIdx.x;
+    const int out_total = kc.max_total;
+    WzPostConsts k = kc;
+    if (kc.clip_after) k.max_total = NMS_KEEP_MAX;           // the walk's "enough" (and the kept list's capacity)
     const int A = k.num_anchors;
 #define NMS_STAMP(i) do { if (tid == 0) b.dbg[(size_t)f * 16 + (i)] = wall_clock64(); } while (0)
     NMS_STAMP(0);
@@ -842,19 +855,57 @@ __global__ __launch_bounds__(NMS_THREADS) void wz_k_nms(WzPostBuffers b, WzPostC
     }
     __syncthreads();
 
+    // clip-after programs: clip what the walk kept, drop what has no area left, close the ranks (band order is kept)
+    const float4_t* obox = S->kbox;
+    const float* oscore = S->kscore;
+    const int32_t* ocls = S->kcls;
+    uint32_t overflow = 0;
+    if (kc.clip_after) {
+        for (int i = tid; i < NMS_KEEP_MAX; i += NMS_THREADS) {
+            float4_t c = {0.f, 0.f, 0.f, 0.f};
+            bool ok = false;
+            if (i < kept) {
+                const float4_t u = S->kbox[i];
+                c = (float4_t){fminf(fmaxf(u[0], 0.0f), 1.0f), fminf(fmaxf(u[1], 0.0f), 1.0f), fminf(fmaxf(u[2], 0.0f), 1.0f),
+                               fminf(fmaxf(u[3], 0.0f), 1.0f)};
+                ok = (c[2] - c[0]) * (c[3] - c[1]) > 0.0f;
+            }
+            S->knorm[i] = c;
+            S->cdead[i] = ok ? 0u : 1u;
+        }
+        __syncthreads();
+        int total_ok = 0;
+        for (int i = 0; i < kept; ++i) total_ok += S->cdead[i] ? 0 : 1;   // (<= 128 LDS broadcasts per thread)
+        for (int i = tid; i < kept; i += NMS_THREADS) {
+            if (S->cdead[i]) continue;
+            int pos = 0;
+            for (int j = 0; j < i; ++j) pos += S->cdead[j] ? 0 : 1;
+            if (pos >= out_total) continue;
+            S->cnorm[pos] = S->knorm[i];
+            S->carea[pos] = S->kscore[i];
+            S->ccls[pos] = S->kcls[i];
+        }
+        __syncthreads();
+        overflow = (kept >= NMS_KEEP_MAX && total_ok < out_total) ? 1u : 0u;
+        kept = min(total_ok, out_total);
+        obox = S->cnorm;
+        oscore = S->carea;
+        ocls = S->ccls;
+    }
+    if (status && tid == 0) status[f] = overflow;
     // detection_boxes / scores / classes (+1 label offset on every row, zero padding included)
-    for (int i = tid; i < k.max_total; i += NMS_THREADS) {
+    for (int i = tid; i < out_total; i += NMS_THREADS) {
         const bool on = i < kept;
-        const float4_t bx = on ? S->kbox[i] : (float4_t){0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<float4_t*>(b.det_boxes + ((size_t)f * k.max_total + i) * 4) = bx;
-        b.det_scores[(size_t)f * k.max_total + i] = on ? S->kscore[i] : 0.0f;
-        b.det_classes[(size_t)f * k.max_total + i] = (on ? S->kcls[i] : 0) + 1;
+        const float4_t bx = on ? obox[i] : (float4_t){0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<float4_t*>(b.det_boxes + ((size_t)f * out_total + i) * 4) = bx;
+        b.det_scores[(size_t)f * out_total + i] = on ? oscore[i] : 0.0f;
+        b.det_classes[(size_t)f * out_total + i] = (on ? ocls[i] : 0) + 1;
     }
     if (tid == 0) b.det_num[f] = kept;
     if (frames && tid < WZ_MAX_DETECTIONS) {
         const bool on = tid < kept;
-        wz_make_row(frames[f], cams, tid < k.max_total, on ? S->kbox[tid] : (float4_t){0.f, 0.f, 0.f, 0.f},
-                    on ? S->kscore[tid] : 0.0f, (on ? S->kcls[tid] : 0) + 1,
+        wz_make_row(frames[f], cams, tid < out_total, on ? obox[tid] : (float4_t){0.f, 0.f, 0.f, 0.f},
+                    on ? oscore[tid] : 0.0f, (on ? ocls[tid] : 0) + 1,
                     rows + (size_t)f * WZ_MAX_DETECTIONS + tid, pass + (size_t)f * WZ_MAX_DETECTIONS + tid);
     }
     NMS_STAMP(4);
@@ -1010,10 +1061,10 @@ void wz_post_init() {
                               (int)sizeof(NmsShared));
 }
 void wz_launch_nms(const WzPostBuffers& b, const WzPostConsts& c, int n, hipStream_t s, const WzFrameDesc* d_frames,
-                   const WzCamFilter* d_cams, wz_detection_t* rows, uint8_t* pass, bool self_scan, bool listed) {
+                   const WzCamFilter* d_cams, wz_detection_t* rows, uint8_t* pass, bool self_scan, bool listed, uint32_t* status) {
     if (((c.num_anchors * c.num_classes + 31) >> 5) > 8 * NMS_THREADS) listed = false;   // bit map larger than one pass: scan instead
     hipLaunchKernelGGL(wz_k_nms, dim3(n), dim3(NMS_THREADS), sizeof(NmsShared), s, b, c, d_frames, d_cams, rows, pass,
-                       self_scan ? 1 : 0, (self_scan && listed) ? 1 : 0);
+                       self_scan ? 1 : 0, (self_scan && listed) ? 1 : 0, status);
 }
 void wz_launch_rows(const WzPostBuffers& b, const WzFrameDesc* d_frames, const WzCamFilter* d_cams, int n,
                     int max_total, wz_detection_t* rows, uint8_t* pass, hipStream_t s) {

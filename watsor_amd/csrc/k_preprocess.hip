@@ -55,21 +55,23 @@ __device__ __forceinline__ void wz_fetch_rgb(const WzFrameDesc& f, int x, int y,
 // `keep`: where to leave a copy of the frame's descriptor for the kernels behind (wz_k_nms reads sizes and camera ids from it),
 // or nullptr.  With `frames` pointing into page-locked HOST memory this replaces the descriptor copy in front of every batch
 // (a graph node of its own, ~4 us of a batch's latency) by one 32-byte read over PCIe per workgroup, in flight together.
+// `half_pixel`: the coordinate rule of graphs exported with ResizeBilinear(half_pixel_centers=True) -- src = (dst + 0.5) * scale - 0.5,
+// three roundings (`HalfPixelScaler`) -- instead of the legacy src = dst * scale (WzBlobHeader::resize_mode; oracle/preprocess.py).
 template <bool HP>
 __global__ __launch_bounds__(256) void wz_k_preprocess(const WzFrameDesc* __restrict__ frames, int size,
-                                                       half_t* __restrict__ out, WzFrameDesc* __restrict__ keep) {
+                                                       half_t* __restrict__ out, WzFrameDesc* __restrict__ keep, int half_pixel) {
     const WzFrameDesc f = frames[blockIdx.y];
     if (keep && blockIdx.x == 0 && threadIdx.x == 0) keep[blockIdx.y] = f;
     const int pix = blockIdx.x * 256 + threadIdx.x;
     if (pix >= size * size) return;
     const int oy = pix / size, ox = pix - oy * size;
 
-    const float in_y = (float)oy * f.scale_y;
+    const float in_y = half_pixel ? ((float)oy + 0.5f) * f.scale_y - 0.5f : (float)oy * f.scale_y;
     const float fl_y = floorf(in_y);
     const int y_lo = max((int)fl_y, 0);
     const int y_hi = min((int)ceilf(in_y), f.h - 1);
     const float ly = in_y - fl_y;
-    const float in_x = (float)ox * f.scale_x;
+    const float in_x = half_pixel ? ((float)ox + 0.5f) * f.scale_x - 0.5f : (float)ox * f.scale_x;
     const float fl_x = floorf(in_x);
     const int x_lo = max((int)fl_x, 0);
     const int x_hi = min((int)ceilf(in_x), f.w - 1);
@@ -102,10 +104,11 @@ __global__ __launch_bounds__(256) void wz_k_preprocess(const WzFrameDesc* __rest
     }
 }
 
-void wz_launch_preprocess(const WzFrameDesc* d_frames, int n, int size, half_t* out, hipStream_t s, bool hp, WzFrameDesc* keep) {
+void wz_launch_preprocess(const WzFrameDesc* d_frames, int n, int size, half_t* out, hipStream_t s, bool hp, WzFrameDesc* keep,
+                          bool half_pixel) {
     dim3 grid((size * size + 255) / 256, n);
     if (hp)
-        WZ_LAUNCH(wz_k_preprocess<true>, grid, dim3(256), 0, s, d_frames, size, out, keep);
+        WZ_LAUNCH(wz_k_preprocess<true>, grid, dim3(256), 0, s, d_frames, size, out, keep, half_pixel ? 1 : 0);
     else
-        WZ_LAUNCH(wz_k_preprocess<false>, grid, dim3(256), 0, s, d_frames, size, out, keep);
+        WZ_LAUNCH(wz_k_preprocess<false>, grid, dim3(256), 0, s, d_frames, size, out, keep, half_pixel ? 1 : 0);
 }

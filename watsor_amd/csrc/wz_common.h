@@ -77,6 +77,8 @@ struct WzPostConsts {
     int32_t max_total, max_per_class;
     float score_thr, iou_thr;
     float scale_y, scale_x, scale_h, scale_w;
+    int32_t clip_after;   // 1: the per-class NMS sees the boxes as decoded, what it selects is clipped afterwards (WzBlobHeader::post_flags)
+    int32_t _pad;
 };
 
 // What finishing a head output needs beyond the convolution's own arguments (static per lane, lives in HBM).
@@ -149,7 +151,7 @@ static inline const char* wz_dev_getenv(const char* name) {
 #define WZ_LAUNCH(...) do { for (int _wz_r = 0; _wz_r < wz_launch_repeat; ++_wz_r) hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 // hp: the input tensor is a hi + lo pair (8 halves per pixel: r g b 0 | r g b 0)
 void wz_launch_preprocess(const WzFrameDesc* d_frames, int n, int size, half_t* out, hipStream_t s, bool hp = false,
-                          WzFrameDesc* keep = nullptr);   // keep: see k_preprocess.hip
+                          WzFrameDesc* keep = nullptr, bool half_pixel = false);   // keep, half_pixel: see k_preprocess.hip
 void wz_launch_stem(const half_t* in, const float* w, const float* bias, half_t* out, int n, int hin, int win,
                     int hout, int wout, int pad_t, int pad_l, hipStream_t s);
 void wz_launch_dw(const half_t* in, const half_t* w, const float* bias, half_t* out, int n, int hin, int win,
@@ -263,7 +265,7 @@ void wz_launch_compact(const WzPostBuffers& b, const WzPostConsts& c, int n, hip
 // self_scan: the kernel selects its candidates itself (no wz_k_hist / wz_k_compact in front of it)
 void wz_launch_nms(const WzPostBuffers& b, const WzPostConsts& c, int n, hipStream_t s, const WzFrameDesc* d_frames = nullptr,
                    const WzCamFilter* d_cams = nullptr, wz_detection_t* rows = nullptr, uint8_t* pass = nullptr,
-                   bool self_scan = false, bool listed = false);
+                   bool self_scan = false, bool listed = false, uint32_t* status = nullptr);   // status: see wz_k_nms
 void wz_launch_rows(const WzPostBuffers& b, const WzFrameDesc* d_frames, const WzCamFilter* d_cams, int n,
                     int max_total, wz_detection_t* rows, uint8_t* pass, hipStream_t s);
 int wz_set_error(int code, const char* fmt, ...);   // sets wz_last_error() of the calling thread, returns code

@@ -127,6 +127,8 @@ struct wz_engine {
         uint8_t* h_pass = nullptr;
         wz_detection_t* m_rows = nullptr;    // device addresses of h_rows / h_pass
         uint8_t* m_pass = nullptr;
+        uint32_t* h_status = nullptr;        // pinned, device-mapped: one word per frame, non-zero = the frame's rows may be short (wz_k_nms)
+        uint32_t* m_status = nullptr;
         std::vector<int32_t> bound_idx;      // frame-table entries of the batch in flight (empty: not a bound batch)
         hipEvent_t done = nullptr;
         int n = 0;
@@ -527,7 +529,7 @@ static void enqueue_post(wz_engine* e, Lane& L, bool rows, int n, StageTimer* t,
     // with `rows` the NMS kernel also fills the Detection rows (straight into the lane's pinned, device-mapped host
     // block: no D2H copy node, no separate row kernel); the "post/rows" stage slot stays empty
     if (rows)
-        wz_launch_nms(L.post, e->pc, n, s, L.d_desc, e->d_cams, L.m_rows, L.m_pass, e->post_self, listed);
+        wz_launch_nms(L.post, e->pc, n, s, L.d_desc, e->d_cams, L.m_rows, L.m_pass, e->post_self, listed, L.m_status);
     else
         wz_launch_nms(L.post, e->pc, n, s, nullptr, nullptr, nullptr, nullptr, e->post_self, listed);
     if (t) t->mark();
@@ -546,7 +548,7 @@ static void enqueue_batch(wz_engine* e, Lane& L, int n, StageTimer* t, int inner
     if (t) t->mark();
     wz_launch_repeat = inner;
     wz_launch_preprocess(zero_copy ? L.h_desc_dev : L.d_desc, n, (int)e->hdr.input_size, L.tptr[input_tensor_index(e)], s,
-                         input_is_pair(e), zero_copy ? L.d_desc : nullptr);
+                         input_is_pair(e), zero_copy ? L.d_desc : nullptr, e->hdr.resize_mode == 1);
     if (t) t->mark();
     enqueue_network(e, L, n, t);
     wz_launch_repeat = 1;
@@ -614,6 +616,8 @@ static int load_blob(wz_engine* e, const char* path) {
     memcpy(&e->hdr, e->blob.data(), sizeof(WzBlobHeader));
     const WzBlobHeader& h = e->hdr;
     if (h.magic != WZ_MAGIC) return wz_fail(WZ_EFORMAT, "%s is not an mi355x engine (bad magic)", path);
+    if (h.version == WZ_FORMAT_VERSION && (h.resize_mode > 1 || h.post_flags > 1))
+        return wz_fail(WZ_EFORMAT, "%s: unknown resize mode %u / post-processing flags %u", path, h.resize_mode, h.post_flags);
     if (h.version != WZ_FORMAT_VERSION)
         return wz_fail(WZ_EFORMAT, "%s: engine format %u, runtime expects %u -- rebuild it with watsor_amd.engine",
                        path, h.version, WZ_FORMAT_VERSION);
@@ -768,6 +772,8 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     e->pc.score_thr = h.score_threshold;
     e->pc.iou_thr = h.iou_threshold;
     e->pc.scale_y = h.scale_y; e->pc.scale_x = h.scale_x; e->pc.scale_h = h.scale_h; e->pc.scale_w = h.scale_w;
+    e->pc.clip_after = (h.post_flags & WZ_POSTF_CLIP_AFTER) ? 1 : 0;
+    e->pc._pad = 0;
     e->post_scratch_bytes = (size_t)max_batch * (WZ_HIST_BINS + 5 + ((h.num_anchors * h.num_classes + 31) >> 5)) * 4;   // hist, count, band[2], hint, hint_logit, cbits
 
     for (uint32_t i = 0; i < h.n_tensors; ++i)
@@ -876,6 +882,9 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
         CK(hipHostMalloc((void**)&L.h_pass, (size_t)WZ_MAX_DETECTIONS * max_batch, hipHostMallocMapped));
         CK(hipHostGetDevicePointer((void**)&L.m_rows, L.h_rows, 0));
         CK(hipHostGetDevicePointer((void**)&L.m_pass, L.h_pass, 0));
+        CK(hipHostMalloc((void**)&L.h_status, sizeof(uint32_t) * max_batch, hipHostMallocMapped));
+        memset(L.h_status, 0, sizeof(uint32_t) * max_batch);
+        CK(hipHostGetDevicePointer((void**)&L.m_status, L.h_status, 0));
         CK(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
     }
     e->stream = e->lanes[0].stream;
@@ -937,6 +946,7 @@ extern "C" void wz_destroy(wz_engine_t* e) {
         if (L.h_desc) (void)hipHostFree(L.h_desc);
         if (L.h_rows) (void)hipHostFree(L.h_rows);
         if (L.h_pass) (void)hipHostFree(L.h_pass);
+        if (L.h_status) (void)hipHostFree(L.h_status);
         if (L.done) (void)hipEventDestroy(L.done);
         if (L.stream && L.owns_stream) (void)hipStreamDestroy(L.stream);
     }
@@ -1004,6 +1014,16 @@ extern "C" int wz_wait(wz_engine_t* e, int slot) {
     return WZ_OK;
 }
 
+// after a lane's rows were handed over: did the NMS kernel flag one of its frames?  (clip-after-NMS engines only; k_post.hip: wz_k_nms)
+static int lane_status(wz_engine* e, int slot) {
+    const Lane& L = e->lanes[slot];
+    for (int i = 0; i < L.n; ++i)
+        if (L.h_status && L.h_status[i])
+            return wz_fail(WZ_ELIMIT, "frame %d of the batch on lane %d: more than %d selected boxes lie entirely outside the image, "
+                                      "its rows may be incomplete", i, slot, 128 - (int)e->hdr.max_total);
+    return WZ_OK;
+}
+
 extern "C" const wz_detection_t* wz_slot_rows(wz_engine_t* e, int slot) {
     if (!e || slot < 0 || slot >= e->n_lanes) return nullptr;
     return e->lanes[slot].h_rows;
@@ -1018,7 +1038,7 @@ extern "C" int wz_collect(wz_engine_t* e, int slot, wz_detection_t* const* out, 
             memcpy(out[i], L.h_rows + (size_t)i * WZ_MAX_DETECTIONS, sizeof(wz_detection_t) * WZ_MAX_DETECTIONS);
         if (pass && pass[i]) memcpy(pass[i], L.h_pass + (size_t)i * WZ_MAX_DETECTIONS, WZ_MAX_DETECTIONS);
     }
-    return WZ_OK;
+    return lane_status(e, slot);
 }
 
 extern "C" int wz_num_slots(wz_engine_t* e) { return e ? e->n_lanes : 0; }
@@ -1193,7 +1213,7 @@ extern "C" int wz_collect_bound(wz_engine_t* e, int slot) {
     for (int i = 0; i < L.n; ++i)
         memcpy(e->bound[L.bound_idx[i]].rows, L.h_rows + (size_t)i * WZ_MAX_DETECTIONS, sizeof(wz_detection_t) * WZ_MAX_DETECTIONS);
     L.bound_idx.clear();
-    return WZ_OK;
+    return lane_status(e, slot);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1434,7 +1454,8 @@ extern "C" int wz_stage_preprocess_fmt(wz_engine_t* e, const uint8_t* rgb, int w
     if (rc != WZ_OK) return rc;
     HIPCHK(hipMemcpyAsync(e->lanes[0].d_desc, e->lanes[0].h_desc, sizeof(WzFrameDesc), hipMemcpyHostToDevice, e->stream));
     const int S = (int)e->hdr.input_size;
-    wz_launch_preprocess(e->lanes[0].d_desc, 1, S, e->lanes[0].tptr[input_tensor_index(e)], e->stream, input_is_pair(e));
+    wz_launch_preprocess(e->lanes[0].d_desc, 1, S, e->lanes[0].tptr[input_tensor_index(e)], e->stream, input_is_pair(e), nullptr,
+                         e->hdr.resize_mode == 1);
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipMemcpy(out_half, e->lanes[0].tptr[input_tensor_index(e)], tensor_frame_bytes(e, input_tensor_index(e)),
                      hipMemcpyDeviceToHost));

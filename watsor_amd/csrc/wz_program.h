@@ -8,7 +8,7 @@
 #include <stdint.h>
 
 #define WZ_MAGIC 0x35335A57u /* "WZ35" */
-#define WZ_FORMAT_VERSION 7u
+#define WZ_FORMAT_VERSION 8u
 
 enum WzOpKind { WZ_OP_STEM = 1, WZ_OP_DW = 2, WZ_OP_CONV = 3, WZ_OP_MBCONV = 4 };
 enum WzOutMode { WZ_OUT_ACT = 0, WZ_OUT_BOX = 1, WZ_OUT_CLS = 2, WZ_OUT_HEAD = 3 };
@@ -28,8 +28,11 @@ struct WzBlobHeader {  // 160 bytes
     uint64_t tensors_off, ops_off, anchors_off, weights_off, weights_bytes, total_bytes;
     uint32_t n_slots;         // activation buffer slots after liveness packing
     uint32_t hp_blocks;       // leading inverted-residual blocks on the split-operand kernel (0 = plain fp16 program)
-    uint32_t reserved[10];
+    uint32_t resize_mode;     // 0: TF1 legacy ResizeBilinear (src = dst * scale); 1: half_pixel_centers ((dst + 0.5) * scale - 0.5)
+    uint32_t post_flags;      // bit 0: per-class NMS on the unclipped boxes, clip afterwards (else: clip, drop zero-area, NMS)
+    uint32_t reserved[8];
 };
+#define WZ_POSTF_CLIP_AFTER 1u
 
 struct WzTensorDesc {  // 64 bytes
     int32_t h, w, c;          // per frame, NHWC; c is the stored channel count (input: 4)

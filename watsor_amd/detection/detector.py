@@ -240,10 +240,13 @@ class BatchedWorkerMixin:
     def _retire_oldest(self, st, fps, inference_time, object_detector):
         lane, latches, t0, frames = st["inflight"].popleft()
         try:
-            if frames is None:
-                object_detector.collect_bound(lane)
-            else:
-                object_detector.collect(lane, [f.header.detections for f in frames])
+            try:
+                if frames is None:
+                    object_detector.collect_bound(lane)
+                else:
+                    object_detector.collect(lane, [f.header.detections for f in frames])
+            except ValueError as e:               # the rows were written; the engine says what is wrong with them
+                self._warn("batch of %d frames: %s" % (len(latches), e))
             now = perf_counter()
             # the batch's SERVICE time: from its submit, or from the previous retirement when it was queued behind another
             # lane's batch until then -- what `fps_max = 1000 / inference_time` (watsor/main.py:242-251) should be derived from

@@ -24,11 +24,65 @@ from . import arch
 from .anchors import ssd_anchor_table
 
 MAGIC = 0x35335A57
-FORMAT_VERSION = 7
+FORMAT_VERSION = 8
 BN_EPSILON = 1e-3          # watsor/test/model/prepare.py:48
 
 DEFAULT_POST = dict(max_total=100, max_per_class=100, score_threshold=1e-8, iou_threshold=0.6,
                     scales=(10.0, 10.0, 5.0, 5.0))   # prepare.py:54-61,120-128; SURVEY.md App. B.5
+# The two steps whose form differs between exporter generations: how ResizeBilinear maps output to
+# input coordinates, and whether boxes are clipped to the image before or after the per-class NMS.  Defaults = the 2018 graph
+# the reference's README names; a frozen graph's own ResizeBilinear attributes override the first (frozen_graph.graph_settings).
+RESIZE_MODES = {"legacy": 0, "half_pixel": 1}
+DEFAULT_OPTIONS = dict(resize="legacy", clip_after_nms=False)
+
+
+def apply_graph_settings(settings: dict, model_width: int, model_height: int, post: Optional[dict], options: Optional[dict]):
+    """What a frozen graph says about itself (`frozen_graph.graph_settings`) -> (post, options) for `build_engine`; raises
+    ValueError for a graph this engine cannot reproduce.  Explicit `post` / `options` entries must agree with the graph."""
+    post, options = dict(post or {}), dict(options or {})
+
+    def adopt(target, key, value, what):
+        if key in target and target[key] != value:
+            raise ValueError("%s: the graph says %r, the command line says %r" % (what, value, target[key]))
+        target[key] = value
+
+    if "input_size" in settings and tuple(settings["input_size"]) != (model_height, model_width):
+        raise ValueError("the graph resizes its input to %dx%d, the engine is being built for %dx%d (-mw / -mh)"
+                         % (settings["input_size"][1], settings["input_size"][0], model_width, model_height))
+    if settings.get("resize_align_corners"):
+        raise ValueError("the graph's ResizeBilinear has align_corners=True: not a resize mode of this engine")
+    if "resize_half_pixel_centers" in settings:
+        adopt(options, "resize", "half_pixel" if settings["resize_half_pixel_centers"] else "legacy", "resize mode")
+    for key, what in (("iou_threshold", "NMS IoU threshold"), ("score_threshold", "score threshold"),
+                      ("max_per_class", "detections per class"), ("max_total", "total detections")):
+        if key in settings:
+            v = settings[key]
+            if key.endswith("threshold"):
+                v = float(np.float32(v))
+                if key in post:
+                    post[key] = float(np.float32(post[key]))
+            adopt(post, key, v, what)
+    if "box_scales" in settings:
+        sc = tuple(float(x) for x in settings["box_scales"])
+        if len(sc) != 4 or min(sc) <= 0:
+            raise ValueError("the graph's box decoder has %d scale factors %r, expected (ty, tx, th, tw)" % (len(sc), sc))
+        adopt(post, "scales", sc, "box coder scale factors")
+    if settings.get("anchor_vectors"):
+        from .anchors import ssd_box_specs
+        specs = ssd_box_specs()
+        expected = []
+        for layer in specs:
+            expected.append(np.array([s for s, _ in layer], np.float32))
+            expected.append(np.array([r for _, r in layer], np.float32))
+        lengths = {len(layer) for layer in specs}
+        for v in settings["anchor_vectors"]:
+            if v.size in lengths and not any(e.size == v.size and np.allclose(e, v, rtol=0, atol=2e-4) for e in expected):
+                raise ValueError("the graph's anchor generator holds %s, which is neither a scale nor an aspect-ratio list of this "
+                                 "engine's anchors (scales 0.2 .. 0.95, ratios 1, 2, 1/2, 3, 1/3; watsor_amd/anchors.py)"
+                                 % np.array2string(v, precision=4))
+    if post.get("max_total", 100) > 100 or post.get("max_total", 100) < 1:
+        raise ValueError("max_total %r: the Detection array of a frame holds 100 rows (watsor/stream/share.py:31)" % post["max_total"])
+    return post, options
 
 
 def _align(n: int, a: int = 256) -> int:
@@ -166,7 +220,7 @@ def assign_slots(prog: "arch.Program", tensor_names: List[str]) -> List[int]:
 
 def build_engine(weights: Dict[str, np.ndarray], precision: int = 16, model_width: int = 300,
                  model_height: int = 300, post: Optional[dict] = None, fuse: bool = True,
-                 fuse_stem: bool = True, hp_upto: Optional[int] = None) -> bytes:
+                 fuse_stem: bool = True, hp_upto: Optional[int] = None, options: Optional[dict] = None) -> bytes:
     """Returns the engine image.  Mirrors `build_engine` of watsor/engine.py:17-51.
     fuse=False keeps one op per layer (used by the per-layer parity tests; same results, slower).
     hp_upto: last inverted-residual block on the split-operand kernel (default for the `-p 16` program with fused
@@ -180,6 +234,10 @@ def build_engine(weights: Dict[str, np.ndarray], precision: int = 16, model_widt
         raise ValueError("square model input expected")
     cfg = dict(DEFAULT_POST)
     cfg.update(post or {})
+    opt = dict(DEFAULT_OPTIONS)
+    opt.update(options or {})
+    if opt["resize"] not in RESIZE_MODES:
+        raise ValueError("resize mode %r: expected one of %s" % (opt["resize"], ", ".join(RESIZE_MODES)))
     if hp_upto is None:
         hp_upto = arch.HP_LAST_BLOCK if (precision == 16 and fuse and fuse_stem) else -1
     prog = arch.build(model_width, fuse=fuse, fuse_stem=fuse_stem, hp_upto=hp_upto)
@@ -321,7 +379,7 @@ def build_engine(weights: Dict[str, np.ndarray], precision: int = 16, model_widt
         cfg["max_total"], cfg["max_per_class"],
         cfg["score_threshold"], cfg["iou_threshold"], sy, sx, sh, sw,
         tensors_off, ops_off, anchors_off, weights_off, len(wblob), total,
-        max(slots) + 1, hp_upto + 1, *([0] * 10))
+        max(slots) + 1, hp_upto + 1, RESIZE_MODES[opt["resize"]], 1 if opt["clip_after_nms"] else 0, *([0] * 8))
     assert len(header) == header_size
     out = bytearray(total)
     out[:header_size] = header
@@ -339,6 +397,14 @@ def save_engine(engine: bytes, engine_dest_path: str) -> None:
     with open(tmp, "wb") as f:
         f.write(engine)
     os.replace(tmp, engine_dest_path)
+
+
+def load_model(model_path: str):
+    """(variables, settings): settings = what a frozen graph says about its own pre- / post-processing (empty for .npz)."""
+    if model_path.endswith(".pb") and os.path.isfile(model_path):
+        from .frozen_graph import read_frozen_graph_model
+        return read_frozen_graph_model(model_path)
+    return load_weights(model_path), {}
 
 
 def load_weights(model_path: str) -> Dict[str, np.ndarray]:
@@ -371,13 +437,26 @@ def main(argv=None) -> int:
     parser.add_argument("-mh", "--model-height", type=int, default=300, help="model image height")
     parser.add_argument("-o", "--output", dest="engine_path", help="path of the output file",
                         default=os.path.join(os.getcwd(), "model", "mi355x.bin"))
+    parser.add_argument("--resize", choices=sorted(RESIZE_MODES), default=None,
+                        help="coordinate rule of the bilinear resize: legacy = TF1 ResizeBilinear(align_corners=False), the 2018 graph; "
+                             "half_pixel = half_pixel_centers=True of later exporters (default: what the .pb says, else legacy)")
+    parser.add_argument("--clip-after-nms", action="store_true",
+                        help="run the per-class NMS on the unclipped boxes and clip what it selected (later Object Detection API "
+                             "exporters) instead of clipping first (the 2018 graph)")
     parser.add_argument("--plain-fp16", action="store_true",
                         help="-p 16 only: one fp16 rounding per operand everywhere (about 1.3x faster; scores then differ "
                              "from the fp32 detector by up to 3e-3 instead of staying within 1e-3)")
     args = parser.parse_args(argv)
     print("Building MI355X engine from {}.".format(args.model_path))
-    engine = build_engine(load_weights(args.model_path), args.precision, args.model_width, args.model_height,
-                          hp_upto=-1 if args.plain_fp16 else None)
+    weights, settings = load_model(args.model_path)
+    options = {"clip_after_nms": True} if args.clip_after_nms else {}
+    if args.resize:
+        options["resize"] = args.resize
+    post, options = apply_graph_settings(settings, args.model_width, args.model_height, None, options)
+    if settings:
+        print("Settings read from the graph: " + ", ".join("%s=%s" % (k, v) for k, v in sorted(settings.items()) if k != "anchor_vectors"))
+    engine = build_engine(weights, args.precision, args.model_width, args.model_height, post=post,
+                          hp_upto=-1 if args.plain_fp16 else None, options=options)
     save_engine(engine, args.engine_path)
     print("MI355X engine saved to {} ({:.1f} MB)".format(args.engine_path, len(engine) / 1e6))
     return 0
