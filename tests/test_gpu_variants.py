@@ -48,14 +48,28 @@ def test_half_pixel_resize_bit_exact(dir_half_pixel, wh):
         e.close()
 
 
-def outside_heavy_head_outputs(seed):
-    """Head outputs whose decoded boxes are large and often reach (or lie) beyond the image, with a trained-like score
-    distribution: where clipping first and clipping last give different rows."""
+def outside_heavy_head_outputs(seed, n_objects=40, per_object=6):
+    """Head outputs shaped like a detector's on a scene whose objects straddle the image border: per object a handful of nearby
+    anchors of one class, each decoding to a jittered copy of the object's box -- boxes that overlap each other by more than
+    the NMS threshold as decoded and by less (or not at all) once clipped, and the other way round: clipping first and
+    clipping last keep different rows (checked below on the oracle twins)."""
     rng = np.random.default_rng(seed)
-    be = (rng.standard_normal((2, 1917, 4)) * np.array([6.0, 6.0, 3.0, 3.0])).astype(np.float32)    # centres far off, sizes x e^(0.6)
-    lg = (rng.standard_normal((2, 1917, 91)) * 2.0 - 5.0).astype(np.float32)
-    hot = rng.integers(0, 1917, 300)
-    lg[:, hot, rng.integers(1, 91, 300)] += 6.0
+    anchors = pu.anchors_cs()
+    be = np.zeros((2, 1917, 4), np.float32)
+    be[:, :, 2:] = -3.0
+    lg = (rng.standard_normal((2, 1917, 91)) * 1.0 - 7.0).astype(np.float32)
+    for f in range(2):
+        for _ in range(n_objects):
+            cy, cx = rng.uniform(-0.15, 1.15, 2)
+            h, w = rng.uniform(0.15, 0.6, 2)
+            cls = int(rng.integers(1, 91))
+            near = np.argsort((anchors[:, 0] - cy) ** 2 + (anchors[:, 1] - cx) ** 2)[:per_object * 3]
+            for a in rng.choice(near, per_object, replace=False):
+                jy, jx = rng.normal(0, 0.02, 2)
+                jh, jw = np.exp(rng.normal(0, 0.08, 2))
+                ay, ax, ah, aw = anchors[a]
+                be[f, a] = [((cy + jy) - ay) / ah * 10, ((cx + jx) - ax) / aw * 10, np.log(h * jh / ah) * 5, np.log(w * jw / aw) * 5]
+                lg[f, a, cls] = rng.uniform(0.5, 4.0)
     return be, lg
 
 
@@ -65,7 +79,6 @@ def test_clip_after_nms_matches_its_oracle_twin(dir_clip_after, model_dir, seed)
     after = conftest.make_engine(dir_clip_after, max_batch=2, dev=True)
     before = conftest.make_engine(model_dir, max_batch=2, dev=True)
     try:
-        differ = 0
         for eng, kw in ((after, dict(clip_after_nms=True)), (before, {})):
             B, S, C, N = eng.stage_postprocess(be, lg)
             rB, rS, rC, rN = pu.oracle_postprocess(be, lg, **kw)
@@ -74,10 +87,9 @@ def test_clip_after_nms_matches_its_oracle_twin(dir_clip_after, model_dir, seed)
             np.testing.assert_allclose(S, rS, rtol=0, atol=1e-6)
             np.testing.assert_allclose(B, rB, rtol=0, atol=2e-6)
             assert (B >= 0).all() and (B <= 1).all()
-            differ += 1 if kw else 0
         a = pu.oracle_postprocess(be, lg, clip_after_nms=True)
         b = pu.oracle_postprocess(be, lg)
-        assert (a[1] != b[1]).any() or (a[0] != b[0]).any()           # the inputs do tell the two orders apart
+        assert (a[1] != b[1]).sum() > 50                              # the inputs do tell the two orders apart
     finally:
         after.close()
         before.close()

@@ -260,13 +260,15 @@ __device__ __forceinline__ float4_t wz_pair_pre(float area, int cls, const WzIou
 // `fmaxf` / `fminf` on values that come out of LDS cost an extra canonicalising v_max_f32 per operand
 __device__ __forceinline__ float wz_max_nn(float a, float b) { return __uint_as_float(max(__float_as_uint(a), __float_as_uint(b))); }
 __device__ __forceinline__ float wz_min_nn(float a, float b) { return __uint_as_float(min(__float_as_uint(a), __float_as_uint(b))); }
+// SIGNED: the boxes may have negative coordinates (clip-after-NMS programs walk the boxes as decoded): plain fmaxf / fminf
+template <bool SIGNED>
 __device__ __forceinline__ bool wz_pair_suppresses(const float4_t a, const float4_t pa, const float4_t c,
                                                    const float4_t pc, const WzIouThr t) {
     // straight-line except for the rare near-threshold case: the pair loop is issue-bound (one CU, ~30 instructions
     // per pair), so every instruction and every divergent branch counts
     const bool same = __float_as_int(pa[3]) == __float_as_int(pc[3]);
-    const float iy0 = wz_max_nn(a[0], c[0]), ix0 = wz_max_nn(a[1], c[1]);
-    const float iy1 = wz_min_nn(a[2], c[2]), ix1 = wz_min_nn(a[3], c[3]);
+    const float iy0 = SIGNED ? fmaxf(a[0], c[0]) : wz_max_nn(a[0], c[0]), ix0 = SIGNED ? fmaxf(a[1], c[1]) : wz_max_nn(a[1], c[1]);
+    const float iy1 = SIGNED ? fminf(a[2], c[2]) : wz_min_nn(a[2], c[2]), ix1 = SIGNED ? fminf(a[3], c[3]) : wz_min_nn(a[3], c[3]);
     const float inter = fmaxf(iy1 - iy0, 0.0f) * fmaxf(ix1 - ix0, 0.0f);
     const bool above_lo = inter > pa[0] + pc[0], above_hi = inter > pa[1] + pc[1];
     bool r = same & above_hi;
@@ -348,6 +350,7 @@ __device__ __forceinline__ int wz_try_keep(NmsShared* S, int kept, const float4_
 
 // One band = all candidates whose score bits fall in histogram bins [lo_bin, hi_bin), `cnt` of them in
 // S->keys (unsorted composites).  Sort, gather boxes, walk.  Returns the new kept count (block-uniform).
+template <bool SIGNED>
 __device__ int wz_nms_band(NmsShared* S, const WzPostBuffers& b, const WzPostConsts& k, int f, int cnt, int kept) {
     const int tid = threadIdx.x;
     const int A = k.num_anchors;
@@ -441,7 +444,7 @@ __device__ int wz_nms_band(NmsShared* S, const WzPostBuffers& b, const WzPostCon
         if (tid == 0 && base == 0) b.dbg[(size_t)f * 16 + 11] = wall_clock64();
         for (int p = tid; p < m * kept; p += NMS_THREADS) {          // vs boxes kept before this chunk
             const int i = p / kept, j = p - i * kept;
-            if (wz_pair_suppresses(S->cnorm[i], S->cpre[i], S->knorm[j], S->kpre[j], ithr))
+            if (wz_pair_suppresses<SIGNED>(S->cnorm[i], S->cpre[i], S->knorm[j], S->kpre[j], ithr))
                 S->cdead[i] = 1u;                                    // benign race: every writer stores 1
         }
         {   // supp[j][w]: bit i of word w = "member 64w + i (before j) suppresses j", built in registers.
@@ -466,7 +469,7 @@ __device__ int wz_nms_band(NmsShared* S, const WzPostBuffers& b, const WzPostCon
                 const int i_end = j < m ? min(i0 + 32, j) : i0;      // i before j
                 uint32_t bits = 0u;
                 for (int i = i0; i < i_end; ++i)                      // i is wave-uniform: LDS broadcasts
-                    bits |= wz_pair_suppresses(bj, pj, S->cnorm[i], S->cpre[i], ithr) ? 1u << (i - i0) : 0u;
+                    bits |= wz_pair_suppresses<SIGNED>(bj, pj, S->cnorm[i], S->cpre[i], ithr) ? 1u << (i - i0) : 0u;
                 word[h] = bits;
             }
         }
@@ -787,7 +790,7 @@ __global__ __launch_bounds__(NMS_THREADS) void wz_k_nms(WzPostBuffers b, WzPostC
                 kept = wz_nms_band_serial(S, b, k, f, kept, (unsigned long long)((uint32_t)lo_bin << 20) << 32,
                                           (unsigned long long)((uint32_t)hi_bin << 20) << 32);
             else if (cnt > 0)
-                kept = wz_nms_band(S, b, k, f, (int)cnt, kept);
+                kept = kc.clip_after ? wz_nms_band<true>(S, b, k, f, (int)cnt, kept) : wz_nms_band<false>(S, b, k, f, (int)cnt, kept);
             processed += cnt;
             if (first) { NMS_STAMP(3); if (tid == 0) { b.dbg[(size_t)f * 16 + 8] = cnt; b.dbg[(size_t)f * 16 + 9] = kept; } }
             first = false;
@@ -844,7 +847,7 @@ __global__ __launch_bounds__(NMS_THREADS) void wz_k_nms(WzPostBuffers b, WzPostC
             kept = wz_nms_band_serial(S, b, k, f, kept, (unsigned long long)((uint32_t)lo_bin << 20) << 32,
                                       (unsigned long long)((uint32_t)hi_bin << 20) << 32);
         else if (cnt_raw > 0)
-            kept = wz_nms_band(S, b, k, f, (int)cnt_raw, kept);
+            kept = kc.clip_after ? wz_nms_band<true>(S, b, k, f, (int)cnt_raw, kept) : wz_nms_band<false>(S, b, k, f, (int)cnt_raw, kept);
         processed += cnt_raw;
         if (first) { NMS_STAMP(3); if (tid == 0) { b.dbg[(size_t)f * 16 + 8] = cnt_raw; b.dbg[(size_t)f * 16 + 9] = kept; } }
         if (kept >= k.max_total || processed >= total || lo_bin == 0) break;
