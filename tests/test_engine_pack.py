@@ -311,3 +311,24 @@ def test_fp32_engine_packs_unrounded_weights(synth_weights):
         elif o["kind"] == arch.OP_DW:
             w = np.frombuffer(blob32, np.float32, 9 * op.cin, hdr["weights_off"] + o["w_off"]).reshape(9, op.cin)
             np.testing.assert_array_equal(w, wf.reshape(9, op.cin).astype(np.float32))
+
+
+def test_builder_reports_the_channel_spread_and_warns_beyond_what_was_validated(tmp_path, synth_weights, capsys):
+    """the -p 16 program's 1e-3 margin was established on He-initialised weights.  The builder measures what
+    the simulation (tools/err_budget.py, SPREAD=...) shows to matter and says so."""
+    from watsor_amd.synth import spread_channel_scales
+    base = engine.channel_spread_decades(synth_weights)
+    assert 0.1 < base < 0.35
+    wide = spread_channel_scales(synth_weights, 1.5)
+    assert 1.1 < engine.channel_spread_decades(wide) < 1.6
+    np.savez(str(tmp_path / "wide.npz"), **wide)
+    out = str(tmp_path / "m" / "mi355x.bin")
+    assert engine.main(["-i", str(tmp_path / "wide.npz"), "-o", out]) == 0
+    cap = capsys.readouterr()
+    assert "WARNING" in cap.err and "-p 32" in cap.err and "decades" in cap.out
+    with pytest.raises(ValueError):
+        engine.main(["-i", str(tmp_path / "wide.npz"), "-o", out, "--precision-check", "error"])
+    assert engine.main(["-i", str(tmp_path / "wide.npz"), "-o", out, "-p", "32"]) == 0
+    assert "WARNING" not in capsys.readouterr().err
+    assert engine.main(["-i", "synthetic", "-o", out]) == 0
+    assert "WARNING" not in capsys.readouterr().err

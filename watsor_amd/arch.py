@@ -124,8 +124,10 @@ def _blk(i: int) -> str:
 HP_LAST_BLOCK = 12   # the blocks in front of the first SSD feature map (the 150x150 ... 19x19 maps)
 
 
-def build(size: int = INPUT_SIZE, fuse: bool = True, fuse_stem: bool = True, hp_upto: int = -1) -> Program:
-    """hp_upto >= 0 (needs fuse and fuse_stem): blocks 0 .. hp_upto run on the split-operand kernel and the tensors
+def build(size: int = INPUT_SIZE, fuse: bool = True, fuse_stem: bool = True, hp_upto: int = -1, input_pair: bool = False) -> Program:
+    """input_pair: the network input is stored as a hi + lo pair of halves even without split-operand blocks (the `-p 32` program:
+    one fp16 rounding of the resized image is otherwise the largest error of an engine that computes in fp32).
+    hp_upto >= 0 (needs fuse and fuse_stem): blocks 0 .. hp_upto run on the split-operand kernel and the tensors
     between them (the network input included) are hi + lo fp16 pairs; block hp_upto's output is plain fp16 again.
     fuse=True: every inverted-residual block is ONE op (OP_MBCONV); block 13 keeps its expand conv as
     a separate op because its output is the first SSD feature map.  fuse=False: one op per layer (the
@@ -191,7 +193,7 @@ def build(size: int = INPUT_SIZE, fuse: bool = True, fuse_stem: bool = True, hp_
                 op.hp = True
 
     # shape inference
-    p.tensors["input"] = Tensor("input", size, size, 3, hp=hp_upto >= 0)
+    p.tensors["input"] = Tensor("input", size, size, 3, hp=hp_upto >= 0 or input_pair)
     for op in ops:
         src = p.tensors[op.src]
         op.hin, op.win = src.h, src.w

@@ -19,10 +19,13 @@
 
 #include "wz_common.h"
 
+// pair: the input tensor holds (r, g, b, 0) hi then (r, g, b, 0) lo per pixel (wz_k_preprocess<true>): x = hi + lo, i.e. the resized
+// image to ~22 significant bits instead of fp16's 11 -- the input rounding was this engine's largest error on weights with a wide
+// per-channel dynamic range (tests/test_gpu_stress.py: 5e-4 of the scores)
 __global__ __launch_bounds__(256) void wz_k_stem_f32(const half_t* __restrict__ in, const float* __restrict__ w,
                                                      const float* __restrict__ bias, float* __restrict__ out,
                                                      int total, int hin, int win, int hout, int wout, int pad_t,
-                                                     int pad_l) {
+                                                     int pad_l, int pair) {
     __shared__ float sw[27 * 32 + 32];
     for (int i = threadIdx.x; i < 27 * 32; i += 256) sw[i] = w[i];
     if (threadIdx.x < 32) sw[27 * 32 + threadIdx.x] = bias[threadIdx.x];
@@ -44,10 +47,13 @@ __global__ __launch_bounds__(256) void wz_k_stem_f32(const half_t* __restrict__ 
         for (int kx = 0; kx < 3; ++kx) {
             const int ix = ox * 2 - pad_l + kx;
             if (ix < 0 || ix >= win) continue;
-            const half4_t p = *reinterpret_cast<const half4_t*>(in + ((size_t)(b * hin + iy) * win + ix) * 4);
+            const size_t px = (size_t)(b * hin + iy) * win + ix;
+            const half4_t p = *reinterpret_cast<const half4_t*>(in + px * (pair ? 8 : 4));
+            half4_t pl = {0, 0, 0, 0};
+            if (pair) pl = *reinterpret_cast<const half4_t*>(in + px * 8 + 4);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float x = (float)p[c];
+                const float x = (float)p[c] + (float)pl[c];
                 const float* wr = sw + ((ky * 3 + kx) * 3 + c) * 32 + cg * 8;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] = fmaf(x, wr[j], acc[j]);
@@ -343,10 +349,10 @@ __global__ __launch_bounds__(256) void wz_k_splitk_reduce_f32(const WzConvArgs a
 }
 
 void wz_launch_stem_f32(const half_t* in, const float* w, const float* bias, float* out, int n, int hin, int win,
-                        int hout, int wout, int pad_t, int pad_l, hipStream_t s) {
+                        int hout, int wout, int pad_t, int pad_l, hipStream_t s, bool pair) {
     const int total = n * hout * wout * 4;
     WZ_LAUNCH(wz_k_stem_f32, dim3((total + 255) / 256), dim3(256), 0, s, in, w, bias, out, total, hin, win,
-                       hout, wout, pad_t, pad_l);
+                       hout, wout, pad_t, pad_l, pair ? 1 : 0);
 }
 
 void wz_launch_dw_f32(const float* in, const float* w, const float* bias, float* out, int n, int hin, int win, int c,

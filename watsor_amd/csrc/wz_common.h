@@ -226,7 +226,7 @@ bool wz_tail_layer_ok(const WzConvArgs& a, int n_frames);
 void wz_launch_extras_tail(const WzTailArgs& A, int n_frames, hipStream_t s);
 // `-p 32` engine (k_f32.hip): fp32 activations and weights, exact-fp32 MFMA
 void wz_launch_stem_f32(const half_t* in, const float* w, const float* bias, float* out, int n, int hin, int win,
-                        int hout, int wout, int pad_t, int pad_l, hipStream_t s);
+                        int hout, int wout, int pad_t, int pad_l, hipStream_t s, bool pair = false);
 void wz_launch_dw_f32(const float* in, const float* w, const float* bias, float* out, int n, int hin, int win, int c,
                       int hout, int wout, int stride, int pad_t, int pad_l, int act, hipStream_t s);
 void wz_launch_conv_f32(const WzConvArgs& a, hipStream_t s, bool reduce = true);   // + its split-K reduce when a.splitk > 1 (unless !reduce)

@@ -259,7 +259,7 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
         const uint8_t* wbase = e->d_weights;
         if (f32 && op.kind == WZ_OP_STEM) {
             wz_launch_stem_f32(L.tptr[op.src], (const float*)(wbase + op.w_off), (const float*)(wbase + op.b_off),
-                               (float*)L.tptr[op.dst], n, op.hin, op.win, op.hout, op.wout, op.pad_t, op.pad_l, s);
+                               (float*)L.tptr[op.dst], n, op.hin, op.win, op.hout, op.wout, op.pad_t, op.pad_l, s, input_is_pair(e));
         } else if (f32 && op.kind == WZ_OP_DW) {
             wz_launch_dw_f32((const float*)L.tptr[op.src], (const float*)(wbase + op.w_off), (const float*)(wbase + op.b_off),
                              (float*)L.tptr[op.dst], n, op.hin, op.win, op.cin, op.hout, op.wout, op.stride, op.pad_t,
@@ -660,6 +660,9 @@ static int load_blob(wz_engine* e, const char* path) {
             wz_engine::Lane none;
             if (wz_launch_mbconv_hp(mb_args(e, none, op), 1, nullptr, true) != 0)
                 return wz_fail(WZ_EFORMAT, "%s: op %u (%s): no split-operand kernel for this shape", path, i, op.name);
+        } else if (op.kind == WZ_OP_STEM && h.precision == 32 && (e->tensors[op.src].flags & WZ_TENSOR_HP) &&
+                   !(op.dst >= 0 && (e->tensors[op.dst].flags & WZ_TENSOR_HP))) {
+            // the fp32 program's stem reads the network input as a hi + lo pair (wz_k_stem_f32)
         } else if ((e->tensors[op.src].flags & WZ_TENSOR_HP) || (op.dst >= 0 && (e->tensors[op.dst].flags & WZ_TENSOR_HP)) ||
                    (op.res >= 0 && (e->tensors[op.res].flags & WZ_TENSOR_HP))) {
             return wz_fail(WZ_EFORMAT, "%s: op %u (%s) touches a pair tensor but is not a split-operand block", path, i, op.name);
