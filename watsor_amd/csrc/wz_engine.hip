@@ -1098,7 +1098,8 @@ extern "C" int wz_detect_batch_fmt(wz_engine_t* e, int n, const uint8_t* const* 
 // (wz_host_register) that is one SDMA transfer at PCIe rate; pageable memory is staged by the runtime.  (A copy KERNEL reading
 // the frames through their device-mapped addresses -- one graph node per batch instead of one call per frame -- reaches
 // 55 GB/s on its own, tools/micro/h2d_streams.hip, but only 23 GB/s beside the other lanes' kernels against the copies'
-// 29 GB/s: profiles/r03_host_path_*.)
+// 29 GB/s; a fifth stream for the copies alone, so that whole batches arrive back to back: 24.8 k against 31.5 k frames/s at
+// 640x480 -- this stack runs four streams side by side, section 10 of DESIGN.md: profiles/r03_host_path_*.)
 static int stage_frame(wz_engine* e, Lane& L, int i, const uint8_t* host, uint64_t bytes, const uint8_t** where) {
     uint8_t* dst = L.d_frames + e->frame_stride * i;
     HIPCHK(hipMemcpyAsync(dst, host, bytes, hipMemcpyHostToDevice, L.stream));
