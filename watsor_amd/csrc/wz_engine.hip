@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
 #include <map>
 #include <string>
@@ -45,7 +46,6 @@ int wz_set_error(int code, const char* fmt, ...) {
                                              __FILE__, __LINE__);                                     \
     } while (0)
 
-#define WZ_WS_BYTES (256ull << 20)
 #define WZ_TICKETS 8192   // tile counters per lane: first half the tile-kernel heads, second half the small ones
 
 struct StageTimer {
@@ -97,6 +97,8 @@ struct wz_engine {
     size_t frame_stride = 0;
     WzPostConsts pc;
     size_t post_scratch_bytes = 0;
+    size_t ws_bytes = 0;       // split-K / channel-group workspace per lane: 32 MiB per frame of max_batch, at least 64 MiB (the heads'
+                               // parked partial sums take ~10 MiB per frame, the other ops keep the lower half)
 
     // A lane is everything one in-flight batch needs: its own stream, activation buffers, head
     // outputs, post-processing scratch, descriptor/result blocks and captured graphs.  Lanes run
@@ -112,6 +114,7 @@ struct wz_engine {
         float* d_ws = nullptr;
         int32_t* d_tickets = nullptr;        // tile counters of the in-launch head reductions (zero between launches)
         WzHeadFinish* d_fin = nullptr;       // what finishing a head output needs (static)
+        int launch_failed = 0;               // op index + 1 of a block no kernel took at launch time (enqueue_network), else 0
         bool decode_fused = false;           // set by enqueue_network: the grouped head reduce decoded the boxes
         bool cands_listed = false;           // ... and listed the candidates of the NMS kernel's first band
         uint8_t* d_frames = nullptr;         // staging for host frames of this lane [max_batch][frame_stride] (lazy)
@@ -210,7 +213,7 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
     // The heads write only into the box / logit buffers that the post kernels read at the very end, so their partial
     // sums can wait: each head's slab is parked at the top of the workspace and ONE launch reduces them all after the
     // last op (six launches fewer per batch).  Everything else uses the workspace below `ws_top`.
-    size_t ws_top = WZ_WS_BYTES;
+    size_t ws_top = e->ws_bytes;
     WzReduceGroup heads;
     heads.n = 0;
     heads.first[0] = 0;
@@ -279,6 +282,7 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
             a.dbg = e->d_mbdbg ? e->d_mbdbg + (size_t)i * 16 : nullptr;
             int groups = a.hp ? wz_launch_mbconv_hp(a, n, s, false)   // split-operand blocks (the `-p 16` program's first 13)
                               : wz_launch_mbconv_wave(a, n, s, false);   // large maps: one wavefront per pixel tile
+            if (a.hp && groups < 0) L.launch_failed = (int)i + 1;   // nothing was enqueued for a split-operand block: run_batch reports it
             if (groups == -2 && e->use_splitk) groups = wz_launch_mbconv_cs(a, n, s, false);   // small maps: channels over waves
             if (groups == -2) groups = wz_launch_mbconv(a, n, s, false);
             if (e->d_mbdbg) e->mb_groups[i] = groups;
@@ -382,7 +386,7 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
                 int sk = !e->use_splitk ? 1 : wz_conv_f32_use_rs(a) ? wz_choose_splitk_rs_f32(a.M, a.n_pad, a.kchunks) : wz_choose_splitk(a.M, a.n_pad, a.kchunks / 2);
                 const size_t slab32 = (((size_t)sk * a.M * a.n_pad * 4) + 255) & ~(size_t)255;
                 if (sk > 1 && e->defer_heads && op.out_mode != WZ_OUT_ACT && heads.n < WZ_REDUCE_GROUP_MAX &&
-                    slab32 + (WZ_WS_BYTES >> 1) <= ws_top) {
+                    slab32 + (e->ws_bytes >> 1) <= ws_top) {
                     // the heads' outputs are fp32 in both engines and their epilogue is the same: the partial sums are
                     // parked and reduced (+ decoded, + candidates marked) by the same grouped launch as in the fp16 engine
                     ws_top -= slab32;
@@ -417,14 +421,14 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
             bool to_wide = wide_T > 0 && wide.n < WZ_CONV_GROUP_MAX && wz_conv_wide_applies(a) && a.M >= e->wide_min_m;
             if (to_wide) {   // its partial sums always go through the grouped reduce, also with a single K slice
                 const int wsk = ((a.kchunks >> 1) + wide_T - 1) / wide_T;
-                if (heads.n < WZ_REDUCE_GROUP_MAX && ((((size_t)wsk * a.M * a.n_pad * 4) + 255) & ~(size_t)255) + (WZ_WS_BYTES >> 1) <= ws_top)
+                if (heads.n < WZ_REDUCE_GROUP_MAX && ((((size_t)wsk * a.M * a.n_pad * 4) + 255) & ~(size_t)255) + (e->ws_bytes >> 1) <= ws_top)
                     sk = wsk;
                 else
                     to_wide = false;
             }
             const size_t slab = (((size_t)sk * a.M * a.n_pad * 4) + 255) & ~(size_t)255;
             if ((sk > 1 || to_wide) && e->defer_heads && op.out_mode != WZ_OUT_ACT && heads.n < WZ_REDUCE_GROUP_MAX &&
-                slab + (WZ_WS_BYTES >> 1) <= ws_top) {   // keep at least half of the workspace for the other ops
+                slab + (e->ws_bytes >> 1) <= ws_top) {   // keep at least half of the workspace for the other ops
                 ws_top -= slab;
                 float* const park = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(L.d_ws) + ws_top);
                 a.splitk = sk;
@@ -557,6 +561,11 @@ static void enqueue_batch(wz_engine* e, Lane& L, int n, StageTimer* t, int inner
 
 static int run_batch(wz_engine* e, int slot, int n) {
     Lane& L = e->lanes[slot];
+    auto failed = [&]() -> int {   // a split-operand block no kernel took (the load-time check prepared batch 1 only): nothing may run on stale data
+        const int op = L.launch_failed - 1;
+        L.launch_failed = 0;
+        return wz_fail(WZ_EFORMAT, "no split-operand kernel took op %d (%s) at batch %d", op, e->ops[op].name, n);
+    };
     if (e->use_graph) {
         auto it = L.graphs.find(n);
         if (it == L.graphs.end()) {
@@ -564,6 +573,10 @@ static int run_batch(wz_engine* e, int slot, int n) {
             HIPCHK(hipStreamBeginCapture(L.stream, hipStreamCaptureModeThreadLocal));
             enqueue_batch(e, L, n, nullptr);
             HIPCHK(hipStreamEndCapture(L.stream, &g));
+            if (L.launch_failed) {
+                (void)hipGraphDestroy(g);
+                return failed();
+            }
             size_t nodes = 0;
             if (hipGraphGetNodes(g, nullptr, &nodes) == hipSuccess) L.graph_nodes[n] = (int)nodes;
             hipGraphExec_t ge = nullptr;
@@ -575,6 +588,10 @@ static int run_batch(wz_engine* e, int slot, int n) {
     } else {
         enqueue_batch(e, L, n, nullptr);
         HIPCHK(hipGetLastError());
+        if (L.launch_failed) {
+            (void)hipStreamSynchronize(L.stream);
+            return failed();
+        }
     }
     HIPCHK(hipEventRecord(L.done, L.stream));
     L.n = n;
@@ -766,6 +783,7 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     CK(hipMalloc((void**)&e->d_anchors, (size_t)h.num_anchors * 16));
     CK(hipMemcpy(e->d_anchors, e->blob.data() + h.anchors_off, (size_t)h.num_anchors * 16, hipMemcpyHostToDevice));
     e->frame_stride = ((size_t)max_width * max_height * 3 + 255) & ~(size_t)255;
+    e->ws_bytes = std::max<size_t>((size_t)64 << 20, (size_t)max_batch * ((size_t)32 << 20));
     CK(hipMalloc((void**)&e->d_frames, e->frame_stride * max_batch));
 
     e->pc.num_anchors = h.num_anchors;
@@ -824,7 +842,7 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
         }
         CK(hipMalloc((void**)&L.d_box_enc, (size_t)max_batch * h.num_anchors * 4 * 4));
         CK(hipMalloc((void**)&L.d_logits, (size_t)max_batch * h.num_anchors * h.num_classes * 4));
-        CK(hipMalloc((void**)&L.d_ws, WZ_WS_BYTES));
+        CK(hipMalloc((void**)&L.d_ws, e->ws_bytes));
         CK(hipMalloc((void**)&L.d_tickets, WZ_TICKETS * 4));
         CK(hipMemset(L.d_tickets, 0, WZ_TICKETS * 4));
         CK(hipMalloc((void**)&L.d_fin, sizeof(WzHeadFinish)));
