@@ -10,6 +10,8 @@
 // Roofline: HBM-bound streaming kernel.  Algorithmic bytes per frame = W*H*3 read + size*size*4*2
 // written (the 4th channel is zero padding so the stem conv reads one aligned 8-byte pixel).
 #pragma clang fp contract(off)
+#include <string.h>
+
 #include "wz_common.h"
 
 // Pixel formats (WzFrameDesc::fmt; SURVEY 8f-3, the decoder side: `watsor/stream/ffmpeg.py:78-88` reads rawvideo frames
@@ -49,6 +51,38 @@ __device__ __forceinline__ void wz_fetch_rgb(const WzFrameDesc& f, int x, int y,
     c[2] = (float)min(max((298 * C + 516 * D + 128) >> 8, 0), 255);
 }
 
+// The two horizontal taps of one source row.  RGB24: pixels x_lo and x_hi = x_lo (+1) are 6 contiguous bytes, so ONE 12-byte load
+// from the 4-byte boundary below them replaces six byte loads (the kernel was bound by the number of vector-memory instructions:
+// twelve byte loads per output pixel); the last few bytes of a frame, where those 12 bytes could reach past it, are read byte-wise.
+__device__ __forceinline__ void wz_fetch_row_pair(const WzFrameDesc& f, int x_lo, int x_hi, int y, float (&a)[3], float (&b)[3]) {
+    if (f.fmt == WZ_FMT_RGB24) {
+        const size_t off = ((size_t)y * f.w + x_lo) * 3;
+        const size_t base = off & ~(size_t)3;
+        if (base + 12 <= (size_t)f.w * f.h * 3 && ((uintptr_t)f.rgb & 3) == 0) {
+            typedef __attribute__((ext_vector_type(3))) unsigned int u3;
+            const u3 v = *reinterpret_cast<const u3*>(f.rgb + base);
+            const unsigned sh = (unsigned)(off - base) * 8;                       // 0, 8, 16 or 24
+            const unsigned long long lo64 = ((unsigned long long)v[1] << 32) | v[0];
+            const unsigned long long hi64 = ((unsigned long long)v[2] << 32) | v[1];
+            const unsigned long long w0 = lo64 >> sh;                             // bytes 0 .. 7 - sh/8 of the window
+            const unsigned w1 = (unsigned)(hi64 >> sh);                           // bytes 4 .. 7 of the window (sh < 32)
+            a[0] = (float)(w0 & 0xff);
+            a[1] = (float)((w0 >> 8) & 0xff);
+            a[2] = (float)((w0 >> 16) & 0xff);
+            if (x_hi != x_lo) {
+                b[0] = (float)((w0 >> 24) & 0xff);
+                b[1] = (float)(w1 & 0xff);
+                b[2] = (float)((w1 >> 8) & 0xff);
+            } else {
+                b[0] = a[0]; b[1] = a[1]; b[2] = a[2];
+            }
+            return;
+        }
+    }
+    wz_fetch_rgb(f, x_lo, y, a);
+    wz_fetch_rgb(f, x_hi, y, b);
+}
+
 // HP: the network input is stored as a hi + lo pair of halves per value (hi = RN16(v), lo = RN16(v - hi), both
 // roundings and the subtraction exact-or-once-rounded fp32 operations): the first blocks of the `-p 16` program take
 // both (k_mbconv_hp.hip), which removes the 2^-11 input rounding from the error budget of the scores.
@@ -57,10 +91,13 @@ __device__ __forceinline__ void wz_fetch_rgb(const WzFrameDesc& f, int x, int y,
 // (a graph node of its own, ~4 us of a batch's latency) by one 32-byte read over PCIe per workgroup, in flight together.
 // `half_pixel`: the coordinate rule of graphs exported with ResizeBilinear(half_pixel_centers=True) -- src = (dst + 0.5) * scale - 0.5,
 // three roundings (`HalfPixelScaler`) -- instead of the legacy src = dst * scale (WzBlobHeader::resize_mode; oracle/preprocess.py).
+// `frames` == nullptr: the descriptors are the kernel's own ARGUMENTS (`pack`, up to WZ_DESC_PACK frames: scalar loads from the
+// kernarg segment) -- neither a copy node in front of the batch nor a read over PCIe at the head of every workgroup; the engine
+// rewrites them in the captured graph's node before every replay (wz_engine.hip: run_batch).
 template <bool HP>
-__global__ __launch_bounds__(256) void wz_k_preprocess(const WzFrameDesc* __restrict__ frames, int size,
+__global__ __launch_bounds__(256) void wz_k_preprocess(const WzFrameDesc* __restrict__ frames, const WzDescPack pack, int size,
                                                        half_t* __restrict__ out, WzFrameDesc* __restrict__ keep, int half_pixel) {
-    const WzFrameDesc f = frames[blockIdx.y];
+    const WzFrameDesc f = frames ? frames[blockIdx.y] : pack.d[blockIdx.y];
     if (keep && blockIdx.x == 0 && threadIdx.x == 0) keep[blockIdx.y] = f;
     const int pix = blockIdx.x * 256 + threadIdx.x;
     if (pix >= size * size) return;
@@ -78,10 +115,8 @@ __global__ __launch_bounds__(256) void wz_k_preprocess(const WzFrameDesc* __rest
     const float lx = in_x - fl_x;
 
     float tap[4][3];   // top-left, top-right, bottom-left, bottom-right
-    wz_fetch_rgb(f, x_lo, y_lo, tap[0]);
-    wz_fetch_rgb(f, x_hi, y_lo, tap[1]);
-    wz_fetch_rgb(f, x_lo, y_hi, tap[2]);
-    wz_fetch_rgb(f, x_hi, y_hi, tap[3]);
+    wz_fetch_row_pair(f, x_lo, x_hi, y_lo, tap[0], tap[1]);
+    wz_fetch_row_pair(f, x_lo, x_hi, y_hi, tap[2], tap[3]);
     half_t v[4], vl[4];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -105,10 +140,19 @@ __global__ __launch_bounds__(256) void wz_k_preprocess(const WzFrameDesc* __rest
 }
 
 void wz_launch_preprocess(const WzFrameDesc* d_frames, int n, int size, half_t* out, hipStream_t s, bool hp, WzFrameDesc* keep,
-                          bool half_pixel) {
+                          bool half_pixel, const WzFrameDesc* by_value) {
     dim3 grid((size * size + 255) / 256, n);
+    WzDescPack pack;
+    memset(&pack, 0, sizeof(pack));
+    if (by_value && n <= WZ_DESC_PACK) {
+        memcpy(pack.d, by_value, sizeof(WzFrameDesc) * n);
+        d_frames = nullptr;
+    }
     if (hp)
-        WZ_LAUNCH(wz_k_preprocess<true>, grid, dim3(256), 0, s, d_frames, size, out, keep, half_pixel ? 1 : 0);
+        WZ_LAUNCH(wz_k_preprocess<true>, grid, dim3(256), 0, s, d_frames, pack, size, out, keep, half_pixel ? 1 : 0);
     else
-        WZ_LAUNCH(wz_k_preprocess<false>, grid, dim3(256), 0, s, d_frames, size, out, keep, half_pixel ? 1 : 0);
+        WZ_LAUNCH(wz_k_preprocess<false>, grid, dim3(256), 0, s, d_frames, pack, size, out, keep, half_pixel ? 1 : 0);
+}
+const void* wz_preprocess_func(bool hp) {
+    return hp ? reinterpret_cast<const void*>(wz_k_preprocess<true>) : reinterpret_cast<const void*>(wz_k_preprocess<false>);
 }

@@ -150,8 +150,12 @@ static inline const char* wz_dev_getenv(const char* name) {
 
 #define WZ_LAUNCH(...) do { for (int _wz_r = 0; _wz_r < wz_launch_repeat; ++_wz_r) hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 // hp: the input tensor is a hi + lo pair (8 halves per pixel: r g b 0 | r g b 0)
+#define WZ_DESC_PACK 16
+struct WzDescPack { WzFrameDesc d[WZ_DESC_PACK]; };   // frame descriptors as kernel arguments (512 bytes)
+// keep, half_pixel, by_value (host descriptors to pass as kernel arguments when n <= WZ_DESC_PACK): see k_preprocess.hip
 void wz_launch_preprocess(const WzFrameDesc* d_frames, int n, int size, half_t* out, hipStream_t s, bool hp = false,
-                          WzFrameDesc* keep = nullptr, bool half_pixel = false);   // keep, half_pixel: see k_preprocess.hip
+                          WzFrameDesc* keep = nullptr, bool half_pixel = false, const WzFrameDesc* by_value = nullptr);
+const void* wz_preprocess_func(bool hp);   // the kernel's host-side address (to find its node in a captured graph)
 void wz_launch_stem(const half_t* in, const float* w, const float* bias, half_t* out, int n, int hin, int win,
                     int hout, int wout, int pad_t, int pad_l, hipStream_t s);
 void wz_launch_dw(const half_t* in, const half_t* w, const float* bias, half_t* out, int n, int hin, int win,

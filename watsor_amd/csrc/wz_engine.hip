@@ -80,6 +80,7 @@ struct wz_engine {
     int wide_min_m = 1;        // WZ_WIDE_MIN_M=n: heads with fewer output pixels than this (per batch) stay on wz_k_conv_group
     int wide_T = 0;            // WZ_WIDE_T=n: K steps per slice of that kernel (0: chosen per launch by wz_choose_wide_T)
     bool tail_fuse = false;       // WZ_TAIL_FUSE=1: the convolutions on the <= 32-pixel maps in one launch (k_tail.hip); measured slower, off
+    bool desc_by_value = true;    // the frame descriptors travel as arguments of the resize kernel (WZ_DESC_ARGS=0: zero-copy / copied)
     bool desc_zero_copy = true;   // the resize kernel reads the frame descriptors from page-locked host memory (WZ_DESC_COPY=1: copied first)
     int num_cus = 256;         // compute units of the device (the wide head kernel sizes its K slices for one round over them)
     bool head_inline = false;  // WZ_HEAD_INLINE=1: ... or inside the head convolutions themselves, by each tile's last K slice.
@@ -136,6 +137,15 @@ struct wz_engine {
         hipEvent_t done = nullptr;
         int n = 0;
         std::map<int, hipGraphExec_t> graphs;    // key = batch size
+        std::map<int, hipGraph_t> graph_src;     // the captured graph itself, kept where one of its node handles is
+        std::map<int, hipGraphNode_t> pre_nodes; // ... and the resize kernel's node in that graph (its arguments carry the frame
+                                                 // descriptors and are rewritten before every replay), if it takes them by value
+        WzDescPack pack;                         // storage behind that node's kernelParams
+        const WzFrameDesc* pre_frames = nullptr;
+        int pre_size = 0, pre_half_pixel = 0;
+        half_t* pre_out = nullptr;
+        WzFrameDesc* pre_keep = nullptr;
+        void* pre_kp[6];
     };
     Lane lanes[WZ_SLOTS];
     int n_lanes = 4;   // default; WZ_LANES overrides (1..WZ_SLOTS)
@@ -547,12 +557,16 @@ static void enqueue_batch(wz_engine* e, Lane& L, int n, StageTimer* t, int inner
     if (t) t->mark();   // "(empty)": two event records with nothing between them = the bracket's own cost
     // the descriptors: read by the resize kernel straight out of the lane's page-locked host block (and left in d_desc for the
     // kernels behind it), or -- WZ_DESC_COPY=1, and where the host block has no device address -- copied in front of it
-    const bool zero_copy = e->desc_zero_copy && L.h_desc_dev;
-    if (!zero_copy) (void)hipMemcpyAsync(L.d_desc, L.h_desc, sizeof(WzFrameDesc) * n, hipMemcpyHostToDevice, s);
+    // (by value: the descriptors are the resize kernel's arguments -- no copy, no PCIe read; batches of more than WZ_DESC_PACK frames
+    // and WZ_DESC_ARGS=0 take one of the older routes)
+    const bool by_value = e->desc_by_value && n <= WZ_DESC_PACK;
+    const bool zero_copy = !by_value && e->desc_zero_copy && L.h_desc_dev;
+    if (!by_value && !zero_copy) (void)hipMemcpyAsync(L.d_desc, L.h_desc, sizeof(WzFrameDesc) * n, hipMemcpyHostToDevice, s);
     if (t) t->mark();
     wz_launch_repeat = inner;
     wz_launch_preprocess(zero_copy ? L.h_desc_dev : L.d_desc, n, (int)e->hdr.input_size, L.tptr[input_tensor_index(e)], s,
-                         input_is_pair(e), zero_copy ? L.d_desc : nullptr, e->hdr.resize_mode == 1);
+                         input_is_pair(e), (zero_copy || by_value) ? L.d_desc : nullptr, e->hdr.resize_mode == 1,
+                         by_value ? L.h_desc : nullptr);
     if (t) t->mark();
     enqueue_network(e, L, n, t);
     wz_launch_repeat = 1;
@@ -579,10 +593,48 @@ static int run_batch(wz_engine* e, int slot, int n) {
             }
             size_t nodes = 0;
             if (hipGraphGetNodes(g, nullptr, &nodes) == hipSuccess) L.graph_nodes[n] = (int)nodes;
+            if (e->desc_by_value && n <= WZ_DESC_PACK && nodes > 0) {   // the resize kernel's node: its arguments are this batch's descriptors
+                std::vector<hipGraphNode_t> all(nodes);
+                const void* want = wz_preprocess_func(input_is_pair(e));
+                if (hipGraphGetNodes(g, all.data(), &nodes) == hipSuccess)
+                    for (size_t k = 0; k < nodes; ++k) {
+                        hipGraphNodeType ty;
+                        hipKernelNodeParams kp;
+                        if (hipGraphNodeGetType(all[k], &ty) == hipSuccess && ty == hipGraphNodeTypeKernel &&
+                            hipGraphKernelNodeGetParams(all[k], &kp) == hipSuccess && kp.func == want) {
+                            L.pre_nodes[n] = all[k];
+                            break;
+                        }
+                    }
+                if (!L.pre_nodes.count(n)) {
+                    (void)hipGraphDestroy(g);
+                    return wz_fail(WZ_EHIP, "the resize kernel's node was not found in the captured graph");
+                }
+            }
             hipGraphExec_t ge = nullptr;
             HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-            (void)hipGraphDestroy(g);
+            if (L.pre_nodes.count(n)) L.graph_src[n] = g;   // (the node handle lives as long as the graph it belongs to)
+            else (void)hipGraphDestroy(g);
             it = L.graphs.emplace(n, ge).first;
+        }
+        auto pn = L.pre_nodes.find(n);
+        if (pn != L.pre_nodes.end()) {   // this batch's descriptors into the node's arguments
+            memset(&L.pack, 0, sizeof(L.pack));
+            memcpy(L.pack.d, L.h_desc, sizeof(WzFrameDesc) * n);
+            L.pre_frames = nullptr;
+            L.pre_size = (int)e->hdr.input_size;
+            L.pre_out = L.tptr[input_tensor_index(e)];
+            L.pre_keep = L.d_desc;
+            L.pre_half_pixel = e->hdr.resize_mode == 1 ? 1 : 0;
+            L.pre_kp[0] = &L.pre_frames; L.pre_kp[1] = &L.pack; L.pre_kp[2] = &L.pre_size;
+            L.pre_kp[3] = &L.pre_out; L.pre_kp[4] = &L.pre_keep; L.pre_kp[5] = &L.pre_half_pixel;
+            hipKernelNodeParams kp;
+            memset(&kp, 0, sizeof(kp));
+            kp.func = const_cast<void*>(wz_preprocess_func(input_is_pair(e)));
+            kp.gridDim = dim3(((unsigned)L.pre_size * L.pre_size + 255) / 256, n);
+            kp.blockDim = dim3(256);
+            kp.kernelParams = L.pre_kp;
+            HIPCHK(hipGraphExecKernelNodeSetParams(it->second, pn->second, &kp));
         }
         HIPCHK(hipGraphLaunch(it->second, L.stream));
     } else {
@@ -730,6 +782,7 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     e->head_inline = (env = wz_dev_getenv("WZ_HEAD_INLINE")) && atoi(env) != 0;
     e->conv_wide = !((env = wz_dev_getenv("WZ_CONV_WIDE")) && atoi(env) == 0);
     e->desc_zero_copy = !((env = wz_dev_getenv("WZ_DESC_COPY")) && atoi(env) != 0);
+    e->desc_by_value = !((env = wz_dev_getenv("WZ_DESC_ARGS")) && atoi(env) == 0);
     e->tail_fuse = (env = wz_dev_getenv("WZ_TAIL_FUSE")) && atoi(env) != 0;
     e->wide_T = (env = wz_dev_getenv("WZ_WIDE_T")) ? atoi(env) : 0;
     e->wide_min_m = (env = wz_dev_getenv("WZ_WIDE_MIN_M")) ? atoi(env) : 1;
@@ -958,6 +1011,7 @@ extern "C" void wz_destroy(wz_engine_t* e) {
     for (int li = 0; li < WZ_SLOTS; ++li) {
         Lane& L = e->lanes[li];
         for (auto& kv : L.graphs) (void)hipGraphExecDestroy(kv.second);
+        for (auto& kv : L.graph_src) (void)hipGraphDestroy(kv.second);
         for (void* p : L.bufs) (void)hipFree(p);
         void* lp[] = {L.d_frames, L.d_box_enc, L.d_logits, L.d_ws, L.d_tickets, L.d_fin, L.post.boxes, L.post.valid, L.d_post_scratch, L.post.cand,
                       L.post.det_boxes, L.post.det_scores, L.post.det_classes, L.post.det_num, L.post.dbg, L.d_desc, L.d_rows,
