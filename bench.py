@@ -919,6 +919,12 @@ def main():
         if not args.no_parity:
             parity = parity_leg(eng, host_frames, d_frames, weights)
             note("parity: max |dscore| %.6f over %d rows" % (parity["max_dscore"], parity["rows_compared"]))
+        eng.submit_device(0, d_frames[:BATCH], ws, hs)
+        eng.wait(0)
+        graph_nodes = eng.graph_nodes(0)   # as captured: kernel launches (+ a descriptor copy where the resize kernel does not take them as arguments)
+        input_size, hp_blocks = eng.input_size, eng.hp_blocks
+        if world == 1:
+            eng.close()                    # (one engine's streams at a time: eight live streams leave later engines sharing hardware queues)
         # per-kernel durations: HIP events around every launch (wz_profile_stages) -- an entry point of the DEVELOPMENT library
         # (the same sources built with -DWZ_DEV_BUILD; the headline above was timed on libwatsor_hip.so, which has no such hooks)
         prof = HipEngine(engine_path, local_rank, BATCH, WIDTH, HEIGHT, dev=True)
@@ -928,15 +934,12 @@ def main():
         single = prof.profile_device(pd, ws, hs, reps=10, inner=1)
         prof.close()
         note("stage profiles done")
-        table, overhead = aggregate_stages(stages, ops, BATCH, WIDTH * HEIGHT * 3, eng.input_size, eng.hp_blocks, PROFILE_INNER)
-        single_table, _ = aggregate_stages(single, ops, BATCH, WIDTH * HEIGHT * 3, eng.input_size, eng.hp_blocks, 1)
+        table, overhead = aggregate_stages(stages, ops, BATCH, WIDTH * HEIGHT * 3, input_size, hp_blocks, PROFILE_INNER)
+        single_table, _ = aggregate_stages(single, ops, BATCH, WIDTH * HEIGHT * 3, input_size, hp_blocks, 1)
         roof = roofline_object(table, overhead, single_table, PROFILE_INNER)
         if args.table:
             json.dump(dict(stages=stages, stages_single_bracket=single, inner=PROFILE_INNER, kernels=table,
                            kernels_single_bracket=single_table), open(args.table, "w"), indent=1)
-        eng.submit_device(0, d_frames[:BATCH], ws, hs)
-        eng.wait(0)
-        graph_nodes = eng.graph_nodes(0)   # as captured: kernel launches + the descriptor copy
         out = {
             "metric": "detected frames/sec (whole node) + p50 per-frame latency, SSD-MobileNet 300x300",
             "value": round(frames_per_round / elapsed, 2), "unit": "frames/s",
@@ -949,15 +952,13 @@ def main():
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": "1 synthetic 640x480 RGB stream per GPU, batch=8 frames, SSD-MobileNet-v2 300x300 "
                                    "(seeded random-init weights), frames resident in HBM, rows copied back to host",
-                       "engine": "-p 16 (fp16 MFMA; stem + blocks 0..%d with split hi+lo operands, the rest plain fp16)" % (eng.hp_blocks - 1)
-                                 if eng.hp_blocks else "-p 16 --plain-fp16",
+                       "engine": "-p 16 (fp16 MFMA; stem + blocks 0..%d with split hi+lo operands, the rest plain fp16)" % (hp_blocks - 1)
+                                 if hp_blocks else "-p 16 --plain-fp16",
                        "batch": BATCH, "frame": "%dx%d" % (WIDTH, HEIGHT), "parallelism": "replica-per-gpu x%d" % world, "batches_in_flight": lanes,
                        "graph_nodes_per_batch": graph_nodes, "detections_per_frame": detections_per_frame},
             "parity": parity,
             "roofline": roof,
         }
-        if world == 1:
-            eng.close()
         if world == 1 and not args.no_live_pmc:
             live = live_pmc_traffic()
             note("live counter passes %s" % ("done" if live else "unavailable (committed json kept)"))

@@ -730,13 +730,18 @@ def test_inline_head_reduction_under_load(eng, model_dir):
     """The in-launch reduction of the SSD heads is a cross-workgroup hand-off (write-through slabs, ticket, acquire): run it
     the way it fails when it is wrong -- four lanes in flight, two alternating scenes so that every slab and every cached
     line holds last step's values of the OTHER scene, hundreds of steps, every row of every frame compared with the rows of
-    an engine that reduces in a launch of its own."""
-    os.environ["WZ_HEAD_INLINE"] = "1"
+    an engine that reduces in a launch of its own (the tile kernel's K slices: the wide kernel's are cut for half the chip when
+    several lanes are in flight, another summation order)."""
+    os.environ.update(WZ_HEAD_INLINE="1")
     try:
         inl = make_engine(model_dir)
-    finally:
         os.environ.pop("WZ_HEAD_INLINE")
-    ref_eng, eng = eng, inl                 # `eng` (the default: a reduce launch of its own) supplies the reference rows
+        os.environ.update(WZ_CONV_WIDE="0")
+        ref_eng = make_engine(model_dir)
+    finally:
+        os.environ.pop("WZ_HEAD_INLINE", None)
+        os.environ.pop("WZ_CONV_WIDE", None)
+    eng = inl
     scenes = [[synthetic_frame(640, 480, 5000 + 100 * s + i) for i in range(8)] for s in range(2)]
     try:
         refs = []
@@ -747,6 +752,8 @@ def test_inline_head_reduction_under_load(eng, model_dir):
     except Exception:
         inl.close()
         raise
+    finally:
+        ref_eng.close()
     assert refs[0].tobytes() != refs[1].tobytes()
     dev = [[eng.upload(f) for f in sc] for sc in scenes]
     ws, hs = [640] * 8, [480] * 8

@@ -269,13 +269,19 @@ static int wz_cs_launch(WzMbArgs a, int n, hipStream_t s, bool prepare) {
 // Serves the blocks with 19x19 outputs (blocks 6 .. 12); the 10x10 ones on request (WZ_MB_CS_MIN_W).  -2: does not apply (caller falls back to wz_launch_mbconv).
 int wz_launch_mbconv_cs(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) {
     static const int enabled = wz_cs_env("WZ_MB_CS", 1);
-    // Measured on the 10x10 maps (9 tiles per frame, 30 chunks): this kernel takes longer there than channel groups
-    // over workgroups + a reduce launch (block 16: 30 vs 17 us) but occupies only 72 CUs, and with four lanes in
-    // flight what counts is CU x time: 43.2 k vs 42.6 k frames/s -- at a worse latency (p50 0.508 vs 0.496 ms) and a
-    // worse per-kernel roofline fraction.  Default: 19x19 only; WZ_MB_CS_MIN_W=1 trades latency for 1 % of throughput.
-    static const int min_w = wz_cs_env("WZ_MB_CS_MIN_W", 11);
+    // On the 10x10 maps (blocks 13 .. 16: 9 tiles per frame, 18 - 30 chunks) this kernel takes longer alone than channel groups
+    // over 256 workgroups + a reduce launch (block 16: 31 us against 10 + 4) -- every workgroup streams all of the block's
+    // 0.6 - 0.9 MB of weights -- but it occupies 72 CUs instead of all of them, writes no fp32 partial sums (80 MB per batch
+    // out and back) and needs no reduce launches (31 graph nodes instead of 35): 49.1 k -> 50.1 k frames/s with four lanes in flight,
+    // p50 0.380 -> 0.394 ms (profiles/r03_wave_counts_*; round 1 measured the same trade at +1 %, round 2 at +0.6 %).  Default since
+    // round 3; WZ_MB_CS_MIN_W=11 brings the channel-group kernel back for the 10x10 maps.
+    static const int min_w = wz_cs_env("WZ_MB_CS_MIN_W", 1);
     if (enabled != 1 || a0.stem || a0.wout > 19 || a0.wout < min_w) return -2;
     const int nto = a0.n_pad / 16;
+    // ... except block 16 (320 output channels, 0.9 MB of weights per workgroup: 31 us alone against 9 + 4): it stays on the channel-group
+    // kernel -- 50.0 k frames/s either way, p50 0.380 instead of 0.395 ms (WZ_MB_CS_MAX_NTO=20: on this kernel as well)
+    static const int max_nto = wz_cs_env("WZ_MB_CS_MAX_NTO", 10);   // blocks with more output tiles than this stay on the channel-group kernel
+    if (!prepare && nto > max_nto) return -2;
     WzMbArgs a = a0;
     a.nsplit = 1;
     a.th = 4; a.tw = 4;

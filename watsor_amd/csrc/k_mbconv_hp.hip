@@ -239,7 +239,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
     if (ps0 < nk32) load_wa(ps0);
     {   // biases (and, LDSW, depthwise weights) into LDS: every load of a thread in flight before its first store
         constexpr int NT = NW * 64;
-        constexpr int WD_IT = 3;   // 9 * cmid_pad / 4 float4s over NT threads: at most 3 each (checked by the launcher)
+        constexpr int WD_IT = NW >= 8 ? 3 : 8;   // 9 * cmid_pad / 4 float4s over NT threads: at most this many each (checked by the launcher)
         const int nb4 = a.cmid_pad >> 2;
         float4_t sw[WD_IT], sb, se;
         if constexpr (LDSW) {
@@ -587,7 +587,7 @@ static int wz_hp_launch(WzMbArgs a, int n, hipStream_t s, bool prepare) {
     constexpr int RED = CS ? NW * MQW * NTO * 1024 : 0;
     const size_t region = (size_t)(NW * EB > RED ? NW * EB : RED);
     const size_t lds = region + (size_t)a.cmid_pad * ((CS || OCC > 2) ? 8 + 36 : 8) + (SH ? (size_t)MPW * KCI * 2 * 1024 : 0);
-    if ((a.cmid_pad >> 2) > NW * 64 || 9 * (a.cmid_pad >> 2) > 3 * NW * 64) return -1;   // the staging code's fixed trip counts
+    if ((a.cmid_pad >> 2) > NW * 64 || 9 * (a.cmid_pad >> 2) > (NW >= 8 ? 3 : 8) * NW * 64) return -1;   // the staging code's fixed trip counts
     auto k = wz_k_mbconv_hp<NW, CS, STEM, MPW, MQW, KCI, NTO, OCC, ONEPASS, SH>;
     if (prepare) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -646,10 +646,18 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
         // round (comment above wz_launch_mbconv_hp).
         const int tiles_s1 = ((a.hout + 3) / 4) * ((a.wout + (a.stride == 1 ? 7 : 3)) / (a.stride == 1 ? 8 : 4));
         const bool few = (tiles_s1 * n + 3) / 4 <= cs_few_wgs;
-        static const int cs_s1_max_w = wz_hp_env("WZ_HP_CS_S1_MAX_W", 19);   // the same threshold for the stride-1 blocks alone
+        // Stride-1 blocks on the 38x38 maps: THREE waves per tile, two chunks each, halo shared through LDS.  One wave per tile walks
+        // six chunks in a row on a chip that 400 such waves leave almost empty (11.3 us per block); six waves with one chunk each
+        // are fastest alone but every workgroup then fills most of a CU (8.0 - 9.0 us, 45.9 k frames/s against 47.3 k); three waves
+        // take 6.7 - 7.0 us and two workgroups share a CU: 47.7 k frames/s, p50 0.378 -> 0.369 ms (profiles/r03_wave_counts_*).
+        static const int cs_s1_max_w = wz_hp_env("WZ_HP_CS_S1_MAX_W", 38);   // the same threshold for the stride-1 blocks alone
         const bool cs = (prepare || a.wout <= cs_max_w || (a.stride == 1 && a.wout <= cs_s1_max_w) || few) && nk32 >= 4 && nk32 <= 6;
         if (a.stride == 1) {        // 4 x 8 tiles, halo 6 x 10 = 60 pixels
+            static const int cs_nw = wz_hp_env("WZ_HP_CS_NW", 3);   // 2 / 3 / 4: that many waves per tile, several chunks each (shared halo); 0: one chunk per wave
             if (prepare) {
+                (void)wz_hp_launch<2, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, true);
+                (void)wz_hp_launch<3, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, true);
+                (void)wz_hp_launch<4, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, true);
                 (void)wz_hp_launch<5, true, false, 4, 2, 1, 2>(a, n, s, true);
                 (void)wz_hp_launch<6, true, false, 4, 2, 1, 2>(a, n, s, true);
                 (void)wz_hp_launch<5, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, true);
@@ -658,6 +666,9 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
                 (void)wz_hp_launch<4, false, false, 4, 2, 1, 2, 4>(a, n, s, true);
                 return wz_hp_launch<4, false, false, 4, 2, 1, 2>(a, n, s, true);
             }
+            if (cs && sh && cs_nw == 2) return wz_hp_launch<2, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, false);
+            if (cs && sh && cs_nw == 3) return wz_hp_launch<3, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, false);
+            if (cs && sh && cs_nw == 4) return wz_hp_launch<4, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, false);
             if (cs && sh && nk32 <= 5) return wz_hp_launch<5, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, false);
             if (cs && sh) return wz_hp_launch<6, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, false);
             if (cs && nk32 <= 5) return wz_hp_launch<5, true, false, 4, 2, 1, 2>(a, n, s, false);
@@ -667,13 +678,18 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
             return wz_hp_launch<4, false, false, 4, 2, 1, 2>(a, n, s, false);
         }
         // stride 2: 4 x 4 tiles, halo 9 x 9 = 81 pixels
+        static const int cs2_nw = wz_hp_env("WZ_HP_CS2_NW", 0);   // stride-2 blocks on maps up to WZ_HP_CS2_MAX_W: that many waves per tile
+        static const int cs2_max_w = wz_hp_env("WZ_HP_CS2_MAX_W", 0);
         if (prepare) {
+            (void)wz_hp_launch<3, true, false, 6, 1, 1, 2, 2, false, true>(a, n, s, true);
             (void)wz_hp_launch<5, true, false, 6, 1, 1, 2>(a, n, s, true);
             (void)wz_hp_launch<5, true, false, 6, 1, 1, 2, 2, false, true>(a, n, s, true);
             (void)wz_hp_launch<4, false, false, 6, 1, 1, 2, 3>(a, n, s, true);
             (void)wz_hp_launch<4, false, false, 6, 1, 1, 2, 4>(a, n, s, true);
             return wz_hp_launch<4, false, false, 6, 1, 1, 2>(a, n, s, true);
         }
+        if (sh && cs2_nw == 3 && a.wout <= cs2_max_w && nk32 >= 4 && nk32 <= 6)
+            return wz_hp_launch<3, true, false, 6, 1, 1, 2, 2, false, true>(a, n, s, false);
         if (cs && sh && nk32 <= 5) return wz_hp_launch<5, true, false, 6, 1, 1, 2, 2, false, true>(a, n, s, false);
         if (cs && nk32 <= 5) return wz_hp_launch<5, true, false, 6, 1, 1, 2>(a, n, s, false);
         if (occ == 3) return wz_hp_launch<4, false, false, 6, 1, 1, 2, 3>(a, n, s, false);
@@ -683,7 +699,15 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
     if (a.wout > 19) return -1;
     if (a.stride == 2) {
         if (a.kc0 == 1 && nto == 4) {
-            if (prepare) (void)wz_hp_launch<HP_CS_WAVES, true, false, 6, 1, 1, 4, 2, false, true>(a, n, s, true);
+            static const int cs6_nw = wz_hp_env("WZ_HP_CS6_NW", 3);   // waves per tile of the 38x38 -> 19x19 block (6 chunks): 3 with two chunks
+                                                                      // each (49.8 k -> 50.5 k frames/s; 8: two waves idle, a CU per workgroup)
+            if (prepare) {
+                (void)wz_hp_launch<HP_CS_WAVES, true, false, 6, 1, 1, 4, 2, false, true>(a, n, s, true);
+                (void)wz_hp_launch<3, true, false, 6, 1, 1, 4, 2, false, true>(a, n, s, true);
+                (void)wz_hp_launch<6, true, false, 6, 1, 1, 4, 2, false, true>(a, n, s, true);
+            }
+            if (sh && !prepare && cs6_nw == 3) return wz_hp_launch<3, true, false, 6, 1, 1, 4, 2, false, true>(a, n, s, false);
+            if (sh && !prepare && cs6_nw == 6) return wz_hp_launch<6, true, false, 6, 1, 1, 4, 2, false, true>(a, n, s, false);
             if (sh && !prepare) return wz_hp_launch<HP_CS_WAVES, true, false, 6, 1, 1, 4, 2, false, true>(a, n, s, false);
             return wz_hp_launch<HP_CS_WAVES, true, false, 6, 1, 1, 4>(a, n, s, prepare);
         }
@@ -702,13 +726,27 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
                             : wz_hp_launch<12, true, false, 3, 1, 2, 6, 3, true>(a, n, s, false);
         }
     }
+    // 19x19 blocks: FOUR waves per tile (3 - 5 chunks each) instead of eight.  Alone a block gets slower (5.2 -> 6.5 us, 9.3 -> 11.5 us:
+    // the chunk walk is longer) -- but a workgroup of four 256-register waves takes half a CU's register file, so two of them (of
+    // this lane's launch or of another lane's) share a CU, where eight waves own it: 47.5 k -> 49.1 k frames/s with four lanes in
+    // flight.  3 waves: 48.2 k; 5: 45.8 k; 6: 46.8 k (workgroups that neither fill a CU nor leave room for a second one);
+    // WZ_HP_CS19_NW=8 is the lowest-latency setting (p50 0.372 against 0.380 ms).  profiles/r03_wave_counts_*.
+    static const int cs19_nw = wz_hp_env("WZ_HP_CS19_NW", 4);
 #define HP_CASE(K, N)                                                                                         \
     if (a.kc0 == K && nto == N) {                                                                             \
         if (prepare) {                                                                                        \
+            (void)wz_hp_launch<3, true, false, 3, 1, K, N, 2, false, true>(a, n, s, true);                   \
+            (void)wz_hp_launch<4, true, false, 3, 1, K, N, 2, false, true>(a, n, s, true);                   \
+            (void)wz_hp_launch<5, true, false, 3, 1, K, N, 2, false, true>(a, n, s, true);                   \
+            (void)wz_hp_launch<6, true, false, 3, 1, K, N, 2, false, true>(a, n, s, true);                   \
             (void)wz_hp_launch<HP_CS_WAVES, true, false, 3, 1, K, N, 2, false, true>(a, n, s, true);         \
             if (K == 2) (void)wz_hp_launch<12, true, false, 3, 1, 2, N, 3, false, true>(a, n, s, true);      \
             return wz_hp_launch<HP_CS_WAVES, true, false, 3, 1, K, N>(a, n, s, true);                        \
         }                                                                                                     \
+        if (sh && cs19_nw == 3) { const int r = wz_hp_launch<3, true, false, 3, 1, K, N, 2, false, true>(a, n, s, false); if (r >= 0) return r; } \
+        if (sh && cs19_nw == 5) { const int r = wz_hp_launch<5, true, false, 3, 1, K, N, 2, false, true>(a, n, s, false); if (r >= 0) return r; } \
+        if (sh && cs19_nw == 4) { const int r = wz_hp_launch<4, true, false, 3, 1, K, N, 2, false, true>(a, n, s, false); if (r >= 0) return r; } \
+        if (sh && cs19_nw == 6) { const int r = wz_hp_launch<6, true, false, 3, 1, K, N, 2, false, true>(a, n, s, false); if (r >= 0) return r; } \
         if (sh && w12 && K == 2) return wz_hp_launch<12, true, false, 3, 1, 2, N, 3, false, true>(a, n, s, false); \
         if (sh) return wz_hp_launch<HP_CS_WAVES, true, false, 3, 1, K, N, 2, false, true>(a, n, s, false);    \
         return wz_hp_launch<HP_CS_WAVES, true, false, 3, 1, K, N>(a, n, s, false);                            \

@@ -82,6 +82,7 @@ struct wz_engine {
     bool tail_fuse = false;       // WZ_TAIL_FUSE=1: the convolutions on the <= 32-pixel maps in one launch (k_tail.hip); measured slower, off
     bool desc_by_value = true;    // the frame descriptors travel as arguments of the resize kernel (WZ_DESC_ARGS=0: zero-copy / copied)
     bool desc_zero_copy = true;   // the resize kernel reads the frame descriptors from page-locked host memory (WZ_DESC_COPY=1: copied first)
+    int wide_cus = 128;        // CUs the wide head kernel's K slices are sized for when several lanes are in flight (WZ_WIDE_CUS)
     int num_cus = 256;         // compute units of the device (the wide head kernel sizes its K slices for one round over them)
     bool head_inline = false;  // WZ_HEAD_INLINE=1: ... or inside the head convolutions themselves, by each tile's last K slice.
                                // Bit-identical and one launch less, but measured SLOWER (profiles/r02l_*: heads 76 + 18 us against
@@ -264,7 +265,9 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
             tile_bytes[cnt] = 128ll * 4 * (((a.cout + 15) & ~15) / (((a.cout + 15) / 16 + 19) / 20));
             ++cnt;
         }
-        if (cnt > 0) wide_T = e->wide_T > 0 ? e->wide_T : wz_choose_wide_T(tiles, steps, tile_bytes, cnt, e->num_cus);
+        // (K slices sized for HALF the chip when other lanes are there to use the rest: at batch 8 T = 27 -> 41 steps per slice, 179 -> ~120
+        // workgroups of this one-wave-per-SIMD kernel, a third fewer fp32 partial tiles: 49.8 k -> 50.5 k frames/s, p50 +8 us)
+        if (cnt > 0) wide_T = e->wide_T > 0 ? e->wide_T : wz_choose_wide_T(tiles, steps, tile_bytes, cnt, e->n_lanes > 1 ? e->wide_cus : e->num_cus);
     }
     int big_head[WZ_CONV_GROUP_MAX] = {0}, small_head[WZ_CONV_GROUP_MAX] = {0};   // ... and which entry
     for (uint32_t i = 0; i < e->hdr.n_ops; ++i) {
@@ -790,6 +793,8 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
             e->num_cus = cus;
+        e->wide_cus = e->num_cus / 2;
+        if ((env = wz_dev_getenv("WZ_WIDE_CUS")) && atoi(env) > 0) e->wide_cus = atoi(env);
     }
     if ((env = getenv("WZ_LANES")) && atoi(env) >= 1 && atoi(env) <= WZ_SLOTS) e->n_lanes = atoi(env);
     if ((env = getenv("WZ_STREAMS")) && atoi(env) >= 1 && atoi(env) <= WZ_SLOTS) e->n_streams = atoi(env);
