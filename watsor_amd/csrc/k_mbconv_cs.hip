@@ -16,9 +16,9 @@
 // with them to fp32 rounding of the sum, i.e. an fp16 ulp here and there (same as k_mbconv.hip's channel groups).
 #include "wz_common.h"
 
-#define CS_WAVES 8
 
-template <bool EXPAND, int MPW, int MQW, int KCI, int NTO>
+// CS_WAVES: waves per workgroup / tile (8; 4: half a CU per workgroup, a longer chunk walk)
+template <bool EXPAND, int MPW, int MQW, int KCI, int NTO, int CS_WAVES = 8>
 __global__ __launch_bounds__(CS_WAVES * 64) void wz_k_mbconv_cs(const WzMbArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wz_cs_smem[];
     constexpr int CE = 32, ES = CE + 8;
@@ -250,14 +250,14 @@ static int wz_cs_env(const char* name, int dflt) {
     return (e && atoi(e) > 0) ? atoi(e) : dflt;
 }
 
-template <bool EXPAND, int MPW, int MQW, int KCI, int NTO>
+template <bool EXPAND, int MPW, int MQW, int KCI, int NTO, int CS_WAVES = 8>
 static int wz_cs_launch(WzMbArgs a, int n, hipStream_t s, bool prepare) {
     constexpr int EB = EXPAND ? MPW * 16 * 40 * 2 : 0;
     constexpr int NTC = NTO > 10 ? 10 : NTO;
     constexpr int RED = CS_WAVES * MQW * NTC * 1024;
     const size_t region = (size_t)(CS_WAVES * EB > RED ? CS_WAVES * EB : RED);
     const size_t lds = region + (size_t)a.cmid_pad * (9 * 2 + 2 * 4);
-    auto k = wz_k_mbconv_cs<EXPAND, MPW, MQW, KCI, NTO>;
+    auto k = wz_k_mbconv_cs<EXPAND, MPW, MQW, KCI, NTO, CS_WAVES>;
     if (prepare) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return lds <= 160 * 1024 ? 0 : -1;
@@ -287,8 +287,13 @@ int wz_launch_mbconv_cs(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
     a.th = 4; a.tw = 4;
     a.tiles_y = (a.hout + a.th - 1) / a.th;
     a.tiles_x = (a.wout + a.tw - 1) / a.tw;
+    static const int nw10 = wz_cs_env("WZ_MB_CS_NW", 8);   // waves per tile on the 10x10 maps (4 or 8)
     if (a.cin0 == 0) {   // no expand stage (block 13)
-        if (nto == 10) return wz_cs_launch<false, 1, 1, 1, 10>(a, n, s, prepare);
+        if (nto == 10) {
+            if (prepare) (void)wz_cs_launch<false, 1, 1, 1, 10, 4>(a, n, s, true);
+            if (!prepare && nw10 == 4) return wz_cs_launch<false, 1, 1, 1, 10, 4>(a, n, s, false);
+            return wz_cs_launch<false, 1, 1, 1, 10>(a, n, s, prepare);
+        }
         return -2;
     }
     if (a.stride == 2) {   // halo 9 x 9 = 81 pixels -> 6 m-tiles
@@ -300,6 +305,10 @@ int wz_launch_mbconv_cs(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
     CS_CASE(2, 4);
     CS_CASE(2, 6);
     CS_CASE(3, 6);
+    if (a.kc0 == 5 && nto == 10) {
+        if (prepare) (void)wz_cs_launch<true, 3, 1, 5, 10, 4>(a, n, s, true);
+        if (!prepare && nw10 == 4) return wz_cs_launch<true, 3, 1, 5, 10, 4>(a, n, s, false);
+    }
     CS_CASE(5, 10);
     CS_CASE(5, 20);
 #undef CS_CASE
