@@ -283,6 +283,43 @@ def live_pmc_traffic(timeout_s=60):
     return out or None
 
 
+def schedule_child():
+    """The headline workload under whatever WZ_SCHEDULE the parent put into the environment (the library reads it once per process):
+    one JSON line {value, p50_ms}."""
+    from watsor_amd import engine as builder
+    from watsor_amd.runtime import HipEngine
+    from watsor_amd.synth import synthetic_frame, synthetic_weights
+    d = "/tmp/wz_sched_child_%d" % os.getpid()
+    os.makedirs(d, exist_ok=True)
+    path = os.path.join(d, "mi355x.bin")
+    builder.save_engine(builder.build_engine(synthetic_weights(1234)), path)
+    eng = HipEngine(path, int(os.environ.get("LOCAL_RANK", "0")), BATCH, WIDTH, HEIGHT)
+    try:
+        dfr = [eng.upload(synthetic_frame(WIDTH, HEIGHT, 1234 + i)) for i in range(RING * BATCH)]
+        r = throughput(eng, lambda lane, s: eng.submit_device(lane, dfr[(s % RING) * BATCH:(s % RING + 1) * BATCH], [WIDTH] * BATCH, [HEIGHT] * BATCH),
+                       BATCH, steps=400, warm=40)
+        r["graph_nodes_per_batch"] = eng.graph_nodes(0)
+        print(json.dumps(r), flush=True)
+    finally:
+        eng.close()
+        os.remove(path)
+        os.rmdir(d)
+    return 0
+
+
+def latency_schedule_leg():
+    """WZ_SCHEDULE=latency: the launch shapes that finish a lone batch soonest (include/watsor_hip.h), measured in a child process on
+    the headline workload -- what the default (throughput) schedule trades away."""
+    env = dict(os.environ, WZ_SCHEDULE="latency", WZ_BENCH_VERBOSE="0")
+    p = subprocess.run([sys.executable, os.path.abspath(__file__), "--schedule-child"], env=env, capture_output=True, text=True, timeout=180)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    if p.returncode != 0 or not lines:
+        return dict(error=(p.stderr or p.stdout)[-300:])
+    r = json.loads(lines[-1])
+    r["workload"] = "the headline workload with WZ_SCHEDULE=latency in the environment (child process)"
+    return r
+
+
 def pmc_child():
     """The workload the two counter passes of `live_pmc_traffic` profile: 12 batches on one lane, nothing else."""
     from watsor_amd import engine as builder
@@ -789,6 +826,7 @@ def main():
     ap.add_argument("--table", default=None, help="write the per-kernel roofline table (JSON) here")
     ap.add_argument("--no-live-pmc", action="store_true", help="take roofline.traffic from the committed profiles/pmc_traffic.json instead of two rocprofv3 --pmc passes of this run")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--schedule-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--dry-run", action="store_true",
                     help="harness self-test without a GPU: a stub engine that sleeps 2 ms per step (used by the "
                          "world_size-2 tests; its output is marked invalid)")
@@ -796,6 +834,8 @@ def main():
 
     if args.pmc_child:
         return pmc_child()
+    if args.schedule_child:
+        return schedule_child()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
@@ -977,6 +1017,8 @@ def main():
             note("host-memory config legs done")
             legs["busy_scene_b8"] = busy_scene_leg(host_frames, rank)
             note("busy-scene leg done")
+            legs["latency_schedule_b8"] = latency_schedule_leg()
+            note("latency-schedule leg done")
             legs.update(worker_legs(model_dir))
             note("worker legs done")
             out["legs"] = legs

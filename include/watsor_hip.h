@@ -16,6 +16,10 @@
  * instance, detector.py:84-112) -- the lanes overlap on the GPU, not on the host.  Host frames are packed RGB24, HWC,
  * C-contiguous (`Frame.get_numpy_image`, watsor/stream/share.py:68-73); they are read only and
  * not retained past the call.
+ *
+ * Environment (read when the first engine of a process is created): WZ_LANES=1..8 (batches in flight, default 4), WZ_STREAMS (HIP
+ * streams they ride, default = lanes, at most 4 pay), WZ_GRAPH=0 (launch kernel by kernel instead of replaying a captured graph),
+ * WZ_SCHEDULE=latency (launch shapes for the shortest lone batch instead of the most frames per second with every lane busy).
  */
 #ifndef WATSOR_HIP_H
 #define WATSOR_HIP_H
@@ -193,7 +197,7 @@ int wz_dev_download(wz_engine_t* e, void* h_dst, const void* d_src, uint64_t byt
  * Development library only (`make dev` -> libwatsor_hip_dev.so, compiled with -DWZ_DEV_BUILD): stage-level entry points of the
  * parity tests, per-kernel profiling for bench.py's roofline, diagnostics, and -- inside the library -- the WZ_* tuning knobs and
  * the kernel variants that lost their A/B.  libwatsor_hip.so exports nothing below this line and reads
- * only WZ_LANES, WZ_STREAMS and WZ_GRAPH from the environment.
+ * only WZ_LANES, WZ_STREAMS, WZ_GRAPH and WZ_SCHEDULE from the environment.
  * ====================================================================================================================== */
 #ifdef WZ_DEV_BUILD
 /* Test hooks for the CPython-set emulation: iteration order after adding keys[0..n) / of

@@ -41,15 +41,15 @@ def test_binding_covers_header():
     _lib.load(dev=True)
 
 
-def test_product_library_reads_three_environment_settings():
-    """WZ_LANES, WZ_STREAMS, WZ_GRAPH (+ GPU_MAX_HW_QUEUES, which it sets for the HIP runtime): every tuning knob the sources read
+def test_product_library_reads_four_environment_settings():
+    """WZ_LANES, WZ_STREAMS, WZ_GRAPH, WZ_SCHEDULE (+ GPU_MAX_HW_QUEUES, which it sets for the HIP runtime): every tuning knob the sources read
     through wz_dev_getenv() exists in the development build only -- its name is not even in the product binary."""
     import glob
     csrc = os.path.join(os.path.dirname(HEADER), "..", "watsor_amd", "csrc")
     text = "".join(open(f).read() for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.cpp")) +
                    glob.glob(os.path.join(csrc, "*.h")))
     read_directly = set(re.findall(r'[^_]getenv\("([A-Z0-9_]+)"\)', text))
-    assert read_directly == {"WZ_GRAPH", "WZ_LANES", "WZ_STREAMS"}, read_directly
+    assert read_directly == {"WZ_GRAPH", "WZ_LANES", "WZ_STREAMS", "WZ_SCHEDULE"}, read_directly
     knobs = set(re.findall(r'"(WZ_[A-Z0-9_]+)"', text)) - read_directly
     assert len(knobs) >= 40
     product, dev = open(_lib.LIB_PATH, "rb").read(), open(_lib.DEV_LIB_PATH, "rb").read()

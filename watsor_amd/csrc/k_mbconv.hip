@@ -367,7 +367,7 @@ static MbCfg wz_mb_choose(const WzMbArgs& a, int n) {
     // workgroups wanted per launch: half the chip.  256 (round 1 / 2) gives the shortest launch (block 16: 9.1 + 4.4 us against
     // 15.8 + 2.8) -- and 50.9 k frames/s against 52.0 k with four lanes in flight: the other lanes' launches want the CUs
     // (profiles/r03_wave_counts_and_cu_footprints.txt)
-    const int target = wz_mb_env("WZ_MB_WGS", 128);
+    const int target = wz_mb_env("WZ_MB_WGS", wz_latency_schedule() ? 256 : 128);
     int nsplit = (target + tiles - 1) / tiles;
     const int max_split = wz_mb_env("WZ_MB_MAXSPLIT", 16);
     if (nsplit > max_split) nsplit = max_split;

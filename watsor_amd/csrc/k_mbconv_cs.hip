@@ -275,7 +275,7 @@ int wz_launch_mbconv_cs(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
     // out and back) and needs no reduce launches (31 graph nodes instead of 35): 49.1 k -> 50.1 k frames/s with four lanes in flight,
     // p50 0.380 -> 0.394 ms (profiles/r03_wave_counts_*; round 1 measured the same trade at +1 %, round 2 at +0.6 %).  Default since
     // round 3; WZ_MB_CS_MIN_W=11 brings the channel-group kernel back for the 10x10 maps.
-    static const int min_w = wz_cs_env("WZ_MB_CS_MIN_W", 1);
+    static const int min_w = wz_cs_env("WZ_MB_CS_MIN_W", wz_latency_schedule() ? 11 : 1);
     if (enabled != 1 || a0.stem || a0.wout > 19 || a0.wout < min_w) return -2;
     const int nto = a0.n_pad / 16;
     // ... except block 16 (320 output channels, 0.9 MB of weights per workgroup: 31 us alone against 9 + 4): it stays on the channel-group

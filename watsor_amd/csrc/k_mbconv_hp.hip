@@ -666,6 +666,11 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
                 (void)wz_hp_launch<4, false, false, 4, 2, 1, 2, 4>(a, n, s, true);
                 return wz_hp_launch<4, false, false, 4, 2, 1, 2>(a, n, s, true);
             }
+            static const int cs75_nw = wz_hp_env("WZ_HP_CS75_NW", 0);   // the 75x75 stride-1 block: 2 / 3 waves per tile (0: one wave per tile)
+            if (!prepare && sh && a.wout > 38 && a.wout <= 75 && nk32 >= 4 && nk32 <= 6) {
+                if (cs75_nw == 2) return wz_hp_launch<2, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, false);
+                if (cs75_nw == 3) return wz_hp_launch<3, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, false);
+            }
             if (cs && sh && cs_nw == 2) return wz_hp_launch<2, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, false);
             if (cs && sh && cs_nw == 3) return wz_hp_launch<3, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, false);
             if (cs && sh && cs_nw == 4) return wz_hp_launch<4, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, false);
@@ -699,7 +704,7 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
     if (a.wout > 19) return -1;
     if (a.stride == 2) {
         if (a.kc0 == 1 && nto == 4) {
-            static const int cs6_nw = wz_hp_env("WZ_HP_CS6_NW", 3);   // waves per tile of the 38x38 -> 19x19 block (6 chunks): 3 with two chunks
+            static const int cs6_nw = wz_hp_env("WZ_HP_CS6_NW", wz_latency_schedule() ? 8 : 3);   // waves per tile of the 38x38 -> 19x19 block (6 chunks): 3 with two chunks
                                                                       // each (49.8 k -> 50.5 k frames/s; 8: two waves idle, a CU per workgroup)
             if (prepare) {
                 (void)wz_hp_launch<HP_CS_WAVES, true, false, 6, 1, 1, 4, 2, false, true>(a, n, s, true);
@@ -731,7 +736,7 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
     // this lane's launch or of another lane's) share a CU, where eight waves own it: 47.5 k -> 49.1 k frames/s with four lanes in
     // flight.  3 waves: 48.2 k; 5: 45.8 k; 6: 46.8 k (workgroups that neither fill a CU nor leave room for a second one);
     // WZ_HP_CS19_NW=8 is the lowest-latency setting (p50 0.372 against 0.380 ms).  profiles/r03_wave_counts_*.
-    static const int cs19_nw = wz_hp_env("WZ_HP_CS19_NW", 4);
+    static const int cs19_nw = wz_hp_env("WZ_HP_CS19_NW", wz_latency_schedule() ? 8 : 4);
 #define HP_CASE(K, N)                                                                                         \
     if (a.kc0 == K && nto == N) {                                                                             \
         if (prepare) {                                                                                        \

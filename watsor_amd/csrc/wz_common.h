@@ -138,7 +138,7 @@ struct WzCamFilter {
 extern thread_local int wz_launch_repeat;
 // Tuning and A/B knobs (the WZ_* variables named next to the code they steer) exist in the DEVELOPMENT build only
 // (`make dev`: -DWZ_DEV_BUILD, libwatsor_hip_dev.so -- what tools/ and the stage-level parity tests load).  The product library
-// takes every default and reads exactly three operator settings from the environment: WZ_LANES, WZ_STREAMS, WZ_GRAPH.
+// takes every default and reads exactly four operator settings from the environment: WZ_LANES, WZ_STREAMS, WZ_GRAPH, WZ_SCHEDULE.
 static inline const char* wz_dev_getenv(const char* name) {
 #ifdef WZ_DEV_BUILD
     return getenv(name);
@@ -146,6 +146,15 @@ static inline const char* wz_dev_getenv(const char* name) {
     (void)name;
     return nullptr;
 #endif
+}
+
+// WZ_SCHEDULE=latency (operator setting, read once per process): the launch shapes that make ONE batch finish soonest on an otherwise
+// idle GPU -- eight waves per 19x19 tile, the 10x10 blocks on 256 workgroups + a reduce launch, the SSD heads' K slices cut for the
+// whole chip.  Default ("throughput"): the shapes that leave room for the other lanes' launches -- 9 % more frames/s with four lanes
+// in flight, 3 % more latency of a lone batch (profiles/r03_wave_counts_and_cu_footprints.txt).
+static inline bool wz_latency_schedule() {
+    static const bool lat = [] { const char* e = getenv("WZ_SCHEDULE"); return e && (e[0] == 'l' || e[0] == 'L'); }();
+    return lat;
 }
 
 #define WZ_LAUNCH(...) do { for (int _wz_r = 0; _wz_r < wz_launch_repeat; ++_wz_r) hipLaunchKernelGGL(__VA_ARGS__); } while (0)

@@ -793,7 +793,7 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
             e->num_cus = cus;
-        e->wide_cus = e->num_cus / 2;
+        e->wide_cus = wz_latency_schedule() ? e->num_cus : e->num_cus / 2;
         if ((env = wz_dev_getenv("WZ_WIDE_CUS")) && atoi(env) > 0) e->wide_cus = atoi(env);
     }
     if ((env = getenv("WZ_LANES")) && atoi(env) >= 1 && atoi(env) <= WZ_SLOTS) e->n_lanes = atoi(env);
