@@ -144,3 +144,42 @@ def test_end_to_end_with_each_option(request, synth_weights, which):
             n_ref = int((ref["confidence"] > 0.1).sum())
             assert n_ref > 0 and len(missing) <= max(1, n_ref // 20)
             assert max(abs(p[3]) for p in pairs) <= 1e-3
+
+
+def test_latency_schedule_detects_the_same_objects(model_dir, tmp_path):
+    """WZ_SCHEDULE=latency (include/watsor_hip.h) picks other launch shapes -- other summation orders -- for the same network: the rows
+    of a child process running it agree with this process's (throughput schedule) to rounding, on the product library."""
+    import json
+    import os
+    import subprocess
+    import sys
+    script = (
+        "import sys, json, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from watsor_amd.runtime import HipEngine, ROW_DTYPE\n"
+        "from watsor_amd.synth import synthetic_frame\n"
+        "e = HipEngine(%r, 0, 8, 640, 480)\n"
+        "frames = [synthetic_frame(640, 480, 8800 + i) for i in range(8)]\n"
+        "rows = [np.zeros(100, ROW_DTYPE) for _ in frames]\n"
+        "e.detect_batch(frames, rows)\n"
+        "print(json.dumps(dict(nodes=e.graph_nodes(0), label=[r['label'].tolist() for r in rows], conf=[r['confidence'].tolist() for r in rows],"
+        " box=[np.stack([r['x_min'], r['y_min'], r['x_max'], r['y_max']], 1).tolist() for r in rows])))\n"
+        "e.close()\n" % (conftest.ROOT, os.path.join(model_dir, "mi355x.bin")))
+    out = {}
+    for sched in ("throughput", "latency"):
+        env = dict(os.environ, WZ_SCHEDULE=sched)
+        p = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=240)
+        assert p.returncode == 0, p.stderr[-1500:]
+        out[sched] = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    a, b = out["throughput"], out["latency"]
+    assert b["nodes"] > a["nodes"]                                   # the latency schedule keeps the reduce launches of blocks 13 .. 16
+    for f in range(8):
+        ref = dict(label=np.array(a["label"][f], np.int32), confidence=np.array(a["conf"][f]), box=np.array(a["box"][f], np.int32))
+        got = np.zeros(100, ROW_DTYPE)
+        got["label"], got["confidence"] = b["label"][f], b["conf"][f]
+        bx = np.array(b["box"][f], np.int32)
+        got["x_min"], got["y_min"], got["x_max"], got["y_max"] = bx[:, 0], bx[:, 1], bx[:, 2], bx[:, 3]
+        pairs, missing = pu.match_rows(got, ref, min_score=0.1)
+        n_ref = int((ref["confidence"] > 0.1).sum())
+        assert n_ref > 50 and len(missing) <= max(1, n_ref // 20)
+        assert max(abs(p[3]) for p in pairs) <= 5e-4
