@@ -88,7 +88,8 @@ class BatchedWorkerMixin:
                               logger=getattr(self, "_logger", None))
         if hasattr(object_detector, "submit_host") and hasattr(object_detector, "collect"):
             st["asynchronous"] = kwargs.get("hip_async", True)
-            st["lanes"] = max(1, min(int(kwargs.get("hip_lanes", 2)), getattr(object_detector, "num_lanes", 1)))
+            lanes = getattr(object_detector, "num_lanes", 1)
+            st["lanes"] = max(1, min(int(kwargs.get("hip_lanes", lanes)), lanes))
         if st["asynchronous"] and kwargs.get("hip_frame_table", True) and hasattr(object_detector, "bind_frame_table"):
             try:
                 st["table"] = object_detector.bind_frame_table(frame_buffers, st["cams"] or {})
@@ -339,7 +340,7 @@ def create_object_detectors(delegate_class, stop_event, log_queue, frame_queue, 
       hip_drop     True: rows failing those filters come back as all-zero rows (for `hip_detection_sieve()`)
       hip_options  dict(max_batch=, max_width=, max_height=) overriding what is derived from the frame buffers;
                    pixel_format= "rgb24" | "nv12" | "yuv420p" (or {camera name: ...}): what the decoders write (hip_gpu.py)
-      hip_lanes    batches kept in flight per GPU by the worker (default 2)
+      hip_lanes    batches kept in flight per GPU by the worker (default: the engine's lanes, 4)
       hip_metric_interval  seconds of batches folded into one `inference_time` observation (default 0.005; 0: one per batch)
       hip_frame_table      False: describe the frames of every batch to the engine instead of binding them once"""
     _ref = _require_watsor()
