@@ -242,3 +242,79 @@ def test_worker_class_survives_the_spawn_start_method(reference_on_path):
     cls = d.BatchedObjectDetector
     assert issubclass(cls, ObjectDetector) and issubclass(cls, d.BatchedWorkerMixin)
     assert pickle.loads(pickle.dumps(cls)) is cls
+
+
+class AddressEngine:
+    """Stand-in for `HipEngine` under the real `HipObjectDetector`: it keeps what `bind_frames` was given -- raw addresses of the
+    reference's shared-memory pixels and `header.detections` -- and, like the library, reads and writes THROUGH those addresses
+    when a bound batch is collected.  Row 0 of a frame carries the frame's first pixel."""
+    instances = []
+
+    def __init__(self, path, device, max_batch, max_width, max_height):
+        self.max_batch, self.num_slots, self.device_name = 4, 2, "stub"
+        self.table, self.busy, self.batches, self.registered = None, {}, [], []
+        AddressEngine.instances.append(self)
+
+    def host_register_address(self, addr, size):
+        self.registered.append((addr, size))
+
+    def host_unregister_address(self, addr):
+        pass
+
+    def bind_frames(self, pix, ws, hs, fmts, cams, rows):
+        self.table = list(zip(pix, ws, hs, fmts, cams, rows))
+
+    def submit_bound(self, lane, entries):
+        assert lane not in self.busy
+        self.busy[lane] = list(entries)
+        self.batches.append(len(entries))
+
+    def collect_bound(self, lane):
+        import ctypes
+        from watsor_amd.share import DetectionArray
+        for e in self.busy.pop(lane):
+            pix, w, h, fmt, cam, rows = self.table[e]
+            d = DetectionArray.from_address(rows)
+            d[0].label, d[0].confidence = 1, 0.9
+            d[0].bounding_box.x_min = ctypes.c_uint8.from_address(pix).value
+            d[0].bounding_box.x_max = w
+            d[0].bounding_box.y_max = h
+
+    def sync(self):
+        pass
+
+    def close(self):
+        pass
+
+
+def test_frame_table_addresses_are_the_reference_frames_own_memory(reference_on_path, tmp_path, monkeypatch):
+    """The real HipObjectDetector.bind_cameras / bind_frame_table over the reference's own FrameBuffer / Frame / StateLatch
+    (`watsor/stream/share.py:16-73`, `sync.py`): the engine is told addresses once; rows written through them are the rows the
+    sieve and the sink then read from `frame.header.detections`, and every frame's latch is stepped exactly once."""
+    from watsor_amd.detection import detector as d
+    from watsor_amd.detection import hip_gpu
+    monkeypatch.setattr(hip_gpu, "HipEngine", AddressEngine)
+    AddressEngine.instances = []
+    (tmp_path / hip_gpu.ENGINE_FILE).write_bytes(b"stub")
+
+    def frame_fn(cam, i, w, h):
+        return np.full((h, w, 3), (int(cam[3:]) * 50 + i) % 256, np.uint8)
+
+    def factory(stop, log_queue, frame_queue, buffers):
+        return [d.BatchedObjectDetector(Thread, "detector1", stop, log_queue, frame_queue, buffers,
+                                        kwargs={'detector_class': hip_gpu.HipObjectDetector,
+                                                'detector_args': (str(tmp_path), 0)})]
+
+    stop, latch, seen, procs = build_pipeline(reference_on_path, factory, 3, frame_fn)
+    assert run(stop, latch, procs, 60)
+    assert len(seen) >= 12
+    for label, conf, x_min, px0 in seen:
+        assert label == 1 and x_min == px0
+    (eng,) = AddressEngine.instances
+    assert len(eng.table) == 30 and len(eng.registered) == 30                 # 3 cameras x FrameBuffer(10, ...)
+    assert all((w, h, fmt, cam) == (64, 48, hip_gpu.FMT_RGB24, -1) for _, w, h, fmt, cam, _ in eng.table)
+    assert len({p for p, *_ in eng.table}) == 30 and len({r for *_, r in eng.table}) == 30
+    assert all(size == 64 * 48 * 3 for _, size in eng.registered)
+    assert max(eng.batches) > 1 and max(eng.batches) <= 4 and not eng.busy
+    det = procs[-1]
+    assert det.fps() > 0 and det.inference_time() > 0
