@@ -685,6 +685,44 @@ def plain_fp16_leg(weights, frames, rank):
     return r
 
 
+def robust_engine_leg(weights, frames, rank):
+    """The `--robust` program (all 17 blocks split, square-root chunk buffer) on the headline workload, and what it is for: the scores of
+    both `-p 16` programs against the oracle on weights whose channels are spread over 1.5 decades (watsor_amd/synth.py:
+    spread_channel_scales -- what folding a trained BatchNorm does to the channel amplitudes)."""
+    from watsor_amd import engine as builder
+    from watsor_amd.runtime import HipEngine
+    from watsor_amd.synth import spread_channel_scales
+    d = "/tmp/wz_bench16r_%d_%d" % (os.getpid(), rank)
+    os.makedirs(d, exist_ok=True)
+    path = os.path.join(d, "mi355x.bin")
+    dev = int(os.environ.get("LOCAL_RANK", "0"))
+    r = {}
+    try:
+        spread = spread_channel_scales(weights, 1.5)
+        for name, w, kw in (("headline", weights, dict(robust=True)), ("spread_default", spread, {}), ("spread_robust", spread, dict(robust=True))):
+            builder.save_engine(builder.build_engine(w, **kw), path)
+            eng = HipEngine(path, dev, BATCH, WIDTH, HEIGHT)
+            try:
+                dfr = [eng.upload(f) for f in frames[:BATCH]]
+                if name == "headline":
+                    r = throughput(eng, lambda lane, s: eng.submit_device(lane, dfr, [WIDTH] * BATCH, [HEIGHT] * BATCH), BATCH)
+                par = parity_leg(eng, frames, dfr, w)
+            finally:
+                eng.close()
+            if name == "headline":
+                r.update(dtype="f16", max_dscore=par["max_dscore"], within_tolerance=par["within_tolerance"])
+            else:
+                r["max_dscore_%s_program_weights_spread_1p5_decades" % name.split("_")[1]] = par["max_dscore"]
+        r["channel_spread_decades"] = dict(headline=round(builder.channel_spread_decades(weights), 2), spread=round(builder.channel_spread_decades(spread), 2))
+    finally:
+        if os.path.exists(path):
+            os.remove(path)
+        os.rmdir(d)
+    r["workload"] = ("the headline workload on the --robust program (what `python -m watsor_amd.engine` builds when the folded weights spread their "
+                     "channels over more than %.2f decades); max_dscore_*: both programs against the oracle on such weights" % builder.SPREAD_VALIDATED_DECADES)
+    return r
+
+
 def cpu_baseline(weights, frames, budget_s=12.0):
     """Oracle detector (kind 'port') on this host's cores over a bounded sample of the same frames, with the split
     between the network (torch-CPU convolutions) and the post-processing (numpy + pure-Python class-by-class NMS)."""
@@ -1023,6 +1061,7 @@ def main():
             note("worker legs done")
             out["legs"] = legs
         if world == 1 and not args.no_fp32_leg:
+            out["robust_engine"] = robust_engine_leg(weights, host_frames, rank)
             out["plain_fp16_engine"] = plain_fp16_leg(weights, host_frames, rank)
             out["fp32_engine"] = fp32_engine_leg(weights, host_frames, rank)
             note("other-precision legs done")

@@ -323,12 +323,79 @@ def test_builder_reports_the_channel_spread_and_warns_beyond_what_was_validated(
     assert 1.1 < engine.channel_spread_decades(wide) < 1.6
     np.savez(str(tmp_path / "wide.npz"), **wide)
     out = str(tmp_path / "m" / "mi355x.bin")
-    assert engine.main(["-i", str(tmp_path / "wide.npz"), "-o", out]) == 0
+    assert engine.main(["-i", str(tmp_path / "wide.npz"), "-o", out, "--robust", "off"]) == 0
     cap = capsys.readouterr()
-    assert "WARNING" in cap.err and "-p 32" in cap.err and "decades" in cap.out
+    assert "WARNING" in cap.err and "-p 32" in cap.err and "--robust on" in cap.err and "decades" in cap.out
     with pytest.raises(ValueError):
-        engine.main(["-i", str(tmp_path / "wide.npz"), "-o", out, "--precision-check", "error"])
+        engine.main(["-i", str(tmp_path / "wide.npz"), "-o", out, "--robust", "off", "--precision-check", "error"])
+    assert engine.main(["-i", str(tmp_path / "wide.npz"), "-o", out, "--precision-check", "error"]) == 0    # (auto: the robust program)
+    capsys.readouterr()
     assert engine.main(["-i", str(tmp_path / "wide.npz"), "-o", out, "-p", "32"]) == 0
     assert "WARNING" not in capsys.readouterr().err
     assert engine.main(["-i", "synthetic", "-o", out]) == 0
     assert "WARNING" not in capsys.readouterr().err
+
+
+def test_robust_program_packs_all_blocks_split_and_square_root_scaled(hp_blob, synth_weights):
+    """`build_engine(robust=True)`: all 17 blocks split-operand with flag 4 (square-root chunk buffer: depthwise weights carry
+    6 / 65535^2), block 13 with an expand stage of its own from block 12's pair output, and the first SSD feature map as a 1x1 conv
+    over both halves of that pair (192 channels, weight rows packed twice)."""
+    rb = engine.build_engine(synth_weights, robust=True)
+    hdr, tensors, ops = parse(rb)
+    dhdr, dtensors, dops = parse(hp_blob)
+    assert hdr["hp_blocks"] == arch.HP_ALL_BLOCKS + 1 == 17
+    assert [o["name"] for o in ops] == [o["name"] for o in dops] and len(tensors) == len(dtensors)
+    prog = arch.build(hp_upto=arch.HP_ALL_BLOCKS)
+    blocks = [(o, op) for o, op in zip(ops, prog.ops) if o["kind"] == arch.OP_MBCONV]
+    assert len(blocks) == 17
+    for o, op in blocks:
+        assert o["flags"] & 1 and o["flags"] & 4 and tensors[o["src"]]["flags"] == 1 and o["cin0"] > 0
+        assert bool(o["flags"] & 2) == bool(tensors[o["dst"]]["flags"]) == (op.block < 16)
+        dw = op.parts[-2]
+        wf, _ = engine.fold_batch_norm(synth_weights, dw)
+        wd = np.frombuffer(rb, np.float32, 9 * o["cmid_pad"], hdr["weights_off"] + o["wd_off"]).reshape(9, -1)
+        np.testing.assert_allclose(wd[:, :o["cmid"]], wf.reshape(9, -1) * (6.0 / 65535.0 ** 2), rtol=1e-6, atol=0)
+    b13 = next(o for o, op in blocks if op.block == 13)
+    assert (b13["cin0"], b13["kc0"], b13["cmid"], b13["cout"], b13["stride"]) == (96, 3, 576, 160, 2)
+    assert tensors[b13["src"]]["name"] == "expanded_conv_12/output"
+    # ... none of the default program's blocks carries flag 4, and its block 13 reads the expanded tensor
+    assert not any(o["flags"] & 4 for o in dops)
+    assert next(o for o in dops if o["name"].endswith("expanded_conv_13"))["cin0"] == 0
+    # the feature-map conv: cin doubled, flag 8, rows k and k + 96 both hold W[k]
+    tap = next(o for o in ops if o["name"].endswith("expanded_conv_13/expand"))
+    assert tap["kind"] == arch.OP_CONV and tap["flags"] == 8 and tap["cin"] == 192 and tap["kc"] == 6 and tap["cout"] == 576
+    assert tensors[tap["src"]]["flags"] == 1 and tensors[tap["src"]]["c"] == 96 and tensors[tap["dst"]]["flags"] == 0
+    w = unpack_conv(rb, hdr, dict(tap, ksize=1))
+    np.testing.assert_array_equal(w[:, :96, :576], w[:, 96:192, :576])
+    dtap = next(o for o in dops if o["name"].endswith("expanded_conv_13/expand"))
+    np.testing.assert_array_equal(w[:, :96, :576], unpack_conv(hp_blob, dhdr, dict(dtap, ksize=1))[:, :96, :576])
+    with pytest.raises(ValueError):
+        engine.build_engine(synth_weights, precision=32, robust=True)
+    with pytest.raises(ValueError):
+        engine.build_engine(synth_weights, hp_upto=-1, robust=True)
+
+
+def test_builder_picks_the_robust_program_by_channel_spread(tmp_path, synth_weights, capsys):
+    from watsor_amd.synth import spread_channel_scales
+    np.savez(str(tmp_path / "wide.npz"), **spread_channel_scales(synth_weights, 1.0))
+    np.savez(str(tmp_path / "wider.npz"), **spread_channel_scales(synth_weights, 2.5))
+    out = str(tmp_path / "m" / "mi355x.bin")
+
+    def hp_blocks():
+        return parse(open(out, "rb").read())[0]["hp_blocks"]
+
+    assert engine.main(["-i", str(tmp_path / "wide.npz"), "-o", out]) == 0           # auto: 1.0 decades -> robust, inside what it was validated for
+    cap = capsys.readouterr()
+    assert hp_blocks() == 17 and "robust" in cap.out and "WARNING" not in cap.err
+    assert engine.main(["-i", str(tmp_path / "wide.npz"), "-o", out, "--robust", "off"]) == 0
+    cap = capsys.readouterr()
+    assert hp_blocks() == 13 and "WARNING" in cap.err
+    assert engine.main(["-i", "synthetic", "-o", out]) == 0                          # one scale: the default program
+    assert hp_blocks() == 13 and "WARNING" not in capsys.readouterr().err
+    assert engine.main(["-i", "synthetic", "-o", out, "--robust", "on"]) == 0
+    assert hp_blocks() == 17
+    assert engine.main(["-i", str(tmp_path / "wider.npz"), "-o", out]) == 0           # beyond the robust program's range as well: it says so
+    cap = capsys.readouterr()
+    assert hp_blocks() == 17 and "WARNING" in cap.err and "-p 32" in cap.err
+    with pytest.raises(ValueError):
+        engine.main(["-i", "synthetic", "-o", out, "--robust", "on", "--plain-fp16"])

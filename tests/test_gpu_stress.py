@@ -46,3 +46,36 @@ def test_score_error_under_channel_spread(tmp_path, synth_weights, decades, bar1
           % (decades, engine.channel_spread_decades(W), out[16][0], out[32][0], out[16][1]))
     assert out[32][0] <= 1e-4                       # the fp32 engine (pair input, exact-fp32 matrix cores): far inside the tolerance at any spread
     assert out[16][0] <= bar16                      # the fp16 engine: the tolerance up to what was validated, a sanity bound beyond
+
+
+@pytest.mark.parametrize("decades,bar", [(0.0, 5e-4), (1.0, 1e-3), (1.5, 1e-3), (2.0, 1.5e-3)])
+def test_robust_program_holds_the_tolerance_under_channel_spread(tmp_path, synth_weights, decades, bar):
+    """`build_engine(robust=True)` -- all 17 blocks on the split-operand kernel, expanded tensors as unorm16 of sqrt(x / 6): the north
+    star's 1e-3 up to 1.5 decades of per-channel spread (where the default program is at 3e-3), measured beyond.  The frames go through
+    in ONE batch of mixed resolutions, so the lean builds behind the 19x19 maps run their multi-frame grids."""
+    from watsor_amd.runtime import HipEngine
+    from watsor_amd.share import DetectionArray
+    W = spread_channel_scales(synth_weights, decades) if decades else synth_weights
+    sizes = [(640, 480), (1280, 720), (320, 240), (640, 360), (640, 480)]
+    frames = [synthetic_frame(w, h, 5100 + i) for i, (w, h) in enumerate(sizes)]
+    path = str(tmp_path / "robust" / "mi355x.bin")
+    engine.save_engine(engine.build_engine(W, robust=True), path)
+    oracle = odet.OracleObjectDetector(weights=W)
+    eng = HipEngine(path, 0, 8, 1280, 720)
+    try:
+        assert eng.hp_blocks == 17
+        rows = [DetectionArray() for _ in frames]
+        eng.detect_batch(frames, rows)
+        worst, n = 0.0, 0
+        for f, r in zip(frames, rows):
+            got = np.frombuffer(r, dtype=ROW_DTYPE)
+            b, c, s, _, _ = oracle.raw(f)
+            ref = odet.rows_as_array(f.shape, b, c, s)
+            pairs, missing = pu.match_rows(got, ref, min_score=0.1)
+            assert len(pairs) >= 50
+            worst = max(worst, max(abs(p[3]) for p in pairs))
+            n += len(pairs)
+    finally:
+        eng.close()
+    print("\\nrobust program, channel spread %.1f decades: max |dscore| %.2e over %d rows" % (decades, worst, n))
+    assert worst <= bar

@@ -61,6 +61,12 @@ def quant(x, mode):
     if mode == "q":      # unorm16 of sqrt(x/6): step 12 sqrt(x/6) / 65535 -- relative precision for small values
         u = torch.round(torch.sqrt(torch.clamp(x, 0.0, 6.0) / 6.0) * 65535.0) / 65535.0
         return u * u * 6.0
+    if mode == "e":      # 16-bit float of x + 2^-12: 4 exponent bits (2^-12 .. 2^2), 12 mantissa bits, round to nearest -- relative
+        c = 2.0 ** -12  # precision 2^-13 whatever the channel's scale is
+        y = (torch.clamp(x, 0.0, 6.0) + c).to(torch.float32)
+        b = y.view(torch.int32).to(torch.int64)
+        b = ((b + (1 << 10)) >> 11) << 11
+        return b.to(torch.int32).view(torch.float32).to(torch.float64) - c
     raise ValueError(mode)
 
 

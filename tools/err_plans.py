@@ -92,6 +92,7 @@ for n in range(2, 17):
     PLANS["hp%dh" % n] = hp(n, dw_in="h")
     PLANS["hp%dx" % n] = hp(n, dw_in="x")
     PLANS["hp%dq" % n] = hp(n, dw_in="q")
+    PLANS["hp%de" % n] = hp(n, dw_in="e")
 
 
 def hp_tail(n, exp=("h", "h", "h"), dep=("h", "h", "h"), pro=("h", "h", "h"), dw_in="x", rest=("h", "h", "h")):
@@ -123,3 +124,31 @@ PLANS["t_pro"] = hp_tail(12, X, X, H)
 PLANS["t_rest_x"] = hp_tail(12, H, H, H, rest=X)
 PLANS["t_dep_in"] = hp_tail(12, X, ("x", "h", "x"), X)                   # the expanded tensor as fp16 in front of the depthwise conv
 PLANS["t_pro_in"] = hp_tail(12, X, X, ("x", "h", "x"))                   # the depthwise output as fp16 in front of the project conv
+
+
+def hp_rest(n, dw_in="q", conv1=H, extras=H, heads=H, e13_out=None):
+    """hp(n, dw_in) with the layers behind the blocks chosen separately (which of Conv_1 / extras / heads decides what is left);
+    e13_out: storage mode of block 13's expand output (the first SSD feature map), None = as hp() has it."""
+    front = hp(n, dw_in=dw_in)
+
+    def plan(spec, groups):
+        cfg = front(spec, groups)
+        for lab, names in groups.items():
+            for nm in names:
+                if lab == "Conv_1":
+                    cfg[nm] = conv1
+                elif lab.startswith("heads"):
+                    cfg[nm] = heads
+                elif _idx(lab) is None and lab != "stem":
+                    cfg[nm] = extras
+                elif e13_out is not None and _idx(lab) == 13 and lab[4:] == "exp":
+                    cfg[nm] = (cfg[nm][0], cfg[nm][1], e13_out)
+        return cfg
+    return plan
+
+
+PLANS["r_rest_x"] = hp_rest(16, conv1=X, extras=X, heads=X)
+PLANS["r_conv1_s"] = hp_rest(16, conv1=S)
+PLANS["r_conv1_extras_s"] = hp_rest(16, conv1=S, extras=S)
+PLANS["r_heads_s"] = hp_rest(16, heads=S)
+PLANS["r_e13h"] = hp_rest(16, e13_out="h")

@@ -83,6 +83,7 @@ class Op:
     block: int = -1            # OP_MBCONV: index of the inverted-residual block (expanded_conv_<block>)
     hp: bool = False           # OP_MBCONV on the split-operand kernel (csrc/k_mbconv_hp.hip): both matrix operands as
                                # hi + lo fp16 pairs, input (and residual) tensor stored as such a pair
+    pair_src: bool = False     # OP_CONV 1x1 whose source is a pair tensor, read as 2 cin plain channels (weight rows packed twice)
 
 
 @dataclass
@@ -121,7 +122,8 @@ def _blk(i: int) -> str:
     return "expanded_conv" if i == 0 else "expanded_conv_%d" % i
 
 
-HP_LAST_BLOCK = 12   # the blocks in front of the first SSD feature map (the 150x150 ... 19x19 maps)
+HP_LAST_BLOCK = 12   # the blocks in front of the first SSD feature map (the 150x150 ... 19x19 maps): the `-p 16` program
+HP_ALL_BLOCKS = 16   # every inverted-residual block: the robust program (engine.py --robust)
 
 
 def build(size: int = INPUT_SIZE, fuse: bool = True, fuse_stem: bool = True, hp_upto: int = -1, input_pair: bool = False) -> Program:
@@ -129,6 +131,8 @@ def build(size: int = INPUT_SIZE, fuse: bool = True, fuse_stem: bool = True, hp_
     one fp16 rounding of the resized image is otherwise the largest error of an engine that computes in fp32).
     hp_upto >= 0 (needs fuse and fuse_stem): blocks 0 .. hp_upto run on the split-operand kernel and the tensors
     between them (the network input included) are hi + lo fp16 pairs; block hp_upto's output is plain fp16 again.
+    With hp_upto >= 13 block 13 computes its own expand stage from block 12's pair output, and the separate expand
+    conv -- the first SSD feature map, plain fp16 for the heads -- reads both halves of that pair (`pair_src`).
     fuse=True: every inverted-residual block is ONE op (OP_MBCONV); block 13 keeps its expand conv as
     a separate op because its output is the first SSD feature map.  fuse=False: one op per layer (the
     program the per-layer parity tests walk); both programs compute bit-identical tensors.
@@ -158,7 +162,11 @@ def build(size: int = INPUT_SIZE, fuse: bool = True, fuse_stem: bool = True, hp_
                             ACT_NONE, True, res=res))
             if fuse:
                 keep_expand = t != 1 and idx == 13          # its output is an SSD feature map
-                if keep_expand:
+                if keep_expand and hp_upto >= idx:          # ... and the block expands for itself, from the pair tensor
+                    ops.append(block[0])
+                    ops[-1].pair_src = True
+                    keep_expand = False
+                elif keep_expand:
                     ops.append(block.pop(0))
                 has_expand = t != 1 and not keep_expand
                 ops.append(Op(OP_MBCONV, FE + name, block[0].src, name + "/output", mid, c, 3, stride, ACT_NONE, True,
@@ -185,9 +193,9 @@ def build(size: int = INPUT_SIZE, fuse: bool = True, fuse_stem: bool = True, hp_
         taps.append(n2)
 
     if hp_upto >= 0:
-        if not (fuse and fuse_stem) or hp_upto > HP_LAST_BLOCK:
+        if not (fuse and fuse_stem) or hp_upto > HP_ALL_BLOCKS:
             raise ValueError("split-operand blocks need the fused program with the stem folded in, and end at block %d"
-                             % HP_LAST_BLOCK)
+                             % HP_ALL_BLOCKS)
         for op in ops:
             if op.kind == OP_MBCONV and op.block <= hp_upto:
                 op.hp = True

@@ -56,9 +56,13 @@ __device__ __forceinline__ void wz_hp_split(const float v[8], half8_t& hi, half8
 typedef __attribute__((ext_vector_type(2))) float wz_f32x2_t;
 
 // eight unorm16 -> four pairs of floats (v_cvt_f32_u32 with SDWA word select)
+template <bool QE = false>
 __device__ __forceinline__ void wz_hp_unpack(const wz_u32x4_t t, wz_f32x2_t x[4]) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) x[r] = (wz_f32x2_t){(float)(t[r] & 0xffffu), (float)(t[r] >> 16)};
+    for (int r = 0; r < 4; ++r) {
+        x[r] = (wz_f32x2_t){(float)(t[r] & 0xffffu), (float)(t[r] >> 16)};
+        if constexpr (QE) x[r] = x[r] * x[r];   // the buffer holds square roots (v_pk_mul_f32)
+    }
 }
 
 // d[0..3] += x[0..3] * (w0, w1) as four v_pk_fma_f32: the depthwise stage is bound by VALU issue, and a packed FMA
@@ -82,8 +86,18 @@ __device__ __forceinline__ void wz_hp_fma8(wz_f32x2_t d[4], const wz_f32x2_t x[4
 // SH (CS only): the halo fragments are fetched ONCE per workgroup -- each wave loads its share of the MPW x KCI x 2 fragments,
 // they meet in LDS, every wave reads all of them back -- instead of once per wave (8 or 12 times the same 13 .. 18 KiB through
 // the vector memory path of one CU: the prologue of the 19x19 blocks was bound by exactly that, profiles/r02zq_*).
-template <int NW, bool CS, bool STEM, int MPW, int MQW, int KCI, int NTO, int OCC = 2, bool ONEPASS = false, bool SH = false>
+// QE: the chunk buffer holds unorm16 of sqrt(v / 6) instead of v / 6 (the ROBUST program, WzMbArgs::qenc): the step is 12 sqrt(v / 6) / 65535,
+// i.e. fine where the values are small -- what channels of very different scale need -- for one v_sqrt_f32 per
+// stored value and one multiply per tap; the depthwise weights then carry 6 / 65535^2.
+// LEAN (CS + SH, one output m-tile): the shapes behind the 19x19 maps (block 13: 96 -> 576 -> 160 at stride 2; blocks 14 .. 16:
+// 160 -> 960 -> 160 / 320 on 10x10) do not fit 256 registers the way the others are written -- MPW x KCI x 2 halo fragments alone are
+// 144 / 120 of them -- so the halo fragments of ONE m-tile at a time come back from LDS inside the expand stage, and a workgroup
+// finishes NTO of the block's n-tiles: blockIdx.x % nsplit picks which (the expand and depthwise stages are repeated per group:
+// these launches have a third of a chip's worth of workgroups, the repeat costs no time and halves the accumulators).
+template <int NW, bool CS, bool STEM, int MPW, int MQW, int KCI, int NTO, int OCC = 2, bool ONEPASS = false, bool SH = false,
+          bool QE = false, bool LEAN = false>
 __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a) {
+    static_assert(!LEAN || (CS && SH && !ONEPASS && !STEM && MQW == 1), "lean: chunk-split, shared halo, 4 x 4 tiles");
     extern __shared__ __attribute__((aligned(16))) unsigned char wz_hp_smem[];
     const long long t_entry = WZ_HP_STAMPS ? __builtin_readcyclecounter() : 0;
     constexpr bool LDSW = CS || OCC > 2;                 // depthwise weights staged in LDS (else: registers, from L2)
@@ -110,7 +124,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
 
     // ---- the tile of this wave (CS: of this workgroup); wave-uniform, kept in scalar registers
     const int tiles = a.tiles_x * a.tiles_y;
-    const int wt = CS ? (int)blockIdx.x : (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave);
+    const int ngrp = LEAN ? a.nsplit : 1;                 // workgroups per tile, each with NTO of the n-tiles
+    const int nt0 = LEAN ? ((int)blockIdx.x % ngrp) * NTO : 0;
+    const int wt = LEAN ? (int)blockIdx.x / ngrp : CS ? (int)blockIdx.x : (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave);
     const bool live = wt < tiles * a.nb;                  // wave-uniform; dead waves still take the barrier below
     const int wtc = live ? wt : 0;
     const int b = wtc / tiles, t = wtc - b * tiles;
@@ -239,7 +255,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
     if (ps0 < nk32) load_wa(ps0);
     {   // biases (and, LDSW, depthwise weights) into LDS: every load of a thread in flight before its first store
         constexpr int NT = NW * 64;
-        constexpr int WD_IT = NW >= 8 ? 3 : 8;   // 9 * cmid_pad / 4 float4s over NT threads: at most this many each (checked by the launcher)
+        constexpr int WD_IT = LEAN ? 5 : NW >= 8 ? 3 : 8;   // 9 * cmid_pad / 4 float4s over NT threads: at most this many each (checked by the launcher)
         const int nb4 = a.cmid_pad >> 2;
         float4_t sw[WD_IT], sb, se;
         if constexpr (LDSW) {
@@ -284,12 +300,12 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
         auto load_wp = [&]() {
 #pragma unroll
             for (int nt = 0; nt < NTO; ++nt) {
-                const size_t off = ((size_t)(nt * a.kc + ps) * 64 + lane) * 8;
+                const size_t off = ((size_t)((nt0 + nt) * a.kc + ps) * 64 + lane) * 8;
                 wph[nt] = *reinterpret_cast<const half8_t*>(a.wp + off);
                 wpl[nt] = *reinterpret_cast<const half8_t*>(a.wp_lo + off);
             }
         };
-        constexpr bool WP_LATE = OCC > 2 && CS;   // 3 waves per SIMD: the project fragments are requested behind the expand stage
+        constexpr bool WP_LATE = (OCC > 2 && CS) || LEAN;   // 3 waves per SIMD: the project fragments are requested behind the expand stage
         if constexpr (!WP_LATE) load_wp();        // (they have the depthwise stage to land) instead of holding 8 x NTO registers through it
         float4_t wt0[9], wt1[9];   // (LDSW: unused, the weights are read from LDS where they are needed)
         if constexpr (!LDSW) {
@@ -299,7 +315,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
                 wt1[tp] = *reinterpret_cast<const float4_t*>(wd32 + (size_t)tp * a.cmid_pad + coff + 4);
             }
         }
-        if constexpr (SH) {   // the halo fragments come back from LDS for every pass: they are dead behind the expand stage, which is
+        if constexpr (SH && !LEAN) {   // the halo fragments come back from LDS for every pass: they are dead behind the expand stage, which is
                               // what lets a multi-pass wave fit 168 registers (3 waves per SIMD, 12 per tile)
 #pragma unroll
             for (int i = 0; i < MPW; ++i)
@@ -311,6 +327,53 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
         }
         __builtin_amdgcn_sched_barrier(0);   // (the loads above stay above: they have the whole expand stage to land)
         // ---- expand: E[p][ce] = in-frame ? unorm16(clamp((sum_k X[p][k] We[k][ce] + be[ce]) / 6, 0, 1)) : 0
+        // one 16 x 4 tile of expanded values of a lane -> the chunk buffer (QE: as sqrt)
+        auto put = [&](float4_t d, int i, int nt, bool keep) {
+            if constexpr (QE) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d[r] = __builtin_amdgcn_sqrtf(fmaxf(d[r], 0.0f));
+            }
+            wz_u32x2_t o;
+            o[0] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pknorm_u16(d[0], d[1]));
+            o[1] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pknorm_u16(d[2], d[3]));
+            if (!keep) o[0] = o[1] = 0u;
+            *reinterpret_cast<wz_u32x2_t*>(E + (i * 16 + r16) * ES + nt * 16 + g * 4) = o;
+        };
+        if constexpr (LEAN) {
+            // one pixel tile at a time: its KCI x 2 fragments come from the shared halo, feed both 16-channel tiles (two independent
+            // accumulator chains, issued term by term) and are dead again
+            float4_t bv[2];
+            bool have[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                have[nt] = ce0 + nt * 16 < a.nmid_pad;
+                bv[nt] = *reinterpret_cast<const float4_t*>(be_l + ce0 + nt * 16 + g * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < MPW; ++i) {
+                half8_t fh[KCI], fl[KCI];
+#pragma unroll
+                for (int c = 0; c < KCI; ++c) {
+                    fh[c] = *reinterpret_cast<const half8_t*>(halo_l + (size_t)((i * KCI + c) * 2) * 1024 + lane * 16);
+                    fl[c] = *reinterpret_cast<const half8_t*>(halo_l + (size_t)((i * KCI + c) * 2 + 1) * 1024 + lane * 16);
+                }
+                float4_t d[2] = {bv[0], bv[1]};
+#pragma unroll
+                for (int c = 0; c < KCI; ++c)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) d[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wal[nt][c], fh[c], d[nt], 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < KCI; ++c)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) d[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wah[nt][c], fl[c], d[nt], 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < KCI; ++c)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) d[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wah[nt][c], fh[c], d[nt], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) put(d[nt], i, nt, (interior || inimg[i]) && have[nt]);
+            }
+        } else {
         // per 16-channel tile the MPW pixel tiles are MPW independent accumulator chains: the three terms are issued term by
         // term across them, so that no MFMA waits for the one in front of it
 #pragma unroll
@@ -337,24 +400,12 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
             __builtin_amdgcn_sched_barrier(0);
             if (interior && have) {
 #pragma unroll
-                for (int i = 0; i < MPW; ++i) {
-                    wz_u32x2_t o;
-                    o[0] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pknorm_u16(d[i][0], d[i][1]));
-                    o[1] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pknorm_u16(d[i][2], d[i][3]));
-                    *reinterpret_cast<wz_u32x2_t*>(E + (i * 16 + r16) * ES + nt * 16 + g * 4) = o;
-                }
+                for (int i = 0; i < MPW; ++i) put(d[i], i, nt, true);
             } else {
 #pragma unroll
-                for (int i = 0; i < MPW; ++i) {
-                    const bool keep = inimg[i] && have;
-                    const wz_us2_t p0 = __builtin_amdgcn_cvt_pknorm_u16(d[i][0], d[i][1]);
-                    const wz_us2_t p1 = __builtin_amdgcn_cvt_pknorm_u16(d[i][2], d[i][3]);
-                    wz_u32x2_t o;
-                    o[0] = keep ? __builtin_bit_cast(unsigned int, p0) : 0u;
-                    o[1] = keep ? __builtin_bit_cast(unsigned int, p1) : 0u;
-                    *reinterpret_cast<wz_u32x2_t*>(E + (i * 16 + r16) * ES + nt * 16 + g * 4) = o;
-                }
+                for (int i = 0; i < MPW; ++i) put(d[i], i, nt, inimg[i] && have);
             }
+        }
         }
         if constexpr (WP_LATE) load_wp();
         if constexpr (!ONEPASS)
@@ -400,7 +451,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
                 for (int t = 0; t < RR * 3; ++t) {
                     const int rr = r0 + t / 3, kx = t % 3;
                     wz_f32x2_t x[4];
-                    wz_hp_unpack(tq[t], x);
+                    wz_hp_unpack<QE>(tq[t], x);
                     if (rr < 3) wz_hp_fma8(dd[0], x, W0(rr * 3 + kx), W1(rr * 3 + kx));
                     if (rr > 0) wz_hp_fma8(dd[1], x, W0((rr - 1) * 3 + kx), W1((rr - 1) * 3 + kx));
                 }
@@ -422,7 +473,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
                     for (int t = 0; t < ROWS * 3; ++t) {
                         const int tp = k0 * 3 + t;
                         wz_f32x2_t x[4];
-                        wz_hp_unpack(tq[t], x);
+                        wz_hp_unpack<QE>(tq[t], x);
                         wz_hp_fma8(dd[j], x, W0(tp), W1(tp));
                     }
                 }
@@ -525,7 +576,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
 #pragma unroll
             for (int jj = 0; jj < MQW; ++jj)
                 if (jj == j) op = opix[jj];
-            const int n4 = nt * 16 + g * 4;
+            const int n4 = (nt0 + nt) * 16 + g * 4;
             const bool on = pr < MQW * NTO && op >= 0 && n4 < a.cout;
             sop[k] = on ? op : -1;
             sn4[k] = n4;
@@ -576,26 +627,63 @@ static int wz_hp_env(const char* name, int dflt) {
     return (e && e[0] && atoi(e) >= 0) ? atoi(e) : dflt;
 }
 
-template <int NW, bool CS, bool STEM, int MPW, int MQW, int KCI, int NTO, int OCC = 2, bool ONEPASS = false, bool SH = false>
+template <int NW, bool CS, bool STEM, int MPW, int MQW, int KCI, int NTO, int OCC = 2, bool ONEPASS = false, bool SH = false,
+          bool QE = false, bool LEAN = false>
 static int wz_hp_launch(WzMbArgs a, int n, hipStream_t s, bool prepare) {
     if (ONEPASS && (a.cmid_pad >> 5) > NW) return -1;
+    if (QE != (a.qenc != 0)) return -1;
     a.nb = n;
     if (MQW == 2) { a.th = 4; a.tw = 8; } else { a.th = 4; a.tw = 4; }
     a.tiles_y = (a.hout + a.th - 1) / a.th;
     a.tiles_x = (a.wout + a.tw - 1) / a.tw;
+    a.nsplit = LEAN ? (a.n_pad / 16 + NTO - 1) / NTO : 1;   // lean: workgroups per tile, NTO n-tiles each
+    if (!LEAN && a.n_pad / 16 != NTO) return -1;
+    if (LEAN && a.nsplit * NTO != a.n_pad / 16) return -1;
     constexpr int EB = MPW * 16 * 40 * 2;
     constexpr int RED = CS ? NW * MQW * NTO * 1024 : 0;
     const size_t region = (size_t)(NW * EB > RED ? NW * EB : RED);
     const size_t lds = region + (size_t)a.cmid_pad * ((CS || OCC > 2) ? 8 + 36 : 8) + (SH ? (size_t)MPW * KCI * 2 * 1024 : 0);
-    if ((a.cmid_pad >> 2) > NW * 64 || 9 * (a.cmid_pad >> 2) > (NW >= 8 ? 3 : 8) * NW * 64) return -1;   // the staging code's fixed trip counts
-    auto k = wz_k_mbconv_hp<NW, CS, STEM, MPW, MQW, KCI, NTO, OCC, ONEPASS, SH>;
+    if ((a.cmid_pad >> 2) > NW * 64 || 9 * (a.cmid_pad >> 2) > (LEAN ? 5 : NW >= 8 ? 3 : 8) * NW * 64) return -1;   // the staging code's fixed trip counts
+    auto k = wz_k_mbconv_hp<NW, CS, STEM, MPW, MQW, KCI, NTO, OCC, ONEPASS, SH, QE, LEAN>;
     if (prepare) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return lds <= 160 * 1024 ? 0 : -1;
     }
     const int tiles = a.tiles_x * a.tiles_y * n;
-    WZ_LAUNCH(k, dim3(CS ? tiles : (tiles + 3) / 4), dim3(NW * 64), lds, s, a);
+    WZ_LAUNCH(k, dim3(CS ? tiles * a.nsplit : (tiles + 3) / 4), dim3(NW * 64), lds, s, a);
     return 1;
+}
+
+// The ROBUST program (WzMbArgs::qenc, `python -m watsor_amd.engine --robust`): all 17 blocks on this kernel with the square-root chunk
+// buffer, one launch shape per block shape -- the throughput defaults of the dispatcher below, plus the lean builds for blocks 13 .. 16.
+static int wz_launch_mbconv_hp_q(WzMbArgs a, int n, hipStream_t s, bool prepare) {
+    const int nto = a.n_pad / 16;
+    a.nsplit = 1;
+    if (a.nmid_pad != a.cmid_pad || (a.cmid_pad & 31) || a.kc != (a.cmid_pad >> 5) || !a.we_lo || !a.wp_lo) return -1;
+    if (a.stem) {
+        if (!(a.kc0 == 1 && nto == 2 && a.stride == 1)) return -1;
+        return wz_hp_launch<4, false, true, 4, 2, 1, 2, 3, false, false, true>(a, n, s, prepare);
+    }
+    if (a.cin0 == 0) return -1;
+    if (a.wout > 19 && a.kc0 == 1 && nto == 2) {
+        const int nk32 = a.cmid_pad >> 5;
+        if (a.stride == 2) return wz_hp_launch<4, false, false, 6, 1, 1, 2, 3, false, false, true>(a, n, s, prepare);
+        if (a.wout <= 38 && nk32 >= 4 && nk32 <= 6) return wz_hp_launch<3, true, false, 4, 2, 1, 2, 2, false, true, true>(a, n, s, prepare);
+        return wz_hp_launch<4, false, false, 4, 2, 1, 2, 3, false, false, true>(a, n, s, prepare);
+    }
+    if (a.wout > 10) {
+        if (a.stride == 2) return (a.kc0 == 1 && nto == 4) ? wz_hp_launch<3, true, false, 6, 1, 1, 4, 2, false, true, true>(a, n, s, prepare) : -1;
+        if (a.kc0 == 2 && nto == 4) return wz_hp_launch<4, true, false, 3, 1, 2, 4, 2, false, true, true>(a, n, s, prepare);
+        if (a.kc0 == 2 && nto == 6) return wz_hp_launch<4, true, false, 3, 1, 2, 6, 2, false, true, true>(a, n, s, prepare);
+        if (a.kc0 == 3 && nto == 6) return wz_hp_launch<4, true, false, 3, 1, 3, 6, 2, false, true, true>(a, n, s, prepare);
+        return -1;
+    }
+    // 10x10 maps: lean builds, 8 waves per 4 x 4 tile, 10 n-tiles per workgroup (block 16: two workgroups per tile).  Five n-tiles per
+    // workgroup and twice the workgroups was measured: blocks 14 / 15 18.9 -> 17.2 us alone, block 16 19.1 -> 34.3 us (288 workgroups that
+    // each take a whole CU: two rounds), 46.3 k -> 41.9 k frames/s (profiles/r03_robust_program.txt).
+    if (a.stride == 2) return (a.kc0 == 3 && nto == 10) ? wz_hp_launch<8, true, false, 6, 1, 3, 10, 2, false, true, true, true>(a, n, s, prepare) : -1;
+    if (a.kc0 == 5 && (nto == 10 || nto == 20)) return wz_hp_launch<8, true, false, 3, 1, 5, 10, 2, false, true, true, true>(a, n, s, prepare);
+    return -1;
 }
 
 // Blocks 0 (with the stem) .. 12 of SSD-MobileNet-v2 300x300.  prepare: 0 = a kernel exists (its attributes are set),
@@ -616,6 +704,7 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
     // cmid-384 blocks 6.95 -> 6.76 us, no gain in frames/s; the cmid-576 shape does not fit 168 registers (spills: 16 us) and stays on 8.
     static const int sh = wz_hp_env("WZ_HP_SH", 1);
     static const int w12 = wz_hp_env("WZ_HP_W12", 0);
+    if (a0.qenc) return wz_launch_mbconv_hp_q(a0, n, s, prepare);
     const int nto = a0.n_pad / 16;
     WzMbArgs a = a0;
     a.nsplit = 1;

@@ -118,6 +118,7 @@ struct WzMbArgs {
     const half_t* we_lo;   // "lo" halves of the expand weights (we = "hi")
     const half_t* wp_lo;   // "lo" halves of the project weights
     int32_t hp, hp_out;    // hp: this block runs on the split-operand kernel; hp_out: `out` is a hi + lo pair tensor
+    int32_t qenc;          // split-operand kernel: the chunk buffer holds unorm16 of sqrt(v / 6) (the robust program; wd carries 6 / 65535^2)
 };
 
 // Per-camera filter state resident in HBM (see wz_set_camera_filter).

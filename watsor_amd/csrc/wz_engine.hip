@@ -204,6 +204,7 @@ static WzMbArgs mb_args(wz_engine* e, const Lane& L, const WzOpDesc& op) {
     a.stride = op.stride; a.pad_t = op.pad_t; a.pad_l = op.pad_l;
     a.hp = (op.flags & WZ_OPF_HP) ? 1 : 0;
     a.hp_out = (op.flags & WZ_OPF_HP_OUT) ? 1 : 0;
+    a.qenc = (op.flags & WZ_OPF_QENC) ? 1 : 0;
     if (a.hp) {
         a.we_lo = (const half_t*)(wbase + op.we_lo_off);
         a.wp_lo = (const half_t*)(wbase + op.w_lo_off);
@@ -735,6 +736,10 @@ static int load_blob(wz_engine* e, const char* path) {
         } else if (op.kind == WZ_OP_STEM && h.precision == 32 && (e->tensors[op.src].flags & WZ_TENSOR_HP) &&
                    !(op.dst >= 0 && (e->tensors[op.dst].flags & WZ_TENSOR_HP))) {
             // the fp32 program's stem reads the network input as a hi + lo pair (wz_k_stem_f32)
+        } else if (op.kind == WZ_OP_CONV && (op.flags & WZ_OPF_PAIR_SRC)) {
+            if (h.precision != 16 || !(e->tensors[op.src].flags & WZ_TENSOR_HP) || op.cin != 2 * e->tensors[op.src].c || op.ksize != 1 ||
+                op.res >= 0 || (op.dst >= 0 && (e->tensors[op.dst].flags & WZ_TENSOR_HP)))
+                return wz_fail(WZ_EFORMAT, "%s: op %u (%s): malformed convolution over a pair tensor", path, i, op.name);
         } else if ((e->tensors[op.src].flags & WZ_TENSOR_HP) || (op.dst >= 0 && (e->tensors[op.dst].flags & WZ_TENSOR_HP)) ||
                    (op.res >= 0 && (e->tensors[op.res].flags & WZ_TENSOR_HP))) {
             return wz_fail(WZ_EFORMAT, "%s: op %u (%s) touches a pair tensor but is not a split-operand block", path, i, op.name);
