@@ -104,7 +104,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
     constexpr bool PRE = OCC <= 2;                       // all taps of an output requested before the first is used
     constexpr int ES = 40;                               // unorm16 per row of the chunk buffer: 32 channels + 8 of padding
     constexpr int EBYTES = MPW * 16 * ES * 2;
-    constexpr int RED_BYTES = CS ? NW * MQW * NTO * 1024 : 0;
+    constexpr int RROUNDS = (LEAN && OCC >= 4 && NTO % 2 == 0 && NTO >= 6) ? 2 : 1;   // rounds of the accumulators' trip through LDS
+    constexpr int RED_BYTES = CS ? NW * MQW * (NTO / RROUNDS) * 1024 : 0;
     constexpr int REGION = (NW * EBYTES > RED_BYTES) ? NW * EBYTES : RED_BYTES;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
@@ -252,7 +253,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
             }
         }
     };
-    if (ps0 < nk32) load_wa(ps0);
+    constexpr bool WA_AHEAD = !(LEAN && OCC >= 4);   // the next pass's expand fragments requested a stage ahead (4 waves per SIMD: at the
+                                                     // top of the pass instead -- the other waves cover the wait, the registers are not there)
+    if (WA_AHEAD && ps0 < nk32) load_wa(ps0);
     {   // biases (and, LDSW, depthwise weights) into LDS: every load of a thread in flight before its first store
         constexpr int NT = NW * 64;
         constexpr int WD_IT = LEAN ? 5 : NW >= 8 ? 3 : 8;   // 9 * cmid_pad / 4 float4s over NT threads: at most this many each (checked by the launcher)
@@ -307,6 +310,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
         };
         constexpr bool WP_LATE = (OCC > 2 && CS) || LEAN;   // 3 waves per SIMD: the project fragments are requested behind the expand stage
         if constexpr (!WP_LATE) load_wp();        // (they have the depthwise stage to land) instead of holding 8 x NTO registers through it
+        if constexpr (!WA_AHEAD) load_wa(ps);
         float4_t wt0[9], wt1[9];   // (LDSW: unused, the weights are read from LDS where they are needed)
         if constexpr (!LDSW) {
 #pragma unroll
@@ -408,7 +412,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
         }
         }
         if constexpr (WP_LATE) load_wp();
-        if constexpr (!ONEPASS)
+        if constexpr (!ONEPASS && WA_AHEAD)
             if (ps + STEP < nk32) load_wa(ps + STEP);   // next pass's expand fragments, in flight under the depthwise stage
         // the wave's own LDS writes are ordered before its reads by the LDS queue; keep the compiler from moving the reads up
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -562,6 +566,40 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
                 finish(acc[j][nt], sd[j][nt], opix[j], n4);
             }
         }
+    } else if constexpr (RROUNDS > 1) {
+        // lean builds at 4 waves per SIMD: the accumulators cross LDS in RROUNDS rounds of NTO / RROUNDS n-tiles, so that the area they
+        // need (NW KiB per n-tile) stays under the chunk buffers and two workgroups fit the LDS of a CU; n-tile t of a round is
+        // summed by wave t, in the order wave 0 .. NW - 1 as everywhere
+        constexpr int NH = NTO / RROUNDS;
+        static_assert(NTO % RROUNDS == 0 && NH <= NW && MQW == 1, "rounds of the lean reduction");
+        Side sd[RROUNDS];
+        const bool fin_wave = wave < NH;
+#pragma unroll
+        for (int r = 0; r < RROUNDS; ++r) {
+            const int n4 = (nt0 + r * NH + (fin_wave ? wave : 0)) * 16 + g * 4;
+            const bool on = fin_wave && opix[0] >= 0 && n4 < a.cout;
+            sd[r] = side(on ? opix[0] : 0, on ? n4 : 0);
+        }
+        float* const red = reinterpret_cast<float*>(wz_hp_smem);
+#pragma unroll
+        for (int r = 0; r < RROUNDS; ++r) {
+            __syncthreads();   // every wave is done with its chunk buffer / with the previous round's partials
+#pragma unroll
+            for (int t = 0; t < NH; ++t)
+                *reinterpret_cast<float4_t*>(red + ((size_t)(wave * NH + t) * 64 + lane) * 4) = acc[0][r * NH + t];
+            __syncthreads();
+            if (fin_wave) {
+                float4_t v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    const float4_t pz = *reinterpret_cast<const float4_t*>(red + ((size_t)(w * NH + wave) * 64 + lane) * 4);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] += pz[q];
+                }
+                const int n4 = (nt0 + r * NH + wave) * 16 + g * 4;
+                if (opix[0] >= 0 && n4 < a.cout) finish(v, sd[r], opix[0], n4);
+            }
+        }
     } else {
         // the 8 waves' accumulators meet in LDS (over the chunk buffers); tile (j, nt) is summed by wave
         // (j*NTO + nt) % 8 in the order wave 0 .. 7 (deterministic)
@@ -640,7 +678,7 @@ static int wz_hp_launch(WzMbArgs a, int n, hipStream_t s, bool prepare) {
     if (!LEAN && a.n_pad / 16 != NTO) return -1;
     if (LEAN && a.nsplit * NTO != a.n_pad / 16) return -1;
     constexpr int EB = MPW * 16 * 40 * 2;
-    constexpr int RED = CS ? NW * MQW * NTO * 1024 : 0;
+    constexpr int RED = CS ? NW * MQW * (NTO / ((LEAN && OCC >= 4 && NTO % 2 == 0 && NTO >= 6) ? 2 : 1)) * 1024 : 0;
     const size_t region = (size_t)(NW * EB > RED ? NW * EB : RED);
     const size_t lds = region + (size_t)a.cmid_pad * ((CS || OCC > 2) ? 8 + 36 : 8) + (SH ? (size_t)MPW * KCI * 2 * 1024 : 0);
     if ((a.cmid_pad >> 2) > NW * 64 || 9 * (a.cmid_pad >> 2) > (LEAN ? 5 : NW >= 8 ? 3 : 8) * NW * 64) return -1;   // the staging code's fixed trip counts
@@ -747,6 +785,8 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
                 (void)wz_hp_launch<2, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, true);
                 (void)wz_hp_launch<3, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, true);
                 (void)wz_hp_launch<4, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, true);
+                (void)wz_hp_launch<5, true, false, 4, 2, 1, 2, 4, false, true>(a, n, s, true);
+                (void)wz_hp_launch<6, true, false, 4, 2, 1, 2, 4, false, true>(a, n, s, true);
                 (void)wz_hp_launch<5, true, false, 4, 2, 1, 2>(a, n, s, true);
                 (void)wz_hp_launch<6, true, false, 4, 2, 1, 2>(a, n, s, true);
                 (void)wz_hp_launch<5, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, true);
@@ -756,10 +796,15 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
                 return wz_hp_launch<4, false, false, 4, 2, 1, 2>(a, n, s, true);
             }
             static const int cs75_nw = wz_hp_env("WZ_HP_CS75_NW", 0);   // the 75x75 stride-1 block: 2 / 3 waves per tile (0: one wave per tile)
+            static const int cs_occ4 = wz_hp_env("WZ_HP_CS_OCC4", 1);   // chunk-split stride-1 tiles: one chunk per wave at 128 registers (4 waves per SIMD)
             if (!prepare && sh && a.wout > 38 && a.wout <= 75 && nk32 >= 4 && nk32 <= 6) {
                 if (cs75_nw == 2) return wz_hp_launch<2, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, false);
                 if (cs75_nw == 3) return wz_hp_launch<3, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, false);
+                if (cs75_nw == 5 && nk32 <= 5) return wz_hp_launch<5, true, false, 4, 2, 1, 2, 4, false, true>(a, n, s, false);
             }
+            if (!prepare && cs && sh && cs_occ4 && a.wout <= 38)
+                return nk32 <= 5 ? wz_hp_launch<5, true, false, 4, 2, 1, 2, 4, false, true>(a, n, s, false)
+                                 : wz_hp_launch<6, true, false, 4, 2, 1, 2, 4, false, true>(a, n, s, false);
             if (cs && sh && cs_nw == 2) return wz_hp_launch<2, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, false);
             if (cs && sh && cs_nw == 3) return wz_hp_launch<3, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, false);
             if (cs && sh && cs_nw == 4) return wz_hp_launch<4, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, false);
@@ -795,11 +840,14 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
         if (a.kc0 == 1 && nto == 4) {
             static const int cs6_nw = wz_hp_env("WZ_HP_CS6_NW", wz_latency_schedule() ? 8 : 3);   // waves per tile of the 38x38 -> 19x19 block (6 chunks): 3 with two chunks
                                                                       // each (49.8 k -> 50.5 k frames/s; 8: two waves idle, a CU per workgroup)
+            static const int cs6_lean4 = wz_hp_env("WZ_HP_CS6_LEAN4", 1);   // six waves (one chunk each) at 128 registers
             if (prepare) {
+                (void)wz_hp_launch<6, true, false, 6, 1, 1, 4, 4, false, true, false, true>(a, n, s, true);
                 (void)wz_hp_launch<HP_CS_WAVES, true, false, 6, 1, 1, 4, 2, false, true>(a, n, s, true);
                 (void)wz_hp_launch<3, true, false, 6, 1, 1, 4, 2, false, true>(a, n, s, true);
                 (void)wz_hp_launch<6, true, false, 6, 1, 1, 4, 2, false, true>(a, n, s, true);
             }
+            if (sh && !prepare && cs6_lean4) return wz_hp_launch<6, true, false, 6, 1, 1, 4, 4, false, true, false, true>(a, n, s, false);
             if (sh && !prepare && cs6_nw == 3) return wz_hp_launch<3, true, false, 6, 1, 1, 4, 2, false, true>(a, n, s, false);
             if (sh && !prepare && cs6_nw == 6) return wz_hp_launch<6, true, false, 6, 1, 1, 4, 2, false, true>(a, n, s, false);
             if (sh && !prepare) return wz_hp_launch<HP_CS_WAVES, true, false, 6, 1, 1, 4, 2, false, true>(a, n, s, false);
@@ -826,9 +874,13 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
     // flight.  3 waves: 48.2 k; 5: 45.8 k; 6: 46.8 k (workgroups that neither fill a CU nor leave room for a second one);
     // WZ_HP_CS19_NW=8 is the lowest-latency setting (p50 0.372 against 0.380 ms).  profiles/r03_wave_counts_*.
     static const int cs19_nw = wz_hp_env("WZ_HP_CS19_NW", wz_latency_schedule() ? 8 : 4);
+    // WZ_HP_CS19_LEAN4=1: EIGHT waves per tile at 128 registers (4 per SIMD; halo fragments per pixel tile, no weight prefetch): as
+    // many waves as the lowest-latency setting, the CU footprint of the four-wave one
+    static const int cs19_lean4 = wz_hp_env("WZ_HP_CS19_LEAN4", 1);
 #define HP_CASE(K, N)                                                                                         \
     if (a.kc0 == K && nto == N) {                                                                             \
         if (prepare) {                                                                                        \
+            (void)wz_hp_launch<8, true, false, 3, 1, K, N, 4, false, true, false, true>(a, n, s, true);      \
             (void)wz_hp_launch<3, true, false, 3, 1, K, N, 2, false, true>(a, n, s, true);                   \
             (void)wz_hp_launch<4, true, false, 3, 1, K, N, 2, false, true>(a, n, s, true);                   \
             (void)wz_hp_launch<5, true, false, 3, 1, K, N, 2, false, true>(a, n, s, true);                   \
@@ -837,6 +889,7 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
             if (K == 2) (void)wz_hp_launch<12, true, false, 3, 1, 2, N, 3, false, true>(a, n, s, true);      \
             return wz_hp_launch<HP_CS_WAVES, true, false, 3, 1, K, N>(a, n, s, true);                        \
         }                                                                                                     \
+        if (sh && cs19_lean4) { const int r = wz_hp_launch<8, true, false, 3, 1, K, N, 4, false, true, false, true>(a, n, s, false); if (r >= 0) return r; } \
         if (sh && cs19_nw == 3) { const int r = wz_hp_launch<3, true, false, 3, 1, K, N, 2, false, true>(a, n, s, false); if (r >= 0) return r; } \
         if (sh && cs19_nw == 5) { const int r = wz_hp_launch<5, true, false, 3, 1, K, N, 2, false, true>(a, n, s, false); if (r >= 0) return r; } \
         if (sh && cs19_nw == 4) { const int r = wz_hp_launch<4, true, false, 3, 1, K, N, 2, false, true>(a, n, s, false); if (r >= 0) return r; } \
