@@ -706,14 +706,15 @@ static int wz_launch_mbconv_hp_q(WzMbArgs a, int n, hipStream_t s, bool prepare)
     if (a.wout > 19 && a.kc0 == 1 && nto == 2) {
         const int nk32 = a.cmid_pad >> 5;
         if (a.stride == 2) return wz_hp_launch<4, false, false, 6, 1, 1, 2, 3, false, false, true>(a, n, s, prepare);
-        if (a.wout <= 38 && nk32 >= 4 && nk32 <= 6) return wz_hp_launch<3, true, false, 4, 2, 1, 2, 2, false, true, true>(a, n, s, prepare);
+        if (a.wout <= 38 && nk32 == 6) return wz_hp_launch<6, true, false, 4, 2, 1, 2, 4, false, true, true>(a, n, s, prepare);
+        if (a.wout <= 38 && nk32 >= 4 && nk32 <= 5) return wz_hp_launch<3, true, false, 4, 2, 1, 2, 2, false, true, true>(a, n, s, prepare);
         return wz_hp_launch<4, false, false, 4, 2, 1, 2, 3, false, false, true>(a, n, s, prepare);
     }
     if (a.wout > 10) {
-        if (a.stride == 2) return (a.kc0 == 1 && nto == 4) ? wz_hp_launch<3, true, false, 6, 1, 1, 4, 2, false, true, true>(a, n, s, prepare) : -1;
-        if (a.kc0 == 2 && nto == 4) return wz_hp_launch<4, true, false, 3, 1, 2, 4, 2, false, true, true>(a, n, s, prepare);
-        if (a.kc0 == 2 && nto == 6) return wz_hp_launch<4, true, false, 3, 1, 2, 6, 2, false, true, true>(a, n, s, prepare);
-        if (a.kc0 == 3 && nto == 6) return wz_hp_launch<4, true, false, 3, 1, 3, 6, 2, false, true, true>(a, n, s, prepare);
+        if (a.stride == 2) return (a.kc0 == 1 && nto == 4) ? wz_hp_launch<6, true, false, 6, 1, 1, 4, 4, false, true, true, true>(a, n, s, prepare) : -1;
+        if (a.kc0 == 2 && nto == 4) return wz_hp_launch<8, true, false, 3, 1, 2, 4, 4, false, true, true, true>(a, n, s, prepare);
+        if (a.kc0 == 2 && nto == 6) return wz_hp_launch<8, true, false, 3, 1, 2, 6, 4, false, true, true, true>(a, n, s, prepare);
+        if (a.kc0 == 3 && nto == 6) return wz_hp_launch<8, true, false, 3, 1, 3, 6, 4, false, true, true, true>(a, n, s, prepare);
         return -1;
     }
     // 10x10 maps: lean builds, 8 waves per 4 x 4 tile, 10 n-tiles per workgroup (block 16: two workgroups per tile).  Five n-tiles per
