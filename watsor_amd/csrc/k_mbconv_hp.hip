@@ -875,8 +875,10 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
     // flight.  3 waves: 48.2 k; 5: 45.8 k; 6: 46.8 k (workgroups that neither fill a CU nor leave room for a second one);
     // WZ_HP_CS19_NW=8 is the lowest-latency setting (p50 0.372 against 0.380 ms).  profiles/r03_wave_counts_*.
     static const int cs19_nw = wz_hp_env("WZ_HP_CS19_NW", wz_latency_schedule() ? 8 : 4);
-    // WZ_HP_CS19_LEAN4=1: EIGHT waves per tile at 128 registers (4 per SIMD; halo fragments per pixel tile, no weight prefetch): as
-    // many waves as the lowest-latency setting, the CU footprint of the four-wave one
+    // WZ_HP_CS19_LEAN4=1 (default, later in round 3): EIGHT waves per tile at 128 registers (4 per SIMD; halo fragments per pixel tile, no
+    // weight prefetch, accumulators through LDS in two rounds): as many waves as the lowest-latency setting, the CU footprint of the
+    // four-wave one -- 6.7 / 5.9 / 6.2 / 7.7 / 11.7 / 10.3 -> 5.7 / 5.0 / 5.2 / 6.3 / 10.1 / 9.0 us, 52.1 -> 52.5 k frames/s, p50 0.399 ->
+    // 0.386 ms (profiles/r03_four_waves_per_simd.txt).  0: the wave counts below.
     static const int cs19_lean4 = wz_hp_env("WZ_HP_CS19_LEAN4", 1);
 #define HP_CASE(K, N)                                                                                         \
     if (a.kc0 == K && nto == N) {                                                                             \
