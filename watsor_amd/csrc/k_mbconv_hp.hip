@@ -821,6 +821,7 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
         static const int cs2_nw = wz_hp_env("WZ_HP_CS2_NW", 0);   // stride-2 blocks on maps up to WZ_HP_CS2_MAX_W: that many waves per tile
         static const int cs2_max_w = wz_hp_env("WZ_HP_CS2_MAX_W", 0);
         if (prepare) {
+            (void)wz_hp_launch<2, true, false, 6, 1, 1, 2, 2, false, true>(a, n, s, true);
             (void)wz_hp_launch<3, true, false, 6, 1, 1, 2, 2, false, true>(a, n, s, true);
             (void)wz_hp_launch<5, true, false, 6, 1, 1, 2>(a, n, s, true);
             (void)wz_hp_launch<5, true, false, 6, 1, 1, 2, 2, false, true>(a, n, s, true);
@@ -830,6 +831,8 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
         }
         if (sh && cs2_nw == 3 && a.wout <= cs2_max_w && nk32 >= 4 && nk32 <= 6)
             return wz_hp_launch<3, true, false, 6, 1, 1, 2, 2, false, true>(a, n, s, false);
+        if (sh && cs2_nw == 2 && a.wout <= cs2_max_w && nk32 >= 3 && nk32 <= 6)
+            return wz_hp_launch<2, true, false, 6, 1, 1, 2, 2, false, true>(a, n, s, false);
         if (cs && sh && nk32 <= 5) return wz_hp_launch<5, true, false, 6, 1, 1, 2, 2, false, true>(a, n, s, false);
         if (cs && nk32 <= 5) return wz_hp_launch<5, true, false, 6, 1, 1, 2>(a, n, s, false);
         if (occ == 3) return wz_hp_launch<4, false, false, 6, 1, 1, 2, 3>(a, n, s, false);
