@@ -705,7 +705,7 @@ def robust_engine_leg(weights, frames, rank):
             try:
                 dfr = [eng.upload(f) for f in frames[:BATCH]]
                 if name == "headline":
-                    r = throughput(eng, lambda lane, s: eng.submit_device(lane, dfr, [WIDTH] * BATCH, [HEIGHT] * BATCH), BATCH)
+                    r = throughput(eng, lambda lane, s: eng.submit_device(lane, dfr, [WIDTH] * BATCH, [HEIGHT] * BATCH), BATCH, steps=600, warm=60)
                 par = parity_leg(eng, frames, dfr, w)
             finally:
                 eng.close()
