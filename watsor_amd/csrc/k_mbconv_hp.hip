@@ -253,7 +253,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
             }
         }
     };
-    constexpr bool WA_AHEAD = !(LEAN && OCC >= 4);   // the next pass's expand fragments requested a stage ahead (4 waves per SIMD: at the
+    constexpr bool WA_AHEAD = !((LEAN || !CS) && OCC >= 4);   // the next pass's expand fragments requested a stage ahead (4 waves per SIMD: at the
                                                      // top of the pass instead -- the other waves cover the wait, the registers are not there)
     if (WA_AHEAD && ps0 < nk32) load_wa(ps0);
     {   // biases (and, LDSW, depthwise weights) into LDS: every load of a thread in flight before its first store
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
                 wpl[nt] = *reinterpret_cast<const half8_t*>(a.wp_lo + off);
             }
         };
-        constexpr bool WP_LATE = (OCC > 2 && CS) || LEAN;   // 3 waves per SIMD: the project fragments are requested behind the expand stage
+        constexpr bool WP_LATE = (OCC > 2 && CS) || LEAN || OCC >= 4;   // 3 waves per SIMD: the project fragments are requested behind the expand stage
         if constexpr (!WP_LATE) load_wp();        // (they have the depthwise stage to land) instead of holding 8 x NTO registers through it
         if constexpr (!WA_AHEAD) load_wa(ps);
         float4_t wt0[9], wt1[9];   // (LDSW: unused, the weights are read from LDS where they are needed)
