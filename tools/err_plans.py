@@ -152,3 +152,31 @@ PLANS["r_conv1_s"] = hp_rest(16, conv1=S)
 PLANS["r_conv1_extras_s"] = hp_rest(16, conv1=S, extras=S)
 PLANS["r_heads_s"] = hp_rest(16, heads=S)
 PLANS["r_e13h"] = hp_rest(16, e13_out="h")
+
+
+def hp_tail_terms(first=13, exp_in="h", pro_in="h", exp_w="s", pro_w="s"):
+    """hp(16, 'q') with the MFMA inputs / weights of blocks first .. 16 chosen separately: which of the three MFMA terms of the robust
+    program's late blocks are worth their time."""
+    front = hp(16, dw_in="q")
+
+    def plan(spec, groups):
+        cfg = front(spec, groups)
+        for lab, names in groups.items():
+            i = _idx(lab)
+            if i is None or i < first:
+                continue
+            for nm in names:
+                kind = lab[4:]
+                if kind == "exp":
+                    cfg[nm] = (exp_w, exp_in, cfg[nm][2])
+                elif kind == "pro":
+                    cfg[nm] = (pro_w, pro_in, cfg[nm][2])
+        return cfg
+    return plan
+
+
+PLANS["rt_in_h"] = hp_tail_terms()                                   # both GEMMs of blocks 13..16: activations hi only (2 terms)
+PLANS["rt_exp_in_h"] = hp_tail_terms(pro_in="s")                     # only the expand GEMM's input hi only
+PLANS["rt_pro_in_h"] = hp_tail_terms(exp_in="s")                     # only the project GEMM's input hi only
+PLANS["rt_w_h"] = hp_tail_terms(exp_in="s", pro_in="s", exp_w="h", pro_w="h")   # weights hi only
+PLANS["rt_in_h_from7"] = hp_tail_terms(first=7)
