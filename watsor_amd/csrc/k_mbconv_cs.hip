@@ -47,8 +47,11 @@ __global__ __launch_bounds__(CS_WAVES * 64) void wz_k_mbconv_cs(const WzMbArgs a
     }
 
     // ---- the workgroup's tile
+    // (a.nsplit > 1: that many workgroups per tile, each with NTO of the block's output tiles -- block 16; the expand and depthwise
+    //  stages are repeated per group, which costs nothing on a launch of 72 tiles and spares the fp32 partial sums in HBM)
     const int tiles = a.tiles_x * a.tiles_y;
-    const int b = blockIdx.x / tiles, t = blockIdx.x - b * tiles;
+    const int bid = (int)blockIdx.x / a.nsplit, nt0 = ((int)blockIdx.x % a.nsplit) * NTO;
+    const int b = bid / tiles, t = bid - b * tiles;
     const int tyi = t / a.tiles_x;
     const int oy0 = tyi * a.th, ox0 = (t - tyi * a.tiles_x) * a.tw;
     const int s = a.stride;
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(CS_WAVES * 64) void wz_k_mbconv_cs(const WzMbArgs a
                 for (int r = 0; r < 8; ++r) bf[r] = (half_t)fminf(fmaxf(d[r], 0.0f), 6.0f);
 #pragma unroll
                 for (int nt = 0; nt < NTO; ++nt) {
-                    const half8_t wp = *reinterpret_cast<const half8_t*>(a.wp + ((size_t)(nt * a.kc + ps) * 64 + lane) * 8);
+                    const half8_t wp = *reinterpret_cast<const half8_t*>(a.wp + ((size_t)((nt0 + nt) * a.kc + ps) * 64 + lane) * 8);
                     acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wp, bf, acc[j][nt], 0, 0, 0);
                 }
             }
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(CS_WAVES * 64) void wz_k_mbconv_cs(const WzMbArgs a
 #pragma unroll
             for (int jj = 0; jj < MQW; ++jj)
                 if (jj == j) op = opix[jj];
-            const int n4 = nt * 16 + g * 4;
+            const int n4 = (nt0 + nt) * 16 + g * 4;
             if (op < 0 || n4 >= a.cout) continue;
             const float4_t bv = *reinterpret_cast<const float4_t*>(a.bp + n4);
 #pragma unroll
@@ -262,7 +265,7 @@ static int wz_cs_launch(WzMbArgs a, int n, hipStream_t s, bool prepare) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return lds <= 160 * 1024 ? 0 : -1;
     }
-    WZ_LAUNCH(k, dim3(a.tiles_x * a.tiles_y * n), dim3(CS_WAVES * 64), lds, s, a);
+    WZ_LAUNCH(k, dim3(a.tiles_x * a.tiles_y * n * a.nsplit), dim3(CS_WAVES * 64), lds, s, a);
     return 1;
 }
 
@@ -281,7 +284,12 @@ int wz_launch_mbconv_cs(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
     // ... except block 16 (320 output channels, 0.9 MB of weights per workgroup: 31 us alone against 9 + 4): it stays on the channel-group
     // kernel -- 50.0 k frames/s either way, p50 0.380 instead of 0.395 ms (WZ_MB_CS_MAX_NTO=20: on this kernel as well)
     static const int max_nto = wz_cs_env("WZ_MB_CS_MAX_NTO", 10);   // blocks with more output tiles than this stay on the channel-group kernel
-    if (!prepare && nto > max_nto) return -2;
+    // ... until late round 3: block 16 runs on this kernel as TWO workgroups per tile with 10 output tiles each (WZ_MB_CS_SPLIT16, default 1;
+    // the expand and depthwise stages are done twice -- on 72 tiles that costs nothing): 15.8 + 2.8 us and a kernel boundary -> 12.7 us,
+    // no fp32 partial sums of any block in HBM any more, 31 graph nodes; 51.8 k -> 52.8 k frames/s, p50 0.383 -> 0.376 ms
+    // (profiles/r03_four_waves_per_simd.txt (e)).  0: the channel-group kernel + reduce as before.
+    static const int split16 = wz_cs_env("WZ_MB_CS_SPLIT16", wz_latency_schedule() ? 0 : 1);
+    if (!prepare && nto > max_nto && !(split16 == 1 && nto == 20 && a0.kc0 == 5 && a0.stride == 1)) return -2;
     WzMbArgs a = a0;
     a.nsplit = 1;
     a.th = 4; a.tw = 4;
@@ -310,6 +318,10 @@ int wz_launch_mbconv_cs(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
         if (!prepare && nw10 == 4) return wz_cs_launch<true, 3, 1, 5, 10, 4>(a, n, s, false);
     }
     CS_CASE(5, 10);
+    if (!prepare && split16 == 1 && a.kc0 == 5 && nto == 20) {
+        a.nsplit = 2;
+        return wz_cs_launch<true, 3, 1, 5, 10>(a, n, s, false);
+    }
     CS_CASE(5, 20);
 #undef CS_CASE
     return -2;
