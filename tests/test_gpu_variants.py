@@ -183,3 +183,47 @@ def test_latency_schedule_detects_the_same_objects(model_dir, tmp_path):
         n_ref = int((ref["confidence"] > 0.1).sum())
         assert n_ref > 50 and len(missing) <= max(1, n_ref // 20)
         assert max(abs(p[3]) for p in pairs) <= 5e-4
+
+
+@pytest.mark.parametrize("knobs", [
+    dict(WZ_MB_CS_SPLIT16="0"),                                                     # block 16 on the channel-group kernel + reduce launch
+    dict(WZ_HP_CS19_LEAN4="0", WZ_HP_CS_OCC4="0", WZ_HP_CS6_LEAN4="0"),             # the 256-register builds of the chunk-split blocks
+    dict(WZ_HP_CS19_LEAN4="0", WZ_HP_CS19_NW="8", WZ_MB_CS_MIN_W="11"),             # round 2's shapes
+])
+def test_earlier_launch_shapes_detect_the_same_objects(model_dir, knobs):
+    """The launch shapes of the split blocks and of blocks 13 .. 16 changed several times this round (DESIGN.md section 5): every one of
+    them is the same network summed in another order.  A child process on the development library with the earlier shapes selected
+    reports more graph nodes where a reduce launch comes back, and rows that agree with the default's to rounding."""
+    import json
+    import os
+    import subprocess
+    import sys
+    script = (
+        "import sys, json, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from watsor_amd.runtime import HipEngine, ROW_DTYPE\n"
+        "from watsor_amd.synth import synthetic_frame\n"
+        "e = HipEngine(%r, 0, 8, 640, 480, dev=True)\n"
+        "frames = [synthetic_frame(640, 480, 8900 + i) for i in range(5)]\n"
+        "rows = [np.zeros(100, ROW_DTYPE) for _ in frames]\n"
+        "e.detect_batch(frames, rows)\n"
+        "print(json.dumps(dict(nodes=e.graph_nodes(0), label=[r['label'].tolist() for r in rows], conf=[r['confidence'].tolist() for r in rows],"
+        " box=[np.stack([r['x_min'], r['y_min'], r['x_max'], r['y_max']], 1).tolist() for r in rows])))\n"
+        "e.close()\n" % (conftest.ROOT, os.path.join(model_dir, "mi355x.bin")))
+    out = {}
+    for name, env in (("default", {}), ("earlier", knobs)):
+        p = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, **env), capture_output=True, text=True, timeout=240)
+        assert p.returncode == 0, p.stderr[-1500:]
+        out[name] = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    a, b = out["default"], out["earlier"]
+    assert b["nodes"] >= a["nodes"] and (b["nodes"] > a["nodes"]) == ("WZ_MB_CS_SPLIT16" in knobs or "WZ_MB_CS_MIN_W" in knobs)
+    for f in range(5):
+        ref = dict(label=np.array(a["label"][f], np.int32), confidence=np.array(a["conf"][f]), box=np.array(a["box"][f], np.int32))
+        got = np.zeros(100, ROW_DTYPE)
+        got["label"], got["confidence"] = b["label"][f], b["conf"][f]
+        bx = np.array(b["box"][f], np.int32)
+        got["x_min"], got["y_min"], got["x_max"], got["y_max"] = bx[:, 0], bx[:, 1], bx[:, 2], bx[:, 3]
+        pairs, missing = pu.match_rows(got, ref, min_score=0.1)
+        n_ref = int((ref["confidence"] > 0.1).sum())
+        assert n_ref > 50 and len(missing) <= max(1, n_ref // 20)
+        assert max(abs(p[3]) for p in pairs) <= 5e-4

@@ -288,7 +288,10 @@ int wz_launch_mbconv_cs(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
     // the expand and depthwise stages are done twice -- on 72 tiles that costs nothing): 15.8 + 2.8 us and a kernel boundary -> 12.7 us,
     // no fp32 partial sums of any block in HBM any more, 31 graph nodes; 51.8 k -> 52.8 k frames/s, p50 0.383 -> 0.376 ms
     // (profiles/r03_four_waves_per_simd.txt (e)).  0: the channel-group kernel + reduce as before.
-    static const int split16 = wz_cs_env("WZ_MB_CS_SPLIT16", wz_latency_schedule() ? 0 : 1);
+    static const int split16 = [] {
+        const char* e = wz_dev_getenv("WZ_MB_CS_SPLIT16");   // (0 is a value here, unlike with wz_cs_env)
+        return (e && e[0]) ? atoi(e) : (wz_latency_schedule() ? 0 : 1);
+    }();
     if (!prepare && nto > max_nto && !(split16 == 1 && nto == 20 && a0.kc0 == 5 && a0.stride == 1)) return -2;
     WzMbArgs a = a0;
     a.nsplit = 1;
