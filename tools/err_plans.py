@@ -180,3 +180,23 @@ PLANS["rt_exp_in_h"] = hp_tail_terms(pro_in="s")                     # only the 
 PLANS["rt_pro_in_h"] = hp_tail_terms(exp_in="s")                     # only the project GEMM's input hi only
 PLANS["rt_w_h"] = hp_tail_terms(exp_in="s", pro_in="s", exp_w="h", pro_w="h")   # weights hi only
 PLANS["rt_in_h_from7"] = hp_tail_terms(first=7)
+
+
+def hp_mixed_buffer(first_q):
+    """hp(16): linear unorm16 chunk buffer in blocks 0 .. first_q - 1, square-root buffer from block first_q on (the square roots cost most
+    on the large maps)."""
+    lin, sq = hp(16, dw_in="u"), hp(16, dw_in="q")
+
+    def plan(spec, groups):
+        a, b = lin(spec, groups), sq(spec, groups)
+        cfg = {}
+        for lab, names in groups.items():
+            i = _idx(lab)
+            for nm in names:
+                cfg[nm] = a[nm] if (i is not None and i < first_q) else b[nm]
+        return cfg
+    return plan
+
+
+for n in (1, 2, 4, 7):
+    PLANS["mixq%d" % n] = hp_mixed_buffer(n)
