@@ -49,7 +49,7 @@ def parse(blob):
         d = dict(zip(keys, o[:20]))
         d.update(w_off=o[20], b_off=o[21], n_box=o[22], cmid=o[23], cin0=o[24], kc0=o[25], cmid_pad=o[26],
                  nmid_pad=o[27], stem=o[28], stem_pad=o[29], we_off=o[30], be_off=o[31], wd_off=o[32], bd_off=o[33],
-                 we_lo_off=o[34], w_lo_off=o[35], flags=o[36], name=o[38].split(b"\0")[0].decode())
+                 we_lo_off=o[34], w_lo_off=o[35], flags=o[36], dst2=o[37], name=o[38].split(b"\0")[0].decode())
         ops.append(d)
     return hdr, tensors, ops
 
@@ -170,7 +170,7 @@ def test_stem_folded_into_the_first_block(default_blob, fused_blob, synth_weight
     """Default program: op 0 reads the 300x300x4 input, its expand stage is the stem conv as a K = 27 (-> 32) GEMM."""
     hdr, tensors, ops = parse(default_blob)
     _, _, fops = parse(fused_blob)
-    assert hdr["n_ops"] == 33 and "Conv" not in {t["name"] for t in tensors}
+    assert hdr["n_ops"] == 32 and "Conv" not in {t["name"] for t in tensors}
     o, blk0 = ops[0], fops[1]
     assert o["kind"] == arch.OP_MBCONV and o["stem"] == 1 and o["stem_pad"] == 0 and tensors[o["src"]]["name"] == "input"
     assert (o["cin0"], o["kc0"], o["nmid_pad"], o["cmid"], o["hin"], o["hout"], o["stride"]) == (32, 1, 32, 32, 150, 150, 1)
@@ -182,8 +182,38 @@ def test_stem_folded_into_the_first_block(default_blob, fused_blob, synth_weight
     np.testing.assert_array_equal(w[0, :27, :], ref)
     assert not w[0, 27:, :].any()
     np.testing.assert_array_equal(np.frombuffer(default_blob, np.float32, 32, hdr["weights_off"] + o["be_off"]), bf.astype(np.float32))
-    for a, b in zip(ops[1:], fops[2:]):                                        # everything behind it is unchanged
+    rest = [b for b in fops[2:] if not b["name"].endswith("expanded_conv_13/expand")]   # (block 13's expand conv: next test)
+    assert len(rest) == len(ops) - 1 == len(fops) - 3
+    for a, b in zip(ops[1:], rest):                                            # everything behind it is unchanged
         assert (a["kind"], a["name"], a["cin"], a["cout"]) == (b["kind"], b["name"], b["cin"], b["cout"])
+
+
+def test_block_13_stores_the_first_feature_map_itself(default_blob, hp_blob, fused_blob, synth_weights):
+    """Stem-folded programs: block 13 has an expand stage of its own (from block 12's output) and a SECOND output, its expanded tensor
+    19 x 19 x 576 -- the first SSD feature map, which BoxPredictor_0 reads -- instead of a separate 1x1 conv in front of it (one launch
+    less per batch).  The fuse_stem=False program keeps that conv; both hold the same weights."""
+    _, ftensors, fops = parse(fused_blob)
+    tap = next(o for o in fops if o["name"].endswith("expanded_conv_13/expand"))
+    fb13 = next(o for o in fops if o["name"].endswith("expanded_conv_13"))
+    assert tap["kind"] == arch.OP_CONV and fb13["cin0"] == 0 and fb13["dst2"] == 0 and ftensors[fb13["src"]]["name"] == "expanded_conv_13/expand"
+    for blob in (default_blob, hp_blob):
+        hdr, tensors, ops = parse(blob)
+        assert not [o for o in ops if o["name"].endswith("expanded_conv_13/expand")]
+        b13 = next(o for o in ops if o["name"].endswith("expanded_conv_13"))
+        assert [o["dst2"] for o in ops if o is not b13] == [0] * (len(ops) - 1)
+        t2 = tensors[b13["dst2"] - 1]
+        assert (t2["name"], t2["h"], t2["w"], t2["c"], t2["flags"]) == ("expanded_conv_13/expand", 19, 19, 576, 0)
+        assert (b13["cin0"], b13["kc0"], b13["nmid_pad"], b13["cmid"], b13["stride"], b13["hin"], b13["hout"]) == (96, 3, 576, 576, 2, 19, 10)
+        assert tensors[b13["src"]]["name"] == "expanded_conv_12/output" and not (b13["flags"] & 1)
+        head0 = next(o for o in ops if o["name"] == "BoxPredictor_0")
+        assert head0["src"] == b13["dst2"] - 1
+        # the second output has a buffer of its own while block 13 .. BoxPredictor_0 run
+        live = [o for o in ops[ops.index(b13):ops.index(head0) + 1]]
+        assert all(tensors[o["dst"]]["slot"] != t2["slot"] for o in live if o["dst"] >= 0 and o is not head0)
+        assert tensors[b13["src"]]["slot"] != t2["slot"]
+        w = unpack_conv(blob, hdr, dict(ksize=1, n_pad=b13["nmid_pad"], kc=b13["kc0"], w_off=b13["we_off"]))
+        np.testing.assert_array_equal(w, unpack_conv(fused_blob, parse(fused_blob)[0], dict(tap, ksize=1)))
+    assert arch.build(tap_in_block=False).ops[13].kind == arch.OP_CONV
 
 
 def test_split_operand_blocks_carry_hi_and_lo_weights(hp_blob, default_blob, synth_weights):
@@ -344,7 +374,8 @@ def test_robust_program_packs_all_blocks_split_and_square_root_scaled(hp_blob, s
     hdr, tensors, ops = parse(rb)
     dhdr, dtensors, dops = parse(hp_blob)
     assert hdr["hp_blocks"] == arch.HP_ALL_BLOCKS + 1 == 17
-    assert [o["name"] for o in ops] == [o["name"] for o in dops] and len(tensors) == len(dtensors)
+    assert [o["name"] for o in ops if not o["name"].endswith("expanded_conv_13/expand")] == [o["name"] for o in dops]
+    assert len(ops) == len(dops) + 1 and len(tensors) == len(dtensors)
     prog = arch.build(hp_upto=arch.HP_ALL_BLOCKS)
     blocks = [(o, op) for o, op in zip(ops, prog.ops) if o["kind"] == arch.OP_MBCONV]
     assert len(blocks) == 17
@@ -358,17 +389,18 @@ def test_robust_program_packs_all_blocks_split_and_square_root_scaled(hp_blob, s
     b13 = next(o for o, op in blocks if op.block == 13)
     assert (b13["cin0"], b13["kc0"], b13["cmid"], b13["cout"], b13["stride"]) == (96, 3, 576, 160, 2)
     assert tensors[b13["src"]]["name"] == "expanded_conv_12/output"
-    # ... none of the default program's blocks carries flag 4, and its block 13 reads the expanded tensor
+    # ... none of the default program's blocks carries flag 4; its block 13 stores the expanded tensor itself (plain fp16 in, no pair to read)
     assert not any(o["flags"] & 4 for o in dops)
-    assert next(o for o in dops if o["name"].endswith("expanded_conv_13"))["cin0"] == 0
+    d13 = next(o for o in dops if o["name"].endswith("expanded_conv_13"))
+    assert d13["dst2"] > 0 and b13["dst2"] == 0
     # the feature-map conv: cin doubled, flag 8, rows k and k + 96 both hold W[k]
     tap = next(o for o in ops if o["name"].endswith("expanded_conv_13/expand"))
     assert tap["kind"] == arch.OP_CONV and tap["flags"] == 8 and tap["cin"] == 192 and tap["kc"] == 6 and tap["cout"] == 576
     assert tensors[tap["src"]]["flags"] == 1 and tensors[tap["src"]]["c"] == 96 and tensors[tap["dst"]]["flags"] == 0
     w = unpack_conv(rb, hdr, dict(tap, ksize=1))
     np.testing.assert_array_equal(w[:, :96, :576], w[:, 96:192, :576])
-    dtap = next(o for o in dops if o["name"].endswith("expanded_conv_13/expand"))
-    np.testing.assert_array_equal(w[:, :96, :576], unpack_conv(hp_blob, dhdr, dict(dtap, ksize=1))[:, :96, :576])
+    np.testing.assert_array_equal(w[:, :96, :576], unpack_conv(hp_blob, dhdr, dict(ksize=1, n_pad=d13["nmid_pad"], kc=d13["kc0"],
+                                                                                w_off=d13["we_off"]))[:, :96, :576])
     with pytest.raises(ValueError):
         engine.build_engine(synth_weights, precision=32, robust=True)
     with pytest.raises(ValueError):

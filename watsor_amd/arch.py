@@ -84,6 +84,8 @@ class Op:
     hp: bool = False           # OP_MBCONV on the split-operand kernel (csrc/k_mbconv_hp.hip): both matrix operands as
                                # hi + lo fp16 pairs, input (and residual) tensor stored as such a pair
     pair_src: bool = False     # OP_CONV 1x1 whose source is a pair tensor, read as 2 cin plain channels (weight rows packed twice)
+    dst2: Optional[str] = None  # OP_MBCONV that also WRITES its expanded tensor (hin x win x cmid, plain fp16): block 13, whose expand
+                                # output is the first SSD feature map -- the block stores what it computes anyway, no launch of its own
 
 
 @dataclass
@@ -126,15 +128,17 @@ HP_LAST_BLOCK = 12   # the blocks in front of the first SSD feature map (the 150
 HP_ALL_BLOCKS = 16   # every inverted-residual block: the robust program (engine.py --robust)
 
 
-def build(size: int = INPUT_SIZE, fuse: bool = True, fuse_stem: bool = True, hp_upto: int = -1, input_pair: bool = False) -> Program:
+def build(size: int = INPUT_SIZE, fuse: bool = True, fuse_stem: bool = True, hp_upto: int = -1, input_pair: bool = False,
+          tap_in_block: bool = True) -> Program:
     """input_pair: the network input is stored as a hi + lo pair of halves even without split-operand blocks (the `-p 32` program:
     one fp16 rounding of the resized image is otherwise the largest error of an engine that computes in fp32).
     hp_upto >= 0 (needs fuse and fuse_stem): blocks 0 .. hp_upto run on the split-operand kernel and the tensors
     between them (the network input included) are hi + lo fp16 pairs; block hp_upto's output is plain fp16 again.
     With hp_upto >= 13 block 13 computes its own expand stage from block 12's pair output, and the separate expand
     conv -- the first SSD feature map, plain fp16 for the heads -- reads both halves of that pair (`pair_src`).
-    fuse=True: every inverted-residual block is ONE op (OP_MBCONV); block 13 keeps its expand conv as
-    a separate op because its output is the first SSD feature map.  fuse=False: one op per layer (the
+    fuse=True: every inverted-residual block is ONE op (OP_MBCONV).  Block 13's expand output is the first SSD feature map:
+    in the stem-folded programs the block writes it itself, next to its own output (`dst2`; tap_in_block=False and the
+    fuse_stem=False program keep the expand conv as a separate op, which block 13 then reads).  fuse=False: one op per layer (the
     program the per-layer parity tests walk); both programs compute bit-identical tensors.
     fuse_stem (with fuse): the stem conv becomes the expand stage of the first block -- input image to block
     output in one launch; the stem then runs on the matrix cores with fp16 weights, so this program matches
@@ -162,15 +166,19 @@ def build(size: int = INPUT_SIZE, fuse: bool = True, fuse_stem: bool = True, hp_
                             ACT_NONE, True, res=res))
             if fuse:
                 keep_expand = t != 1 and idx == 13          # its output is an SSD feature map
+                dst2 = None
                 if keep_expand and hp_upto >= idx:          # ... and the block expands for itself, from the pair tensor
                     ops.append(block[0])
                     ops[-1].pair_src = True
+                    keep_expand = False
+                elif keep_expand and fuse_stem and tap_in_block:   # the block expands for itself and stores the feature map as well
+                    dst2 = block[0].dst
                     keep_expand = False
                 elif keep_expand:
                     ops.append(block.pop(0))
                 has_expand = t != 1 and not keep_expand
                 ops.append(Op(OP_MBCONV, FE + name, block[0].src, name + "/output", mid, c, 3, stride, ACT_NONE, True,
-                              res=res, cmid=mid, cin0=cin if has_expand else 0, parts=block, block=idx))
+                              res=res, cmid=mid, cin0=cin if has_expand else 0, parts=block, block=idx, dst2=dst2))
             else:
                 ops.extend(block)
             cur, cin = name + "/output", c
@@ -212,6 +220,8 @@ def build(size: int = INPUT_SIZE, fuse: bool = True, fuse_stem: bool = True, hp_
         op.hout, op.pad_t = tf_same(op.hin, op.k, op.stride)
         op.wout, op.pad_l = tf_same(op.win, op.k, op.stride)
         p.tensors[op.dst] = Tensor(op.dst, op.hout, op.wout, op.cout, hp=op.hp and op.block < hp_upto)
+        if op.dst2:
+            p.tensors[op.dst2] = Tensor(op.dst2, op.hin, op.win, op.cmid)
 
     # heads: BoxEncodingPredictor and ClassPredictor of a feature map read the same input, so they run
     # as ONE 3x3 conv whose output columns are [a*4 box encodings | a*91 class logits] (biases, no activation)

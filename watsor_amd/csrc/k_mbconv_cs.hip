@@ -73,6 +73,9 @@ __global__ __launch_bounds__(CS_WAVES * 64) void wz_k_mbconv_cs(const WzMbArgs a
 
     half8_t xf[EXPAND ? MPW : 1][EXPAND ? KCI : 1];
     bool inimg[EXPAND ? MPW : 1];
+    // a.out2: the block also STORES its expanded tensor (block 13: the first SSD feature map) -- every input pixel by the tile that owns
+    // it: the first th * s rows / tw * s columns of a tile's halo are its own, the rest is the next tile's (tiles step by th * s)
+    int own2[EXPAND ? MPW : 1];   // pixel offset into out2, or -1
     if constexpr (EXPAND) {
 #pragma unroll
         for (int i = 0; i < MPW; ++i) {
@@ -81,6 +84,7 @@ __global__ __launch_bounds__(CS_WAVES * 64) void wz_k_mbconv_cs(const WzMbArgs a
             const int iy = iy_base + hy, ix = ix_base + hx;
             const bool ok = p < P && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
             inimg[i] = ok;
+            own2[i] = (a.out2 && ok && nt0 == 0 && hy < a.th * s && hx < a.tw * s) ? (b * a.hin + iy) * a.win + ix : -1;
             const half_t* src = a.in + ((size_t)(b * a.hin + (ok ? iy : 0)) * a.win + (ok ? ix : 0)) * a.cin0;
 #pragma unroll
             for (int c = 0; c < KCI; ++c) {
@@ -134,6 +138,8 @@ __global__ __launch_bounds__(CS_WAVES * 64) void wz_k_mbconv_cs(const WzMbArgs a
                     for (int c = 0; c < KCI; ++c) d = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa_c[nt][c], xf[i][c], d, 0, 0, 0);
                     const half4_t o = wz_relu6_pack(d, bv, inimg[i] && have);
                     *reinterpret_cast<half4_t*>(E + (i * 16 + r16) * ES + nt * 16 + g * 4) = o;
+                    if (own2[i] >= 0 && ce0 + nt * 16 + g * 4 < a.cmid)
+                        *reinterpret_cast<half4_t*>(a.out2 + (size_t)own2[i] * a.cmid + ce0 + nt * 16 + g * 4) = o;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -279,7 +285,7 @@ int wz_launch_mbconv_cs(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
     // p50 0.380 -> 0.394 ms (profiles/r03_wave_counts_*; round 1 measured the same trade at +1 %, round 2 at +0.6 %).  Default since
     // round 3; WZ_MB_CS_MIN_W=11 brings the channel-group kernel back for the 10x10 maps.
     static const int min_w = wz_cs_env("WZ_MB_CS_MIN_W", wz_latency_schedule() ? 11 : 1);
-    if (enabled != 1 || a0.stem || a0.wout > 19 || a0.wout < min_w) return -2;
+    if (a0.stem || a0.wout > 19 || ((enabled != 1 || a0.wout < min_w) && !a0.has_out2)) return -2;   // (a block with a second output runs here or nowhere)
     const int nto = a0.n_pad / 16;
     // ... except block 16 (320 output channels, 0.9 MB of weights per workgroup: 31 us alone against 9 + 4): it stays on the channel-group
     // kernel -- 50.0 k frames/s either way, p50 0.380 instead of 0.395 ms (WZ_MB_CS_MAX_NTO=20: on this kernel as well)
@@ -309,6 +315,7 @@ int wz_launch_mbconv_cs(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
     }
     if (a.stride == 2) {   // halo 9 x 9 = 81 pixels -> 6 m-tiles
         if (a.kc0 == 1 && nto == 4) return wz_cs_launch<true, 6, 1, 1, 4>(a, n, s, prepare);
+        if (a.kc0 == 3 && nto == 10) return wz_cs_launch<true, 6, 1, 3, 10>(a, n, s, prepare);   // block 13 with its expand stage (19x19 -> 10x10)
         return -2;
     }
     // stride 1: halo 6 x 6 = 36 pixels -> 3 m-tiles

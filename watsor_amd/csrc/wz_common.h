@@ -118,6 +118,8 @@ struct WzMbArgs {
     const half_t* we_lo;   // "lo" halves of the expand weights (we = "hi")
     const half_t* wp_lo;   // "lo" halves of the project weights
     int32_t hp, hp_out;    // hp: this block runs on the split-operand kernel; hp_out: `out` is a hi + lo pair tensor
+    half_t* out2;          // chunk-split kernel: where the expanded tensor is stored as well (hin x win x cmid fp16), or nullptr
+    int32_t has_out2;      // the op has such a second output (out2 itself is null while a launcher is only asked to prepare)
     int32_t qenc;          // split-operand kernel: the chunk buffer holds unorm16 of sqrt(v / 6) (the robust program; wd carries 6 / 65535^2)
 };
 

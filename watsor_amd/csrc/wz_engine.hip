@@ -205,6 +205,8 @@ static WzMbArgs mb_args(wz_engine* e, const Lane& L, const WzOpDesc& op) {
     a.hp = (op.flags & WZ_OPF_HP) ? 1 : 0;
     a.hp_out = (op.flags & WZ_OPF_HP_OUT) ? 1 : 0;
     a.qenc = (op.flags & WZ_OPF_QENC) ? 1 : 0;
+    a.out2 = (op.dst2 > 0 && !L.tptr.empty()) ? L.tptr[op.dst2 - 1] : nullptr;
+    a.has_out2 = op.dst2 > 0 ? 1 : 0;
     if (a.hp) {
         a.we_lo = (const half_t*)(wbase + op.we_lo_off);
         a.wp_lo = (const half_t*)(wbase + op.w_lo_off);
@@ -297,7 +299,8 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
             int groups = a.hp ? wz_launch_mbconv_hp(a, n, s, false)   // split-operand blocks (the `-p 16` program's first 13)
                               : wz_launch_mbconv_wave(a, n, s, false);   // large maps: one wavefront per pixel tile
             if (a.hp && groups < 0) L.launch_failed = (int)i + 1;   // nothing was enqueued for a split-operand block: run_batch reports it
-            if (groups == -2 && e->use_splitk) groups = wz_launch_mbconv_cs(a, n, s, false);   // small maps: channels over waves
+            if (groups == -2 && (e->use_splitk || a.has_out2)) groups = wz_launch_mbconv_cs(a, n, s, false);   // small maps: channels over waves
+            if (a.has_out2 && groups < 0) L.launch_failed = (int)i + 1;   // only the chunk-split kernel stores a second output
             if (groups == -2) groups = wz_launch_mbconv(a, n, s, false);
             if (e->d_mbdbg) e->mb_groups[i] = groups;
             if (t) t->mark();
@@ -720,6 +723,12 @@ static int load_blob(wz_engine* e, const char* path) {
                                 op.nmid_pad < op.cmid || op.we_off < 0 || (uint64_t)op.we_off >= h.weights_bytes ||
                                 op.be_off < 0 || (uint64_t)op.be_off >= h.weights_bytes)))))
             return wz_fail(WZ_EFORMAT, "%s: op %u (%s) is malformed", path, i, op.name);
+        if (op.dst2 != 0) {
+            const WzTensorDesc* t2 = (op.dst2 > 0 && op.dst2 <= (int64_t)h.n_tensors) ? &e->tensors[op.dst2 - 1] : nullptr;
+            if (op.kind != WZ_OP_MBCONV || (op.flags & WZ_OPF_HP) || !t2 || op.cin0 <= 0 || t2->h != op.hin || t2->w != op.win ||
+                t2->c != op.cmid || (t2->flags & WZ_TENSOR_HP) || op.dst2 - 1 == op.dst || op.dst2 - 1 == op.src)
+                return wz_fail(WZ_EFORMAT, "%s: op %u (%s): malformed second output", path, i, op.name);
+        }
         if (op.kind == WZ_OP_MBCONV && h.precision != 16)
             return wz_fail(WZ_EFORMAT, "%s: fused blocks exist for the fp16 engine only", path);
         if (h.precision == 32 && ((op.kind == WZ_OP_CONV && op.cin % 4 != 0) || (op.kind == WZ_OP_DW && op.cin % 4 != 0)))
@@ -752,7 +761,8 @@ static int load_blob(wz_engine* e, const char* path) {
                 return wz_fail(WZ_EFORMAT, "%s: op %u (%s): no stem-fused kernel for this shape", path, i, op.name);
         } else if (op.kind == WZ_OP_MBCONV) {
             wz_engine::Lane none;
-            if (wz_launch_mbconv(mb_args(e, none, op), 1, nullptr, true) != 0)
+            if (op.dst2 > 0 ? wz_launch_mbconv_cs(mb_args(e, none, op), 1, nullptr, true) != 0
+                            : wz_launch_mbconv(mb_args(e, none, op), 1, nullptr, true) != 0)
                 return wz_fail(WZ_EFORMAT, "%s: op %u (%s): no fused-block kernel for this shape", path, i, op.name);
         }
     }

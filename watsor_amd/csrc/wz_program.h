@@ -8,7 +8,7 @@
 #include <stdint.h>
 
 #define WZ_MAGIC 0x35335A57u /* "WZ35" */
-#define WZ_FORMAT_VERSION 8u
+#define WZ_FORMAT_VERSION 9u
 
 enum WzOpKind { WZ_OP_STEM = 1, WZ_OP_DW = 2, WZ_OP_CONV = 3, WZ_OP_MBCONV = 4 };
 enum WzOutMode { WZ_OUT_ACT = 0, WZ_OUT_BOX = 1, WZ_OUT_CLS = 2, WZ_OUT_HEAD = 3 };
@@ -73,7 +73,8 @@ struct WzOpDesc {  // 256 bytes
     // in LDS as unorm16 of relu6(x)/6)
     int64_t we_lo_off, w_lo_off;
     int64_t flags;                          // WzOpFlags
-    int64_t reserved2[1];
+    int64_t dst2;                           // WZ_OP_MBCONV: 1 + index of a second output tensor, or 0 -- the block's EXPANDED tensor (hin x win x cmid,
+                                            // plain fp16), stored by the block itself (block 13: the first SSD feature map)
     char name[64];
 };
 #pragma pack(pop)

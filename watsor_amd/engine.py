@@ -24,7 +24,7 @@ from . import arch
 from .anchors import ssd_anchor_table
 
 MAGIC = 0x35335A57
-FORMAT_VERSION = 8
+FORMAT_VERSION = 9
 BN_EPSILON = 1e-3          # watsor/test/model/prepare.py:48
 
 DEFAULT_POST = dict(max_total=100, max_per_class=100, score_threshold=1e-8, iou_threshold=0.6,
@@ -177,7 +177,7 @@ def _op_record(op, tindex, n_pad, kc, w_off, b_off, mb) -> bytes:
         w_off, b_off,
         op.n_box, mb["cmid"], mb["cin0"], mb["kc0"], mb["cmid_pad"], mb["nmid_pad"], mb["stem"], mb["stem_pad"],
         mb["we_off"], mb["be_off"], mb["wd_off"], mb["bd_off"], mb.get("we_lo_off", 0), mb.get("w_lo_off", 0),
-        mb.get("flags", 0), 0,
+        mb.get("flags", 0), (tindex[op.dst2] + 1) if getattr(op, "dst2", None) else 0,
         op.scope.encode()[:63])
 
 
@@ -197,8 +197,10 @@ def assign_slots(prog: "arch.Program", tensor_names: List[str]) -> List[int]:
     slot_of[index["input"]] = 0
     slot_size.append(size["input"])
     for oi, op in enumerate(prog.ops):
-        if op.out_mode == arch.OUT_ACT:
-            need = size[op.dst]
+        for out in ([op.dst, op.dst2] if op.out_mode == arch.OUT_ACT else []):
+            if out is None:
+                continue
+            need = size[out]
             best = None
             for s in free:                                   # best fit among free slots
                 if best is None or abs(slot_size[s] - need) < abs(slot_size[best] - need):
@@ -209,8 +211,8 @@ def assign_slots(prog: "arch.Program", tensor_names: List[str]) -> List[int]:
             else:
                 free.remove(best)
                 slot_size[best] = max(slot_size[best], need)
-            slot_of[index[op.dst]] = best
-            if last_use[op.dst] < 0:                         # never read (cannot happen in this graph)
+            slot_of[index[out]] = best
+            if last_use[out] < 0:                            # never read (cannot happen in this graph)
                 free.append(best)
         for n in {op.src, op.res} - {None}:
             if last_use[n] == oi:
@@ -221,7 +223,7 @@ def assign_slots(prog: "arch.Program", tensor_names: List[str]) -> List[int]:
 def build_engine(weights: Dict[str, np.ndarray], precision: int = 16, model_width: int = 300,
                  model_height: int = 300, post: Optional[dict] = None, fuse: bool = True,
                  fuse_stem: bool = True, hp_upto: Optional[int] = None, options: Optional[dict] = None,
-                 robust: bool = False) -> bytes:
+                 robust: bool = False, tap_in_block: bool = True) -> bytes:
     """Returns the engine image.  Mirrors `build_engine` of watsor/engine.py:17-51.
     fuse=False keeps one op per layer (used by the per-layer parity tests; same results, slower).
     hp_upto: last inverted-residual block on the split-operand kernel (default for the `-p 16` program with fused
@@ -229,7 +231,9 @@ def build_engine(weights: Dict[str, np.ndarray], precision: int = 16, model_widt
     everywhere, the faster engine that misses that tolerance by 3x).
     robust (precision 16): ALL 17 blocks on the split-operand kernel and the expanded tensors kept as unorm16 of sqrt(x / 6) instead
     of x / 6 -- the program for weights whose channels live at very different scales (a folded trained BatchNorm), where the
-    default program loses the tolerance."""
+    default program loses the tolerance.
+    tap_in_block=False: block 13's expand conv -- the first SSD feature map -- as a launch of its own in front of the block instead of
+    the block's second output (the program of rounds 1 .. 3; for A/B runs)."""
     if precision not in (16, 32):
         raise ValueError("precision must be 16 (fp16 storage, fp16 MFMA, fused blocks) or 32 (fp32 storage, fp32 MFMA)")
     if precision == 32:
@@ -246,7 +250,7 @@ def build_engine(weights: Dict[str, np.ndarray], precision: int = 16, model_widt
         raise ValueError("the robust program is the `-p 16` program with fused blocks")
     if hp_upto is None:
         hp_upto = (arch.HP_ALL_BLOCKS if robust else arch.HP_LAST_BLOCK) if (precision == 16 and fuse and fuse_stem) else -1
-    prog = arch.build(model_width, fuse=fuse, fuse_stem=fuse_stem, hp_upto=hp_upto, input_pair=precision == 32)
+    prog = arch.build(model_width, fuse=fuse, fuse_stem=fuse_stem, hp_upto=hp_upto, input_pair=precision == 32, tap_in_block=tap_in_block)
     missing = [n for n in prog.variable_shapes() if n not in weights]
     if missing:
         raise KeyError("model is missing %d variables, e.g. %s" % (len(missing), missing[0]))
@@ -254,7 +258,7 @@ def build_engine(weights: Dict[str, np.ndarray], precision: int = 16, model_widt
         if tuple(weights[name].shape) != tuple(shape):
             raise ValueError("%s has shape %s, expected %s" % (name, weights[name].shape, shape))
 
-    tensor_names = ["input"] + [op.dst for op in prog.ops if op.out_mode == arch.OUT_ACT]
+    tensor_names = ["input"] + [t for op in prog.ops if op.out_mode == arch.OUT_ACT for t in (op.dst, op.dst2) if t]
     tindex = {n: i for i, n in enumerate(tensor_names)}
     slots = assign_slots(prog, tensor_names)
 
