@@ -83,7 +83,6 @@ class Op:
     block: int = -1            # OP_MBCONV: index of the inverted-residual block (expanded_conv_<block>)
     hp: bool = False           # OP_MBCONV on the split-operand kernel (csrc/k_mbconv_hp.hip): both matrix operands as
                                # hi + lo fp16 pairs, input (and residual) tensor stored as such a pair
-    pair_src: bool = False     # OP_CONV 1x1 whose source is a pair tensor, read as 2 cin plain channels (weight rows packed twice)
     dst2: Optional[str] = None  # OP_MBCONV that also WRITES its expanded tensor (hin x win x cmid, plain fp16): block 13, whose expand
                                 # output is the first SSD feature map -- the block stores what it computes anyway, no launch of its own
 
@@ -134,8 +133,7 @@ def build(size: int = INPUT_SIZE, fuse: bool = True, fuse_stem: bool = True, hp_
     one fp16 rounding of the resized image is otherwise the largest error of an engine that computes in fp32).
     hp_upto >= 0 (needs fuse and fuse_stem): blocks 0 .. hp_upto run on the split-operand kernel and the tensors
     between them (the network input included) are hi + lo fp16 pairs; block hp_upto's output is plain fp16 again.
-    With hp_upto >= 13 block 13 computes its own expand stage from block 12's pair output, and the separate expand
-    conv -- the first SSD feature map, plain fp16 for the heads -- reads both halves of that pair (`pair_src`).
+    With hp_upto >= 13 block 13 reads block 12's pair output (and stores the feature map as plain fp16, like the other programs).
     fuse=True: every inverted-residual block is ONE op (OP_MBCONV).  Block 13's expand output is the first SSD feature map:
     in the stem-folded programs the block writes it itself, next to its own output (`dst2`; tap_in_block=False and the
     fuse_stem=False program keep the expand conv as a separate op, which block 13 then reads).  fuse=False: one op per layer (the
@@ -167,11 +165,7 @@ def build(size: int = INPUT_SIZE, fuse: bool = True, fuse_stem: bool = True, hp_
             if fuse:
                 keep_expand = t != 1 and idx == 13          # its output is an SSD feature map
                 dst2 = None
-                if keep_expand and hp_upto >= idx:          # ... and the block expands for itself, from the pair tensor
-                    ops.append(block[0])
-                    ops[-1].pair_src = True
-                    keep_expand = False
-                elif keep_expand and fuse_stem and tap_in_block:   # the block expands for itself and stores the feature map as well
+                if keep_expand and fuse_stem and (tap_in_block or hp_upto >= idx):   # the block expands for itself and stores the feature map as well
                     dst2 = block[0].dst
                     keep_expand = False
                 elif keep_expand:

@@ -158,6 +158,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
     // ---- halo pixels of this lane: input channels as B fragments, hi and lo
     half8_t xh[MPW][KCI], xl[MPW][KCI];
     bool inimg[MPW];
+    constexpr bool TAP = LEAN && OCC == 2 && MPW == 6;   // (the 256-register lean build of the stride-2 shape only: block 13)
+    int own2[MPW];   // lean builds with a second output (WzMbArgs::out2: block 13 of the robust program stores its expanded tensor, the first SSD
+                     // feature map): pixel offset into it for the halo pixels this tile owns (its first th * s rows / tw * s columns), else -1
     const float rcp_hw = 1.0f / (float)hw_;   // p < 96, hw_ <= 10: floor((p + 0.5) / hw_) is exact in fp32 (no integer division)
 #pragma unroll
     for (int i = 0; i < MPW; ++i) {
@@ -166,6 +169,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
         const int iy = iy_base + hy, ix = ix_base + hx;
         const bool ok = live && p < P && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
         inimg[i] = ok;
+        own2[i] = (TAP && a.out2 && ok && nt0 == 0 && hy < a.th * s && hx < a.tw * s) ? (b * a.hin + iy) * a.win + ix : -1;
         if constexpr (STEM) {
             // K order of the stem GEMM in this program (engine.py: stem_k_rows): k = tap*4 + c for taps 0 .. 7, i.e. lane group
             // g holds the 4-channel pixels of taps 2g and 2g+1 exactly as they lie in the input pair tensor, and the ninth
@@ -333,6 +337,14 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
         // ---- expand: E[p][ce] = in-frame ? unorm16(clamp((sum_k X[p][k] We[k][ce] + be[ce]) / 6, 0, 1)) : 0
         // one 16 x 4 tile of expanded values of a lane -> the chunk buffer (QE: as sqrt)
         auto put = [&](float4_t d, int i, int nt, bool keep) {
+            if constexpr (TAP) {   // the second output: relu6 of the expanded value as plain fp16 (d carries the 1 / 6 of the chunk buffer)
+                if (own2[i] >= 0 && keep && ce0 + nt * 16 + g * 4 < a.cmid) {
+                    half4_t t2;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) t2[r] = (half_t)(6.0f * fminf(fmaxf(d[r], 0.0f), 1.0f));
+                    *reinterpret_cast<half4_t*>(a.out2 + (size_t)own2[i] * a.cmid + ce0 + nt * 16 + g * 4) = t2;
+                }
+            }
             if constexpr (QE) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) d[r] = __builtin_amdgcn_sqrtf(fmaxf(d[r], 0.0f));
@@ -670,6 +682,7 @@ template <int NW, bool CS, bool STEM, int MPW, int MQW, int KCI, int NTO, int OC
 static int wz_hp_launch(WzMbArgs a, int n, hipStream_t s, bool prepare) {
     if (ONEPASS && (a.cmid_pad >> 5) > NW) return -1;
     if (QE != (a.qenc != 0)) return -1;
+    if (a.has_out2 && !(LEAN && OCC == 2 && MPW == 6)) return -1;   // only the lean build of block 13's shape stores a second output
     a.nb = n;
     if (MQW == 2) { a.th = 4; a.tw = 8; } else { a.th = 4; a.tw = 4; }
     a.tiles_y = (a.hout + a.th - 1) / a.th;

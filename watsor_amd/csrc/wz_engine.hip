@@ -725,7 +725,7 @@ static int load_blob(wz_engine* e, const char* path) {
             return wz_fail(WZ_EFORMAT, "%s: op %u (%s) is malformed", path, i, op.name);
         if (op.dst2 != 0) {
             const WzTensorDesc* t2 = (op.dst2 > 0 && op.dst2 <= (int64_t)h.n_tensors) ? &e->tensors[op.dst2 - 1] : nullptr;
-            if (op.kind != WZ_OP_MBCONV || (op.flags & WZ_OPF_HP) || !t2 || op.cin0 <= 0 || t2->h != op.hin || t2->w != op.win ||
+            if (op.kind != WZ_OP_MBCONV || !t2 || op.cin0 <= 0 || t2->h != op.hin || t2->w != op.win ||
                 t2->c != op.cmid || (t2->flags & WZ_TENSOR_HP) || op.dst2 - 1 == op.dst || op.dst2 - 1 == op.src)
                 return wz_fail(WZ_EFORMAT, "%s: op %u (%s): malformed second output", path, i, op.name);
         }
@@ -745,10 +745,6 @@ static int load_blob(wz_engine* e, const char* path) {
         } else if (op.kind == WZ_OP_STEM && h.precision == 32 && (e->tensors[op.src].flags & WZ_TENSOR_HP) &&
                    !(op.dst >= 0 && (e->tensors[op.dst].flags & WZ_TENSOR_HP))) {
             // the fp32 program's stem reads the network input as a hi + lo pair (wz_k_stem_f32)
-        } else if (op.kind == WZ_OP_CONV && (op.flags & WZ_OPF_PAIR_SRC)) {
-            if (h.precision != 16 || !(e->tensors[op.src].flags & WZ_TENSOR_HP) || op.cin != 2 * e->tensors[op.src].c || op.ksize != 1 ||
-                op.res >= 0 || (op.dst >= 0 && (e->tensors[op.dst].flags & WZ_TENSOR_HP)))
-                return wz_fail(WZ_EFORMAT, "%s: op %u (%s): malformed convolution over a pair tensor", path, i, op.name);
         } else if ((e->tensors[op.src].flags & WZ_TENSOR_HP) || (op.dst >= 0 && (e->tensors[op.dst].flags & WZ_TENSOR_HP)) ||
                    (op.res >= 0 && (e->tensors[op.res].flags & WZ_TENSOR_HP))) {
             return wz_fail(WZ_EFORMAT, "%s: op %u (%s) touches a pair tensor but is not a split-operand block", path, i, op.name);

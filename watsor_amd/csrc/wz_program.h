@@ -16,9 +16,7 @@ enum WzAct { WZ_ACT_NONE = 0, WZ_ACT_RELU6 = 1 };
 enum WzTensorFlags { WZ_TENSOR_HP = 1 };
 enum WzOpFlags {
     WZ_OPF_HP = 1, WZ_OPF_HP_OUT = 2,   // split-operand block (k_mbconv_hp.hip) / its output tensor is a hi + lo pair
-    WZ_OPF_QENC = 4,                    // ... whose chunk buffer holds square roots (the robust program; depthwise weights carry 6 / 65535^2)
-    WZ_OPF_PAIR_SRC = 8                 // WZ_OP_CONV 1x1 reading BOTH halves of a pair tensor as 2 c plain channels (weight rows packed twice:
-                                        // W.hi + W.lo) -- block 13's expand output, the first SSD feature map, in the robust program
+    WZ_OPF_QENC = 4                     // ... whose chunk buffer holds square roots (the robust program; depthwise weights carry 6 / 65535^2)
 };
 
 #pragma pack(push, 1)

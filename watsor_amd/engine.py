@@ -170,7 +170,7 @@ def _op_record(op, tindex, n_pad, kc, w_off, b_off, mb) -> bytes:
         "<20i2q8i8q64s",
         op.kind, tindex[op.src], tindex.get(op.dst, -1) if op.out_mode == arch.OUT_ACT else -1,
         tindex[op.res] if op.res else -1,
-        mb.get("cin", op.cin), op.cout, op.k, op.stride,
+        op.cin, op.cout, op.k, op.stride,
         op.hin, op.win, op.hout, op.wout,
         op.pad_t, op.pad_l, op.act, op.out_mode,
         op.anchor_offset, op.anchors_per_loc, n_pad, kc,
@@ -363,17 +363,6 @@ def build_engine(weights: Dict[str, np.ndarray], precision: int = 16, model_widt
         elif op.kind == arch.OP_DW:
             w_off = put(w.reshape(9, op.cin).astype(np.float32 if precision == 32 else np.float16))
             b_off = put(b.astype(np.float32))
-        elif op.pair_src:
-            # a 1x1 conv over a pair tensor: per pixel cin "hi" halves, then cin "lo" halves -- 2 cin plain channels, the weight rows
-            # packed twice (W.hi + W.lo in the fp32 accumulator)
-            assert op.k == 1 and prog.tensors[op.src].hp and precision == 16
-            n_pad = _align(op.cout, 64 if op.cout >= 256 else 32)
-            kc = (2 * op.cin + 31) // 32
-            w_off = put(pack_conv_weights(np.concatenate([w, w], axis=2).astype(np.float32), n_pad, kc))
-            bp = np.zeros(n_pad, np.float32)
-            bp[:op.cout] = b
-            b_off = put(bp)
-            mb.update(cin=2 * op.cin, flags=8)
         else:
             w_off, b_off, n_pad, kc = put_conv(op)
         op_recs.append(_op_record(op, tindex, n_pad, kc, w_off, b_off, mb))
