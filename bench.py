@@ -353,7 +353,7 @@ def rocprof_avg_us(kernel):
 # --------------------------------------------------------------------------------------------------
 # legs
 # --------------------------------------------------------------------------------------------------
-def throughput(eng, submit, n_frames_per_step, steps=120, warm=12):
+def throughput(eng, submit, n_frames_per_step, steps=400, warm=40):
     """frames/s of `steps` asynchronous steps over the engine's lanes + p50 of synchronous ones."""
     lanes = eng.num_slots
     for s in range(warm):
