@@ -42,6 +42,9 @@ extern "C" {
 #define WZ_EHIP (-4)     /* HIP runtime error (message has the hipError string) */
 #define WZ_ENODEV (-5)   /* no such GPU */
 #define WZ_ELIMIT (-6)   /* batch / resolution / camera id beyond what wz_create() reserved */
+#define WZ_EINCOMPLETE (-7) /* the call DID its work -- every row was written -- but a frame's rows may be short (clip-after-NMS engines: more
+                             * selected boxes lay entirely outside the image than the walk keeps in reserve; wz_collect / wz_collect_bound /
+                             * wz_detect_batch).  Every other code means the rows were NOT written.  -> Python raises RowsIncomplete */
 
 /* Byte-for-byte `Detection` of watsor/stream/share.py:11-25 (72 bytes; label@0 zones@4
  * confidence@48 bounding_box@56).  Rows are written in place. */

@@ -90,11 +90,14 @@ def _int_vector(M, g, name, values):
 
 def write_detection_graph(path, variables, input_size=(300, 300), align_corners=False, half_pixel_centers=None, iou=0.6,
                           score=1e-8, max_per_class=100, max_total=100, box_scales=(10.0, 10.0, 5.0, 5.0), anchor_scales=None,
-                          nms_op="NonMaxSuppressionV3", classes=3):
+                          nms_op="NonMaxSuppressionV3", classes=3, faithful=True):
     """A frozen detection graph in miniature: the variables, and around them the nodes that carry the graph's own settings the way an
     Object Detection API export does -- Preprocessor ResizeBilinear (attributes + size input), per-class NonMaxSuppression nodes
     with constant inputs behind Identity nodes, the FilterGreaterThan comparisons, the box coder's divisions, the anchor
-    generator's scale / aspect-ratio constants, the top-k behind the NMS."""
+    generator's scale / aspect-ratio constants, the top-k behind the NMS.  `faithful` (default) adds what a real export also has
+    in those scopes and what an extractor must NOT mistake for settings: the `tf.minimum(max_size_per_class, num_boxes)` node in front of
+    every NMS node, the `tf.minimum(max_total_size, num_boxes)` behind the sort, the decoder's `h / 2.` / `w / 2.` divisions
+    (Decode/truediv_4 .. _7) and those of get_center_coordinates_and_sizes."""
     import numpy as np
     M = _messages()
     g = M["GraphDef"]()
@@ -116,14 +119,34 @@ def write_detection_graph(path, variables, input_size=(300, 300), align_corners=
         nms = g.node.add(name=scope + "non_max_suppression%s/%s" % (sfx, nms_op), op=nms_op)
         size_c = _scalar(M, g, scope + "Minimum%s/x" % sfx, max_per_class, 3)
         ident = g.node.add(name=scope + "non_max_suppression%s/max_output_size" % sfx, op="Identity")
-        ident.input.append(size_c)
+        if faithful:
+            mn = g.node.add(name=scope + "Minimum%s" % sfx, op="Minimum")
+            mn.input.extend([size_c, scope + "strided_slice%s" % sfx])
+            ident.input.append(mn.name)
+        else:
+            ident.input.append(size_c)
         ins = [scope + "boxes%s" % sfx, scope + "scores%s" % sfx, ident.name,
                _scalar(M, g, scope + "non_max_suppression%s/iou_threshold" % sfx, iou, 1)]
         if nms_op != "NonMaxSuppressionV2":
             ins.append(_scalar(M, g, scope + "non_max_suppression%s/score_threshold" % sfx, float("-inf"), 1))
         nms.input.extend(ins)
     tk = g.node.add(name=scope + "SortByField/TopKV2", op="TopKV2")
-    tk.input.extend([scope + "concat", _scalar(M, g, scope + "SortByField/k", max_total, 3)])
+    if faithful:                                               # sort_by_field sorts ALL boxes (k = their number), the clip follows
+        tk.input.extend([scope + "concat", scope + "SortByField/Size"])
+        mt = g.node.add(name=scope + "Minimum_%d" % classes, op="Minimum")
+        mt.input.extend([_scalar(M, g, scope + "Minimum_%d/x" % classes, max_total, 3), scope + "SortByField/strided_slice"])
+    else:
+        tk.input.extend([scope + "concat", _scalar(M, g, scope + "SortByField/k", max_total, 3)])
+    g.node.add(name="Postprocessor/Decode/transpose", op="Transpose").input.extend(["Postprocessor/Reshape_1", "Postprocessor/Decode/transpose/perm"])
+    g.node.add(name="Postprocessor/Decode/unstack", op="Unpack").input.append("Postprocessor/Decode/transpose")
+    if faithful:
+        for i, src in ((4, "mul_1"), (5, "mul"), (6, "mul_1"), (7, "mul")):      # ymin = ycenter - h / 2. ...
+            d = g.node.add(name="Postprocessor/Decode/truediv_%d" % i, op="RealDiv")
+            d.input.extend(["Postprocessor/Decode/" + src, _scalar(M, g, "Postprocessor/Decode/truediv_%d/y" % i, 2.0, 1)])
+        for i, src in ((0, "sub_1"), (1, "sub")):                                # ycenter = ymin + height / 2. ...
+            nm = "Postprocessor/Decode/get_center_coordinates_and_sizes/truediv" + ("" if i == 0 else "_%d" % i)
+            d = g.node.add(name=nm, op="RealDiv")
+            d.input.extend(["Postprocessor/Decode/get_center_coordinates_and_sizes/" + src, _scalar(M, g, nm + "/y", 2.0, 1)])
     for i, v in enumerate(box_scales):
         d = g.node.add(name="Postprocessor/Decode/truediv" + ("" if i == 0 else "_%d" % i), op="RealDiv")
         d.input.extend(["Postprocessor/Decode/unstack:%d" % i, _scalar(M, g, "Postprocessor/Decode/truediv%s/y" % ("" if i == 0 else "_%d" % i), v, 1)])

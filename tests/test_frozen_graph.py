@@ -127,3 +127,33 @@ def test_engine_cli_adopts_the_graphs_settings(tmp_path, synth_weights, capsys):
     assert "iou_threshold=0.4" in capsys.readouterr().out          # (0.45 as the float32 the graph holds)
     with pytest.raises(ValueError):
         engine.main(["-i", path, "-o", out, "--resize", "legacy"])
+
+
+def test_decoder_halvings_are_not_scale_factors_and_ambiguity_only_warns(tmp_path, synth_weights):
+    """a real Object Detection API export divides by 2. in the Decode scope as well (`h / 2.`, `w / 2.`,
+    get_center_coordinates_and_sizes): the scale factors are the four divisions that read the unstacked encodings, by dataflow.
+    The simplified graph of earlier rounds (no Unpack node, no halvings) still reads by name; a decoder nobody can sort out
+    warns and keeps the defaults instead of refusing the graph."""
+    from pb_writer import write_detection_graph
+    from watsor_amd import frozen_graph as fg
+    small = {k: v for k, v in list(synth_weights.items())[:3]}
+    path = str(tmp_path / "g.pb")
+    write_detection_graph(path, small, box_scales=(10.0, 10.0, 5.0, 4.0), max_per_class=30, max_total=70)
+    g = fg.read_frozen_graph(path)
+    halvings = [n for n in g.nodes.values() if n.op == "RealDiv" and g.constant(n.inputs[1]) is not None and float(g.constant(n.inputs[1]).reshape(-1)[0]) == 2.0]
+    assert len(halvings) == 6                                   # (they are in the graph ...)
+    s = fg.graph_settings(g)
+    assert s["box_scales"] == (10.0, 10.0, 5.0, 4.0)            # (... and not among the scale factors)
+    assert s["max_per_class"] == 30 and s["max_total"] == 70    # per-class Minimum nodes are not the total (ADVICE r3, low)
+    write_detection_graph(path, small, faithful=False)
+    assert fg.read_frozen_graph_model(path)[1]["box_scales"] == (10.0, 10.0, 5.0, 5.0)
+    # a fifth division reading the unstack: ambiguous -> a warning, the defaults, no exception
+    g = fg.read_frozen_graph(path)
+    extra = fg.Node("Postprocessor/Decode/truediv_9", "RealDiv", ["Postprocessor/Decode/unstack:1", "Postprocessor/Decode/truediv_9/y"], {}, None)
+    g.nodes[extra.name] = extra
+    g.nodes[extra.name + "/y"] = fg.Node(extra.name + "/y", "Const", [], {}, np.array([7.0], np.float32))
+    s = fg.graph_settings(g)
+    assert "box_scales" not in s and "box_scales_ambiguous" in s
+    with pytest.warns(UserWarning, match="scale factors"):
+        post, _ = engine.apply_graph_settings(s, 300, 300, None, None)
+    assert "scales" not in post

@@ -1,6 +1,6 @@
 """HIP path vs the CPU oracle, stage by stage and end to end, all through the C ABI (ctypes).
 
-Tolerances (stated here, measured in profiles/r01_parity.txt):
+Tolerances (stated here; measured values: DESIGN.md section 4, the pytest logs under profiles/*_pytest_gpu.txt):
   * resize+normalise ............ bit-exact fp16 (integer/byte stage of the oracle, fp32 ops in TF order)
   * row fill (int truncation) .... bit-exact
   * post-processing on identical fp32 head outputs: same (class, anchor) rows, |score| <= 1e-6,

@@ -230,3 +230,47 @@ def test_plain_plugin_without_batch_or_async_api():
     fps, it = drive(w, Plain(), cams, [[shm.Payload("cam0", 0)], [shm.Payload("cam1", 1)]])
     assert first_row(cams["cam0"].frames[0])[0] == 5 and first_row(cams["cam1"].frames[1])[0] == 5
     assert fps.count.value == 2 and abs(it.total.value - 4.0) < 1e-9
+
+
+def test_rows_incomplete_counts_the_batch_any_other_collect_failure_does_not(monkeypatch):
+    """only WZ_EINCOMPLETE (`RowsIncomplete`) means "the rows were written" -- the batch is latched on and counted.
+    Any other failure of collect (a bad slot, a lane without a bound batch: rows NOT written) must not pass as detected frames:
+    it propagates like the reference's 'Detection failure' (detector.py:99-100); the latches are still stepped (detector.py:111-112).
+    And on the synchronous path an incomplete batch is NOT re-run frame by frame."""
+    import pytest
+    from watsor_amd._lib import RowsIncomplete
+
+    class Overflowing(ScriptedDetector):
+        def collect(self, lane, detections):
+            super().collect(lane, detections)
+            raise RowsIncomplete("frame 1 of the batch on lane %d: rows may be incomplete" % lane)
+
+    _, cams = setup()
+    det, w = Overflowing(), Worker()
+    fps, it = drive(w, det, cams, [[shm.Payload("cam%d" % c, 0) for c in range(3)]], hip_lanes=2, hip_metric_interval=0)
+    assert fps.count.value == 3 and all(cams["cam%d" % c].frames[0].latch.steps.value == 1 for c in range(3))
+    assert first_row(cams["cam1"].frames[0])[0] == 11                     # the rows are there
+
+    class Broken(ScriptedDetector):
+        def collect(self, lane, detections):
+            self.busy.pop(lane)
+            raise ValueError("wz_collect_bound: lane %d holds no bound batch" % lane)
+
+    _, cams = setup()
+    det, w = Broken(), Worker()
+    with pytest.raises(ValueError, match="no bound batch"):
+        drive(w, det, cams, [[shm.Payload("cam%d" % c, 0) for c in range(3)]], hip_lanes=2, hip_metric_interval=0)
+    assert all(cams["cam%d" % c].frames[0].latch.steps.value == 1 for c in range(3))   # released all the same
+
+    class SyncOverflowing(ScriptedDetector):
+        def detect_batch(self, shapes, images, detections, cameras=None):
+            super().detect_batch(shapes, images, detections, cameras)
+            raise RowsIncomplete("frame 0: rows may be incomplete")
+
+    _, cams = setup()
+    det, w = SyncOverflowing(), Worker()
+    ctx = shm.spawn_context()
+    fps, it = shm.Gauge(ctx), shm.Gauge(ctx)
+    w._next_frames([shm.Payload("cam%d" % c, 1) for c in range(3)], None, cams, fps, it, det)
+    assert [e for e in det.log if e[0] == "sync"] == [("sync", 3)]         # one batched call, no frame-by-frame retry
+    assert fps.count.value == 3 and all(cams["cam%d" % c].frames[1].latch.steps.value == 1 for c in range(3))

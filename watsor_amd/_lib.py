@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libwatsor_hip.so")
 # tools at a measurement build of it (e.g. one compiled with -DWZ_HP_STAMPS=1)
 DEV_LIB_PATH = os.environ.get("WATSOR_HIP_DEV_LIBRARY") or os.path.join(_HERE, "libwatsor_hip_dev.so")
 
-WZ_OK, WZ_EINVAL, WZ_ENOENT, WZ_EFORMAT, WZ_EHIP, WZ_ENODEV, WZ_ELIMIT = 0, -1, -2, -3, -4, -5, -6
+WZ_OK, WZ_EINVAL, WZ_ENOENT, WZ_EFORMAT, WZ_EHIP, WZ_ENODEV, WZ_ELIMIT, WZ_EINCOMPLETE = 0, -1, -2, -3, -4, -5, -6, -7
 WZ_SLOTS = 8
 WZ_FMT_RGB24, WZ_FMT_NV12, WZ_FMT_I420 = 0, 1, 2
 WZ_NUM_LABELS = 91
@@ -114,6 +114,11 @@ class HipLibraryMissing(ImportError):
     pass
 
 
+class RowsIncomplete(ValueError):
+    """WZ_EINCOMPLETE: the call wrote every row, but a frame's rows may be short (clip-after-NMS engines).  The ONLY failure after
+    which the rows are valid: callers that must tell "rows written" from "rows not written" catch this class, not ValueError."""
+
+
 def _open(path, signatures):
     if not os.path.isfile(path):
         raise HipLibraryMissing(
@@ -157,6 +162,8 @@ def check(rc: int, what: str = "", lib=None) -> None:
     msg = last_error(lib) or what
     if rc == WZ_ENOENT:
         raise FileNotFoundError(msg)
+    if rc == WZ_EINCOMPLETE:
+        raise RowsIncomplete(msg)
     if rc in (WZ_EINVAL, WZ_ELIMIT):
         raise ValueError(msg)
     if rc == WZ_EFORMAT:

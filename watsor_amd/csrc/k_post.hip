@@ -288,7 +288,7 @@ __device__ __forceinline__ float4_t wz_norm_box(const float4_t b, float& area) {
 }
 
 #define NMS_THREADS 1024
-#define NMS_KEEP_MAX 128   // >= max_total (100)
+#define NMS_KEEP_MAX WZ_NMS_KEEP_MAX   // >= max_total (100); wz_common.h (the engine's overflow message quotes it)
 #define NMS_CHUNK 256     // candidates per parallel suppression pass (4 per lane of the scanning wave)
 #define NMS_RANK_MAX 1536  // up to here an O(n^2/threads) rank sort beats the barrier-bound bitonic network
 

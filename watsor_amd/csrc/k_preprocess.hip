@@ -59,8 +59,9 @@ __device__ __forceinline__ void wz_fetch_row_pair(const WzFrameDesc& f, int x_lo
         const size_t off = ((size_t)y * f.w + x_lo) * 3;
         const size_t base = off & ~(size_t)3;
         if (base + 12 <= (size_t)f.w * f.h * 3 && ((uintptr_t)f.rgb & 3) == 0) {
-            typedef __attribute__((ext_vector_type(3))) unsigned int u3;
-            const u3 v = *reinterpret_cast<const u3*>(f.rgb + base);
+            typedef __attribute__((ext_vector_type(3))) unsigned int u3;   // (natural alignment 16; the address is only 4-byte aligned:
+            u3 v;                                                          //  memcpy states that, and still compiles to one 12-byte load)
+            __builtin_memcpy(&v, __builtin_assume_aligned(f.rgb + base, 4), 12);
             const unsigned sh = (unsigned)(off - base) * 8;                       // 0, 8, 16 or 24
             const unsigned long long lo64 = ((unsigned long long)v[1] << 32) | v[0];
             const unsigned long long hi64 = ((unsigned long long)v[2] << 32) | v[1];

@@ -253,6 +253,7 @@ int wz_launch_mbconv_hp(const WzMbArgs& a, int n, hipStream_t s, bool prepare); 
 
 #define WZ_HIST_BINS 1024
 #define WZ_CAND_CAP 4096
+#define WZ_NMS_KEEP_MAX 128   // capacity of the NMS walk's kept list (k_post.hip); >= max_total (100)
 #define WZ_CAND_TARGET 192
 struct WzPostBuffers {
     const float* box_enc;     // [n][A][4]

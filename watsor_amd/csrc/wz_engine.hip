@@ -1110,8 +1110,8 @@ static int lane_status(wz_engine* e, int slot) {
     const Lane& L = e->lanes[slot];
     for (int i = 0; i < L.n; ++i)
         if (L.h_status && L.h_status[i])
-            return wz_fail(WZ_ELIMIT, "frame %d of the batch on lane %d: more than %d selected boxes lie entirely outside the image, "
-                                      "its rows may be incomplete", i, slot, 128 - (int)e->hdr.max_total);
+            return wz_fail(WZ_EINCOMPLETE, "frame %d of the batch on lane %d: more than %d selected boxes lie entirely outside the image, "
+                                           "its rows may be incomplete", i, slot, WZ_NMS_KEEP_MAX - (int)e->hdr.max_total);
     return WZ_OK;
 }
 
@@ -1172,11 +1172,11 @@ extern "C" int wz_detect_batch_fmt(wz_engine_t* e, int n, const uint8_t* const* 
     int rc = wz_submit_device_fmt(e, 0, n, dptr.data(), w, h, fmt, cam);
     if (rc != WZ_OK) return rc;
     rc = wz_collect(e, 0, out, pass);
-    if (rc != WZ_OK) return rc;
+    if (rc != WZ_OK && rc != WZ_EINCOMPLETE) return rc;
     const float el = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (ms)
         for (int i = 0; i < n; ++i) ms[i] = el;
-    return WZ_OK;
+    return rc;   // WZ_OK, or WZ_EINCOMPLETE: the rows are written (and timed), one frame's may be short
 }
 
 // ------------------------------------------------------------------------------------------------

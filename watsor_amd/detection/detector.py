@@ -43,6 +43,7 @@ from time import perf_counter
 
 from numpy import uint8
 
+from watsor_amd._lib import RowsIncomplete
 from watsor_amd.detection.devices import hip_gpus
 from watsor_amd.detection.hip_gpu import ENGINE_FILE
 
@@ -163,6 +164,11 @@ class BatchedWorkerMixin:
                         inference_time(value=time_of_inference / len(frames))
                         fps(value=True)
                     done = True
+                except RowsIncomplete as e:       # rows written (and complete for every frame but the one named): no retry
+                    self._warn("batch of %d frames: %s" % (len(frames), e))
+                    for _ in frames:
+                        fps(value=True)
+                    done = True
                 except ValueError as e:           # a frame the engine cannot take (size): the others still get detected
                     self._warn("batch of %d frames rejected (%s), retrying frame by frame" % (len(frames), e))
             if not done:
@@ -178,10 +184,15 @@ class BatchedWorkerMixin:
     def _detect_one(self, st, payload, frame, fps, inference_time, object_detector):
         image_shape, image_np = frame.get_numpy_image(uint8)
         cams = self._camera_ids(st, [payload])
-        if cams is not None and hasattr(object_detector, "detect_batch"):
-            t = object_detector.detect_batch([image_shape], [image_np], [frame.header.detections], cameras=cams)
-        else:
-            t = object_detector.detect(image_shape, image_np, frame.header.detections)
+        try:
+            if cams is not None and hasattr(object_detector, "detect_batch"):
+                t = object_detector.detect_batch([image_shape], [image_np], [frame.header.detections], cameras=cams)
+            else:
+                t = object_detector.detect(image_shape, image_np, frame.header.detections)
+        except RowsIncomplete as e:               # the rows were written (possibly fewer than the frame deserves): it counts
+            self._warn("frame of %s: %s" % (payload.sender, e))
+            fps(value=True)
+            return
         inference_time(value=t)
         fps(value=True)
 
@@ -246,8 +257,8 @@ class BatchedWorkerMixin:
                     object_detector.collect_bound(lane)
                 else:
                     object_detector.collect(lane, [f.header.detections for f in frames])
-            except ValueError as e:               # the rows were written; the engine says what is wrong with them
-                self._warn("batch of %d frames: %s" % (len(latches), e))
+            except RowsIncomplete as e:           # the rows WERE written; the engine says what is wrong with them.  Any other
+                self._warn("batch of %d frames: %s" % (len(latches), e))   # failure (rows not written) propagates: detector.py:99-100
             now = perf_counter()
             # the batch's SERVICE time: from its submit, or from the previous retirement when it was queued behind another
             # lane's batch until then -- what `fps_max = 1000 / inference_time` (watsor/main.py:242-251) should be derived from

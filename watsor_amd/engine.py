@@ -62,6 +62,10 @@ def apply_graph_settings(settings: dict, model_width: int, model_height: int, po
                 if key in post:
                     post[key] = float(np.float32(post[key]))
             adopt(post, key, v, what)
+    if "box_scales_ambiguous" in settings and "box_scales" not in settings:
+        import warnings
+        warnings.warn("the graph's box-coder scale factors could not be read unambiguously (%r): keeping %r"
+                      % (settings["box_scales_ambiguous"], tuple(post.get("scales", (10.0, 10.0, 5.0, 5.0)))))
     if "box_scales" in settings:
         sc = tuple(float(x) for x in settings["box_scales"])
         if len(sc) != 4 or min(sc) <= 0:
@@ -197,6 +201,7 @@ def assign_slots(prog: "arch.Program", tensor_names: List[str]) -> List[int]:
     slot_of[index["input"]] = 0
     slot_size.append(size["input"])
     for oi, op in enumerate(prog.ops):
+        never_read = []                                      # released only after ALL outputs of the op have their slots
         for out in ([op.dst, op.dst2] if op.out_mode == arch.OUT_ACT else []):
             if out is None:
                 continue
@@ -213,7 +218,8 @@ def assign_slots(prog: "arch.Program", tensor_names: List[str]) -> List[int]:
                 slot_size[best] = max(slot_size[best], need)
             slot_of[index[out]] = best
             if last_use[out] < 0:                            # never read (cannot happen in this graph)
-                free.append(best)
+                never_read.append(best)
+        free.extend(never_read)
         for n in {op.src, op.res} - {None}:
             if last_use[n] == oi:
                 free.append(slot_of[index[n]])

@@ -315,6 +315,13 @@ def graph_settings(g: Graph) -> dict:
     for n in g.nodes.values():
         if n.op.startswith("NonMaxSuppression") and len(n.inputs) >= 4:
             m, t = g.constant(n.inputs[2]), g.constant(n.inputs[3])
+            if m is None:                                        # `tf.minimum(max_size_per_class, boxlist.num_boxes())`: the constant side
+                mn = g.resolve(n.inputs[2])
+                if mn is not None and mn.op == "Minimum":
+                    for ref in mn.inputs:
+                        m = g.constant(ref)
+                        if m is not None:
+                            break
             if m is not None and m.size == 1:
                 per_class.append(int(m.reshape(-1)[0]))
             if t is not None and t.size == 1:
@@ -334,9 +341,25 @@ def graph_settings(g: Graph) -> dict:
     score = [s_ for s_ in score if s_ > -1e30]                  # (NonMaxSuppressionV3's default "-inf" filter is no filter)
     if score:
         out["score_threshold"] = _one(score, "score thresholds")
+    # max_total: the constant of the top-k / Minimum that consumes the CONCATENATED boxlist (sort_by_field + pad-or-clip behind the
+    # per-class loop).  The per-class `Minimum(max_size_per_class, num_boxes)` nodes sit in the same scope: constants that are an
+    # NMS node's max_output_size input are those and are left out, so a graph with max_detections_per_class != max_total_detections
+    # yields the total instead of "differ from node to node".
+    feeds_nms = set()                                            # nodes between an NMS node and the Const behind its max_output_size
+    for n in g.nodes.values():
+        if n.op.startswith("NonMaxSuppression") and len(n.inputs) >= 3:
+            todo, hops = [n.inputs[2]], 0
+            while todo and hops < 64:
+                node = g.nodes.get(todo.pop().split(":")[0].lstrip("^"))
+                hops += 1
+                if node is None or node.name in feeds_nms:
+                    continue
+                feeds_nms.add(node.name)
+                if node.op in ("Identity", "StopGradient", "Minimum", "Cast"):
+                    todo.extend(node.inputs)
     totals = []
     for n in g.nodes.values():
-        if "MultiClassNonMaxSuppression" in n.name and n.op in ("TopKV2", "Minimum") and len(n.inputs) == 2:
+        if "MultiClassNonMaxSuppression" in n.name and n.op in ("TopKV2", "Minimum") and len(n.inputs) == 2 and n.name not in feeds_nms:
             for ref in (n.inputs[1], n.inputs[0]):
                 k = g.constant(ref)
                 if k is not None and k.size == 1 and k.dtype == np.int64:
@@ -344,20 +367,53 @@ def graph_settings(g: Graph) -> dict:
                     break
     if totals:
         out["max_total"] = _one(totals, "maximum total detections")
-    scales = []
+    # box_scales: FasterRcnnBoxCoder._decode divides the four rows of the transposed, unstacked encodings by its scale factors
+    # (`ty /= 10.` ...) -- RealDiv nodes whose FIRST input is an output of that Unpack node; the output index says which of ty, tx,
+    # th, tw it is.  The same scope also divides by 2. (`h / 2.`, `w / 2.`: Decode/truediv_4 .. _7, and
+    # get_center_coordinates_and_sizes/truediv{,_1}): those read products / differences, not the unstack, and are no scale factors.
+    by_unstack = {}
     for n in g.nodes.values():
-        if "/Decode/" in "/" + n.name and n.op in ("RealDiv", "Div", "Mul") and len(n.inputs) == 2:
+        if "/Decode/" in "/" + n.name and n.op in ("RealDiv", "Div") and len(n.inputs) == 2:
             c = g.constant(n.inputs[1])
-            if c is not None and c.size == 1 and c.dtype == np.float32 and g.constant(n.inputs[0]) is None:
-                v = float(c.reshape(-1)[0])
-                if n.op == "Mul":
-                    if v == 0.0 or v in (0.5, 2.0):            # (half-extent arithmetic of the decoder, not a scale factor)
+            src = g.resolve(n.inputs[0])
+            if c is not None and c.size == 1 and c.dtype == np.float32 and src is not None and src.op == "Unpack" \
+                    and "get_center_coordinates_and_sizes" not in n.name:
+                ref = n.inputs[0]
+                hops = 0
+                while hops < 16:                                  # the output index survives Identity nodes in between
+                    node = g.nodes.get(ref.split(":")[0])
+                    if node is None or node.op not in ("Identity", "StopGradient"):
+                        break
+                    ref = node.inputs[0]
+                    hops += 1
+                idx = int(ref.split(":")[1]) if ":" in ref else 0
+                by_unstack.setdefault(idx, []).append(float(c.reshape(-1)[0]))
+    if by_unstack:
+        if sorted(by_unstack) == [0, 1, 2, 3] and all(len(set(v)) == 1 for v in by_unstack.values()):
+            out["box_scales"] = tuple(round(by_unstack[i][0], 6) for i in range(4))
+        else:
+            out["box_scales_ambiguous"] = {k: sorted(set(v)) for k, v in by_unstack.items()}
+    else:
+        # graphs whose decoder does not read an Unpack node (other exporters): by name, leaving out what cannot be a scale factor
+        scales = []
+        for n in g.nodes.values():
+            if "/Decode/" in "/" + n.name and n.op in ("RealDiv", "Div", "Mul") and len(n.inputs) == 2 \
+                    and "get_center_coordinates_and_sizes" not in n.name:
+                c = g.constant(n.inputs[1])
+                if c is not None and c.size == 1 and c.dtype == np.float32 and g.constant(n.inputs[0]) is None:
+                    v = float(c.reshape(-1)[0])
+                    if v == 0.0 or v in (0.5, 2.0):                # (half-extent arithmetic of the decoder, not a scale factor)
                         continue
-                    v = 1.0 / v
-                scales.append((n.op != "Mul", _index_of(n.name), n.name, v))
-    if scales:
-        divs = sorted(x for x in scales if x[0]) or sorted(scales)
-        out["box_scales"] = tuple(round(x[3], 6) for x in sorted(divs, key=lambda x: (x[1], x[2])))
+                    if n.op == "Mul":
+                        v = 1.0 / v
+                    scales.append((n.op != "Mul", _index_of(n.name), n.name, v))
+        if scales:
+            divs = sorted(x for x in scales if x[0]) or sorted(scales)
+            vals = tuple(round(x[3], 6) for x in sorted(divs, key=lambda x: (x[1], x[2])))
+            if len(vals) == 4:
+                out["box_scales"] = vals
+            else:
+                out["box_scales_ambiguous"] = {"by_name": list(vals)}
     vecs = [n.value.astype(np.float32) for n in g.nodes.values()
             if n.op == "Const" and "AnchorGenerator" in n.name and n.value is not None and n.value.dtype == np.float32
             and n.value.ndim == 1 and 2 <= n.value.size <= 16]

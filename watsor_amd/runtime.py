@@ -51,6 +51,7 @@ class HipEngine:
         self.num_slots = self._lib.wz_num_slots(self._h)
         self.hp_blocks = self._lib.wz_hp_blocks(self._h)   # leading blocks with split (hi + lo) matrix operands
         self._dev_allocs: List[int] = []
+        self._bound_arrays = {}                            # (submit_bound before any bind_frames: the engine's EINVAL, not an AttributeError)
 
     def _ck(self, rc: int, what: str = "") -> None:
         if rc:
