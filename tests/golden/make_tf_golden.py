@@ -37,6 +37,19 @@ OPTIONAL = {
 }
 
 
+def collect(frames, run, meta):
+    """The arrays of the golden file: `run(frame)` -> {tensor key: array} for every (width, height, seed) of `frames`.  Shared by the
+    TensorFlow route below and by the self-test of tests/test_tf_golden.py, which feeds it the ORACLE's outputs so that the file
+    format and the comparison code are exercised in every CI run, not first on the day TensorFlow shows up."""
+    from watsor_amd.synth import synthetic_frame
+    out = {"frames": np.array(frames, np.int32)}
+    out.update({k: np.array(v) for k, v in meta.items()})
+    for i, (w, h, seed) in enumerate(frames):
+        for k, v in run(synthetic_frame(w, h, seed)).items():
+            out["f%d_%s" % (i, k)] = np.asarray(v)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--pb", required=True)
@@ -44,7 +57,6 @@ def main():
     args = ap.parse_args()
     import tensorflow as tf
     tf1 = tf.compat.v1 if hasattr(tf, "compat") and hasattr(tf.compat, "v1") else tf
-    from watsor_amd.synth import synthetic_frame
 
     graph = tf.Graph()
     with graph.as_default():                                       # tensorflow_cpu.py:50-62
@@ -62,14 +74,9 @@ def main():
                 fetch[key] = graph.get_tensor_by_name(c + ":0")
                 found[key] = c
                 break
-    out = {"frames": np.array(FRAMES, np.int32), "tf_version": np.array(tf.__version__),
-           "pb_sha256": np.array(hashlib.sha256(blob).hexdigest()), "optional_tensor_names": np.array(repr(found))}
+    meta = {"tf_version": tf.__version__, "pb_sha256": hashlib.sha256(blob).hexdigest(), "optional_tensor_names": repr(found)}
     with tf1.Session(graph=graph) as sess:
-        for i, (w, h, seed) in enumerate(FRAMES):
-            frame = synthetic_frame(w, h, seed)
-            res = sess.run(fetch, feed_dict={graph.get_tensor_by_name("image_tensor:0"): frame[None]})
-            for k, v in res.items():
-                out["f%d_%s" % (i, k)] = np.asarray(v)
+        out = collect(FRAMES, lambda frame: sess.run(fetch, feed_dict={graph.get_tensor_by_name("image_tensor:0"): frame[None]}), meta)
     np.savez_compressed(args.out, **out)
     print("wrote %s (%d arrays; intermediates found: %s)" % (args.out, len(out), found))
 

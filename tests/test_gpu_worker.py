@@ -149,3 +149,23 @@ def test_spawned_worker_takes_nv12_frame_buffers(model_dir, asynchronous):
             assert yard["y_max"].max() <= 719 and yard["x_max"].max() <= 1279 and yard["confidence"][0] > 0
     finally:
         e.close()
+
+
+def test_two_workers_share_one_queue_and_one_gpu(model_dir):
+    """The reference's multi-device topology (`watsor/main.py:414-418`: every detector process pulls from the same `BalancedQueue`)
+    with two `BatchedWorkerMixin` worker PROCESSES, here sharing the one GPU of the box: both page-lock and bind the same
+    shared-memory frames, each drains up to max_batch payloads per turn.  Every dequeued payload is latched exactly once and
+    counted once, both workers get work, no camera is starved, and the rows in shared memory are real detections.
+    (CPU twin with the reference's own queue / sources / sieves: tests/test_two_workers_one_queue.py.)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import worker_bench
+    r = worker_bench.run(model_dir, n_cams=8, seconds=1.5, workers=2, gpus=1, costly=False, check=True, max_batch=4, warm_frames=20)
+    print("\ntwo workers, one queue, one GPU: %s" % r)
+    c = r["check"]
+    assert c["latch_steps"] == c["fps_calls"] == c["worker_frames"] > 1000
+    assert len(r["per_worker"]) == 2 and all(w["frames"] > 0.15 * c["worker_frames"] for w in r["per_worker"]), r["per_worker"]
+    per_cam = c["per_camera_steps"]
+    assert min(per_cam) > 0 and max(per_cam) <= 1.5 * min(per_cam) + 20, per_cam
+    assert c["rows_written"] == c["frames_total"]                  # every frame of every camera carries detections

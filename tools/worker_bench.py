@@ -10,7 +10,11 @@ real `multiprocessing.Queue` under the reference's one-queued-frame-per-camera r
 stand-ins of tests/shm_standins.py that take the same locks in the same order as the reference's classes (their per-call cost is
 held against the reference's in tests/test_reference_plumbing.py).
 
-    python tools/worker_bench.py [cameras] [seconds]          # prints one JSON object
+Several workers on ONE queue -- the reference's multi-device topology (`watsor/main.py:414-418`: every detector process gets the
+same `BalancedQueue`) -- with `workers=N`: N spawned worker processes, worker i on GPU `i % gpus`, i.e. `--workers 2 --gpus 1` is
+two workers sharing one GPU, `--workers 8 --gpus 8` one worker per GPU of a node.  Reported per worker and summed.
+
+    python tools/worker_bench.py [cameras] [seconds] [--workers N] [--gpus G] [--max-batch B]      # prints JSON objects
 """
 import json
 import os
@@ -90,7 +94,7 @@ class NullDetector:
         return 1.0
 
 
-def worker(model_dir, frame_buffers, q, sems, stop_event, fps, inference_time, result_q, kwargs, null_detector=False):
+def worker(model_dir, frame_buffers, q, sems, stop_event, fps, inference_time, result_q, kwargs, null_detector=False, device=0, tag=0):
     """`ObjectDetector._run` (`watsor/detection/detector.py:84-100`): plugin constructed in THIS process, then the spin loop."""
     try:
         import shm_standins as shm
@@ -106,7 +110,13 @@ def worker(model_dir, frame_buffers, q, sems, stop_event, fps, inference_time, r
             def _no_frame(self, *a, **k):
                 pass
 
-        acct = dict(c_time=0.0, c_calls=0)
+        acct = dict(c_time=0.0, c_calls=0, frames=0)
+        shared_fps = fps
+
+        def fps(value=None):                                       # this worker's own share of the (shared) frames/s gauge
+            if value is not None:
+                acct["frames"] += 1
+            return shared_fps(value=value)
 
         def timed(fn):
             def call(*a):
@@ -121,20 +131,19 @@ def worker(model_dir, frame_buffers, q, sems, stop_event, fps, inference_time, r
         bq = shm.BalancedQueueStandIn(q, sems)
         opts = hip_detector_options(frame_buffers, kwargs)
         w = Worker()
-        with HipObjectDetector(model_dir, 0, opts) as det:
+        with HipObjectDetector(model_dir, device, opts) as det:
             st = w._hip_state(frame_buffers, det, kwargs)          # binds cameras + frame table (what the first _process does)
             for name in ("submit_bound", "collect_bound", "submit_host", "collect"):
                 if hasattr(det, name):
                     setattr(det, name, timed(getattr(det, name)))
             result_q.put(("ready", det.device_name, st["table"] is not None, st["lanes"]))
             t0 = time.perf_counter()
-            n0 = fps.count.value
             while not stop_event.is_set():
                 w._process(bq, stop_event, frame_buffers, fps, inference_time, det, **kwargs)
             w.drain(fps, inference_time)
             wall = time.perf_counter() - t0
-            frames = fps.count.value - n0
-            result_q.put(("done", dict(wall_s=wall, frames=frames, c_time_s=acct["c_time"], c_calls=acct["c_calls"],
+            frames = acct["frames"]
+            result_q.put(("done", dict(tag=tag, device=device, wall_s=wall, frames=frames, c_time_s=acct["c_time"], c_calls=acct["c_calls"],
                                        python_us_per_frame=(wall - acct["c_time"]) / max(frames, 1) * 1e6,
                                        inside_library_us_per_frame=acct["c_time"] / max(frames, 1) * 1e6)))
     except Exception:
@@ -142,7 +151,7 @@ def worker(model_dir, frame_buffers, q, sems, stop_event, fps, inference_time, r
 
 
 def run(model_dir, n_cams=8, width=640, height=480, seconds=3.0, costly=True, lanes=4, frame_table=True, producers=2,
-        frames_per_buffer=4, max_batch=8, null_detector=False, warm_frames=40):
+        frames_per_buffer=4, max_batch=8, null_detector=False, warm_frames=40, workers=1, gpus=1, check=False):
     """-> dict(value=frames/s over a `seconds` window of the running worker, p50_ms enqueue -> latch, python_us_per_frame, ...)."""
     import numpy as np
     import shm_standins as shm
@@ -162,20 +171,24 @@ def run(model_dir, n_cams=8, width=640, height=480, seconds=3.0, costly=True, la
     sems = {name: ctx.BoundedSemaphore(1) for name in cams}
     stop, result_q = ctx.Event(), ctx.Queue()
     kwargs = dict(hip_lanes=lanes, hip_frame_table=frame_table, hip_options={"max_batch": max_batch})
-    wp = ctx.Process(target=worker, args=(model_dir, cams, q, sems, stop, fps, it, result_q, kwargs, null_detector))
-    wp.start()
+    wps = [ctx.Process(target=worker, args=(model_dir, cams, q, sems, stop, fps, it, result_q, kwargs, null_detector, k % max(gpus, 1), k))
+           for k in range(workers)]
+    for wp in wps:
+        wp.start()
     procs = []
     try:
-        msg, t_give_up = None, time.time() + 300
-        while msg is None:                                  # (a worker that died while starting says nothing)
-            try:
-                msg = result_q.get(timeout=1)
-            except pyqueue.Empty:
-                if not wp.is_alive() or time.time() > t_give_up:
-                    raise RuntimeError("worker process did not come up (exit code %r)" % (wp.exitcode,))
-        if msg[0] != "ready":
-            raise RuntimeError(msg[1])
-        _, device, table, eff_lanes = msg
+        t_give_up = time.time() + 300
+        for _ in wps:
+            msg = None
+            while msg is None:                              # (a worker that died while starting says nothing)
+                try:
+                    msg = result_q.get(timeout=1)
+                except pyqueue.Empty:
+                    if not all(wp.is_alive() for wp in wps) or time.time() > t_give_up:
+                        raise RuntimeError("a worker process did not come up (exit codes %r)" % ([wp.exitcode for wp in wps],))
+            if msg[0] != "ready":
+                raise RuntimeError(msg[1])
+            _, device, table, eff_lanes = msg
         names = sorted(cams)
         for k in range(producers):
             ready = ctx.Event()
@@ -195,12 +208,19 @@ def run(model_dir, n_cams=8, width=640, height=480, seconds=3.0, costly=True, la
         lat = np.array(samples[1:1 + min(nsamp, 4096)], dtype=np.float64) * 1e3
     finally:
         stop.set()
-    done = result_q.get(timeout=120)
+    dones = [result_q.get(timeout=120) for _ in wps]
     for p in procs:
         p.join(30)
-    wp.join(60)
-    if done[0] != "done":
-        raise RuntimeError(done[1])
+    for wp in wps:
+        wp.join(60)
+    for d in dones:
+        if d[0] != "done":
+            raise RuntimeError(d[1])
+    dones.sort(key=lambda d: d[1]["tag"])
+    tot = {k: sum(d[1][k] for d in dones) for k in ("frames", "c_time_s", "c_calls")}
+    done = ("done", dict(frames=tot["frames"], c_calls=tot["c_calls"],
+                         python_us_per_frame=sum(d[1]["python_us_per_frame"] * d[1]["frames"] for d in dones) / max(tot["frames"], 1),
+                         inside_library_us_per_frame=sum(d[1]["inside_library_us_per_frame"] * d[1]["frames"] for d in dones) / max(tot["frames"], 1)))
     out = dict(value=round((c1 - c0) / (t1 - t0), 1), unit="frames/s", cameras=n_cams, frame="%dx%d" % (width, height),
                window_s=round(t1 - t0, 3), worker_lanes=eff_lanes, frame_table=bool(table), producers=producers,
                p50_ms_enqueue_to_latch=round(float(np.median(lat)), 3) if lat.size else None,
@@ -212,6 +232,19 @@ def run(model_dir, n_cams=8, width=640, height=480, seconds=3.0, costly=True, la
                inference_time_observations=int(it.count.value), frames_seen=int(fps.count.value),
                runtime_objects="stand-ins with the reference's locking (tests/shm_standins.py: Costly*)" if costly else "light stand-ins",
                device=device)
+    if workers > 1:
+        out.update(workers=workers, gpus=gpus, max_batch=max_batch,
+                   per_worker=[dict(worker=d[1]["tag"], gpu=d[1]["device"], frames=d[1]["frames"],
+                                    frames_per_s=round(d[1]["frames"] / max(d[1]["wall_s"], 1e-9), 1)) for d in dones])
+    elif max_batch != 8:
+        out["max_batch"] = max_batch
+    if check:
+        # every dequeued payload latched exactly once and counted once; per camera, how many of its frames went through
+        steps = {name: sum(int(f.latch.steps.value) for f in fb.frames) for name, fb in cams.items()}
+        out["check"] = dict(latch_steps=sum(steps.values()), fps_calls=int(fps.count.value), worker_frames=tot["frames"],
+                            per_camera_steps=[steps[n] for n in sorted(steps)],
+                            rows_written=sum(1 for fb in cams.values() for f in fb.frames if f.header.get_obj().detections[0].label >= 1),
+                            frames_total=sum(len(fb.frames) for fb in cams.values()))
     if null_detector:
         out["invalid"] = "harness self-test: no detector behind the worker"
     return out
@@ -220,10 +253,17 @@ def run(model_dir, n_cams=8, width=640, height=480, seconds=3.0, costly=True, la
 if __name__ == "__main__":
     from watsor_amd import engine
     from watsor_amd.synth import synthetic_weights
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-    secs = float(sys.argv[2]) if len(sys.argv) > 2 else 3.0
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("cameras", nargs="?", type=int, default=8)
+    ap.add_argument("seconds", nargs="?", type=float, default=3.0)
+    ap.add_argument("--workers", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--max-batch", type=int, default=8)
+    a = ap.parse_args()
     d = "/tmp/wz_worker_bench_%d" % os.getpid()
     os.makedirs(d, exist_ok=True)
     engine.save_engine(engine.build_engine(synthetic_weights(1234)), os.path.join(d, "mi355x.bin"))
-    for table in (True, False):
-        print(json.dumps(run(d, n, seconds=secs, frame_table=table)), flush=True)
+    for table in ((True, False) if a.workers == 1 else (True,)):
+        print(json.dumps(run(d, a.cameras, seconds=a.seconds, frame_table=table, workers=a.workers, gpus=a.gpus,
+                             max_batch=a.max_batch)), flush=True)
