@@ -30,6 +30,9 @@ def test_two_ranks_over_gloo():
                "--warmup", "4", "--dry-run"])
     assert out["n_gpus"] == 2
     assert out["camera_seeds"] == [1234, 2234]        # every rank serves its own camera (cameras are the shard)
+    # the host-side legs run on EVERY rank at the same time when N > 1 and come back per rank and summed (stubbed in a dry run)
+    leg = out["legs_all_ranks_concurrently"]["host_frames_pinned_b8"]
+    assert leg["per_rank"] == [1000.0, 1001.0] and leg["sum"] == 2001.0 and leg["min"] == 1000.0
     single = run([sys.executable, "bench.py", "--gpus", "1", "--steps", "40", "--warmup", "4", "--dry-run"])
     # whole-job aggregate = frames of all ranks / max over ranks of each rank's OWN clock (stopped after its device synchronize,
     # before the gloo barrier): two replicas are worth two, within 10 %

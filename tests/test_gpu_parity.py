@@ -382,13 +382,15 @@ def test_row_fill_bit_exact(eng, head_outputs, wh):
 
 def test_detect_end_to_end_matches_oracle_detector(model_dir, synth_weights, frames_640):
     """`detect()` through the plugin class on full-resolution frames vs the oracle plugin: the north star's tolerance
-    (|dscore| <= 1e-3 on every matched detection row) on 9 frames over 640x480 / 1280x720 / 1920x1080, for the engine
-    `bench.py` times."""
+    (|dscore| <= 1e-3 on every matched detection row, boxes within `box_tolerance_px`, no unexplained row) on 9 frames over
+    640x480 / 1280x720 / 1920x1080, for the engine `bench.py` times."""
     from watsor_amd.detection.hip_gpu import HipObjectDetector
     from watsor_amd.share import DetectionArray
     oracle = odet.OracleObjectDetector(weights=synth_weights)
     frames = list(frames_640[:3]) + [synthetic_frame(1280, 720, 2000 + i) for i in range(3)] + \
         [synthetic_frame(1920, 1080, 3000 + i) for i in range(3)]
+    from oracle.compare import assert_rows_match
+    worst_px = {}
     with HipObjectDetector(model_dir, 0) as det:
         assert "gfx950" in det.device_name or "MI3" in det.device_name
         for f in frames:
@@ -400,13 +402,13 @@ def test_detect_end_to_end_matches_oracle_detector(model_dir, synth_weights, fra
             got = np.frombuffer(rows, dtype=ROW_DTYPE)
             b, c, s, _, _ = oracle.raw(f)
             ref = odet.rows_as_array(f.shape, b, c, s)
-            pairs, missing = pu.match_rows(got, ref, min_score=0.1)
-            n_ref = int((ref["confidence"] > 0.1).sum())
-            assert n_ref > 0 and len(missing) <= max(1, n_ref // 20), (n_ref, missing)
-            assert max(abs(p[3]) for p in pairs) <= SCORE_TOL
-            every, _ = pu.match_rows(got, ref, min_score=0.0)          # ... and on every row that has a partner at all
-            assert len(every) >= 90 and max(abs(p[3]) for p in every) <= SCORE_TOL
+            # all 100 rows: scores within 1e-3, every box coordinate within the stated pixel tolerance of the frame size, and every
+            # row without a partner explained by the score tolerance itself (top-100 cut / NMS tie) -- oracle/compare.py
+            r = assert_rows_match(got, ref, f.shape, tol=SCORE_TOL, what="%dx%d" % (f.shape[1], f.shape[0]))
+            assert len(r["pairs"]) >= 90
+            worst_px[f.shape[1]] = max(worst_px.get(f.shape[1], 0), r["max_dbox_px"])
             assert got["label"][0] == ref_rows[0].label
+    print("\nmax |dbox| by frame width: %s px" % worst_px)
 
 
 @pytest.mark.parametrize("seed", [77, 4242])

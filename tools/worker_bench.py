@@ -151,7 +151,7 @@ def worker(model_dir, frame_buffers, q, sems, stop_event, fps, inference_time, r
 
 
 def run(model_dir, n_cams=8, width=640, height=480, seconds=3.0, costly=True, lanes=4, frame_table=True, producers=2,
-        frames_per_buffer=4, max_batch=8, null_detector=False, warm_frames=40, workers=1, gpus=1, check=False):
+        frames_per_buffer=4, max_batch=8, null_detector=False, warm_frames=40, workers=1, gpus=1, check=False, device=0):
     """-> dict(value=frames/s over a `seconds` window of the running worker, p50_ms enqueue -> latch, python_us_per_frame, ...)."""
     import numpy as np
     import shm_standins as shm
@@ -171,7 +171,7 @@ def run(model_dir, n_cams=8, width=640, height=480, seconds=3.0, costly=True, la
     sems = {name: ctx.BoundedSemaphore(1) for name in cams}
     stop, result_q = ctx.Event(), ctx.Queue()
     kwargs = dict(hip_lanes=lanes, hip_frame_table=frame_table, hip_options={"max_batch": max_batch})
-    wps = [ctx.Process(target=worker, args=(model_dir, cams, q, sems, stop, fps, it, result_q, kwargs, null_detector, k % max(gpus, 1), k))
+    wps = [ctx.Process(target=worker, args=(model_dir, cams, q, sems, stop, fps, it, result_q, kwargs, null_detector, device + k % max(gpus, 1), k))
            for k in range(workers)]
     for wp in wps:
         wp.start()

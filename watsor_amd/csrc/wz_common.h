@@ -166,8 +166,11 @@ static inline bool wz_latency_schedule() {
 struct WzDescPack { WzFrameDesc d[WZ_DESC_PACK]; };   // frame descriptors as kernel arguments (512 bytes)
 // keep, half_pixel, by_value (host descriptors to pass as kernel arguments when n <= WZ_DESC_PACK): see k_preprocess.hip
 void wz_launch_preprocess(const WzFrameDesc* d_frames, int n, int size, half_t* out, hipStream_t s, bool hp = false,
-                          WzFrameDesc* keep = nullptr, bool half_pixel = false, const WzFrameDesc* by_value = nullptr);
-const void* wz_preprocess_func(bool hp);   // the kernel's host-side address (to find its node in a captured graph)
+                          WzFrameDesc* keep = nullptr, bool half_pixel = false, const WzFrameDesc* by_value = nullptr, int rows_lds = 0);
+// rows_lds > 0: the row-staged form of the kernel (one workgroup per output row, `rows_lds` bytes of LDS = wz_preprocess_rows_lds(widest frame))
+size_t wz_preprocess_rows_lds(int max_w);
+int wz_preprocess_rows_threads();
+const void* wz_preprocess_func(bool hp, bool rows = false);   // the kernel's host-side address (to find its node in a captured graph)
 void wz_launch_stem(const half_t* in, const float* w, const float* bias, half_t* out, int n, int hin, int win,
                     int hout, int wout, int pad_t, int pad_l, hipStream_t s);
 void wz_launch_dw(const half_t* in, const half_t* w, const float* bias, half_t* out, int n, int hin, int win,

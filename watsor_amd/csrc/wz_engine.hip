@@ -82,6 +82,12 @@ struct wz_engine {
     bool tail_fuse = false;       // WZ_TAIL_FUSE=1: the convolutions on the <= 32-pixel maps in one launch (k_tail.hip); measured slower, off
     bool desc_by_value = true;    // the frame descriptors travel as arguments of the resize kernel (WZ_DESC_ARGS=0: zero-copy / copied)
     bool desc_zero_copy = true;   // the resize kernel reads the frame descriptors from page-locked host memory (WZ_DESC_COPY=1: copied first)
+    bool pre_rows = false;        // the resize kernel in its row-staged form (k_preprocess.hip: wz_k_preprocess_rows)
+    int pre_rows_lds = 0;         // ... and its LDS bytes for the widest frame this engine takes
+    int host_read = 0;            // page-locked host frames: 0 = staged by one DMA each, 1 = read in place by the resize kernel (no copy),
+                                  // 2 = read in place when the resize skips rows (down-scale >= 2 vertically), staged otherwise
+    struct HostRange { const uint8_t* host; uint64_t bytes; const uint8_t* dev; };
+    std::vector<HostRange> host_ranges;   // what wz_host_register page-locked, with the address the device sees it at
     int wide_cus = 128;        // CUs the wide head kernel's K slices are sized for when several lanes are in flight (WZ_WIDE_CUS)
     int num_cus = 256;         // compute units of the device (the wide head kernel sizes its K slices for one round over them)
     bool head_inline = false;  // WZ_HEAD_INLINE=1: ... or inside the head convolutions themselves, by each tile's last K slice.
@@ -155,6 +161,7 @@ struct wz_engine {
     // the worker's frame table (wz_bind_frames): one entry per Frame of every FrameBuffer, described once instead of once per batch
     struct BoundFrame {
         const uint8_t* host;   // the frame's pixels (host address)
+        const uint8_t* dev;    // the same bytes as the device sees them when the frame lies in a wz_host_register range, else nullptr
         int32_t w, h, fmt, cam;
         uint64_t bytes;
         wz_detection_t* rows;  // Header.detections of that frame (host), written by wz_collect_bound
@@ -573,7 +580,7 @@ static void enqueue_batch(wz_engine* e, Lane& L, int n, StageTimer* t, int inner
     wz_launch_repeat = inner;
     wz_launch_preprocess(zero_copy ? L.h_desc_dev : L.d_desc, n, (int)e->hdr.input_size, L.tptr[input_tensor_index(e)], s,
                          input_is_pair(e), (zero_copy || by_value) ? L.d_desc : nullptr, e->hdr.resize_mode == 1,
-                         by_value ? L.h_desc : nullptr);
+                         by_value ? L.h_desc : nullptr, e->pre_rows ? e->pre_rows_lds : 0);
     if (t) t->mark();
     enqueue_network(e, L, n, t);
     wz_launch_repeat = 1;
@@ -602,7 +609,7 @@ static int run_batch(wz_engine* e, int slot, int n) {
             if (hipGraphGetNodes(g, nullptr, &nodes) == hipSuccess) L.graph_nodes[n] = (int)nodes;
             if (e->desc_by_value && n <= WZ_DESC_PACK && nodes > 0) {   // the resize kernel's node: its arguments are this batch's descriptors
                 std::vector<hipGraphNode_t> all(nodes);
-                const void* want = wz_preprocess_func(input_is_pair(e));
+                const void* want = wz_preprocess_func(input_is_pair(e), e->pre_rows);
                 if (hipGraphGetNodes(g, all.data(), &nodes) == hipSuccess)
                     for (size_t k = 0; k < nodes; ++k) {
                         hipGraphNodeType ty;
@@ -637,9 +644,15 @@ static int run_batch(wz_engine* e, int slot, int n) {
             L.pre_kp[3] = &L.pre_out; L.pre_kp[4] = &L.pre_keep; L.pre_kp[5] = &L.pre_half_pixel;
             hipKernelNodeParams kp;
             memset(&kp, 0, sizeof(kp));
-            kp.func = const_cast<void*>(wz_preprocess_func(input_is_pair(e)));
-            kp.gridDim = dim3(((unsigned)L.pre_size * L.pre_size + 255) / 256, n);
-            kp.blockDim = dim3(256);
+            kp.func = const_cast<void*>(wz_preprocess_func(input_is_pair(e), e->pre_rows));
+            if (e->pre_rows) {
+                kp.gridDim = dim3((unsigned)L.pre_size, n);
+                kp.blockDim = dim3(wz_preprocess_rows_threads());
+                kp.sharedMemBytes = (unsigned)e->pre_rows_lds;
+            } else {
+                kp.gridDim = dim3(((unsigned)L.pre_size * L.pre_size + 255) / 256, n);
+                kp.blockDim = dim3(256);
+            }
             kp.kernelParams = L.pre_kp;
             HIPCHK(hipGraphExecKernelNodeSetParams(it->second, pn->second, &kp));
         }
@@ -798,6 +811,11 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     e->desc_zero_copy = !((env = wz_dev_getenv("WZ_DESC_COPY")) && atoi(env) != 0);
     e->desc_by_value = !((env = wz_dev_getenv("WZ_DESC_ARGS")) && atoi(env) == 0);
     e->tail_fuse = (env = wz_dev_getenv("WZ_TAIL_FUSE")) && atoi(env) != 0;
+    e->pre_rows = (env = wz_dev_getenv("WZ_PRE_ROWS")) ? atoi(env) != 0 : e->pre_rows;
+    e->host_read = (env = wz_dev_getenv("WZ_HOST_READ")) ? atoi(env) : e->host_read;
+    if (e->host_read) e->pre_rows = true;   // (in-place reads of host frames only pay in whole contiguous rows)
+    e->pre_rows_lds = (int)wz_preprocess_rows_lds(max_width);
+    if (e->pre_rows_lds > 60 * 1024) e->pre_rows = false, e->host_read = 0;   // (frames wider than ~10 k pixels: the per-pixel form)
     e->wide_T = (env = wz_dev_getenv("WZ_WIDE_T")) ? atoi(env) : 0;
     e->wide_min_m = (env = wz_dev_getenv("WZ_WIDE_MIN_M")) ? atoi(env) : 1;
     {
@@ -1188,6 +1206,19 @@ extern "C" int wz_detect_batch_fmt(wz_engine_t* e, int n, const uint8_t* const* 
 // 55 GB/s on its own, tools/micro/h2d_streams.hip, but only 23 GB/s beside the other lanes' kernels against the copies'
 // 29 GB/s; a fifth stream for the copies alone, so that whole batches arrive back to back: 24.8 k against 31.5 k frames/s at
 // 640x480 -- this stack runs four streams side by side, section 10 of DESIGN.md: profiles/r03_host_path_*.)
+// Where the device sees a page-locked host frame, or nullptr: inside a range wz_host_register locked (WzFrameDesc::rgb may then point
+// at the frame itself and the resize kernel reads its tap rows over PCIe, no staging copy -- `host_read`).
+static const uint8_t* device_view(wz_engine* e, const uint8_t* host, uint64_t bytes) {
+    for (const auto& r : e->host_ranges)
+        if (host >= r.host && host + bytes <= r.host + r.bytes) return r.dev ? r.dev + (host - r.host) : nullptr;
+    return nullptr;
+}
+// host_read policy for one frame: 1 = always in place, 2 = only when the vertical down-scale skips source rows (>= 2: at most half
+// of the rows are tapped; below that nearly every row is, some twice, and one DMA of the whole frame moves fewer bytes)
+static bool read_in_place(const wz_engine* e, int h) {
+    return e->host_read == 1 || (e->host_read == 2 && h >= 2 * (int)e->hdr.input_size);
+}
+
 static int stage_frame(wz_engine* e, Lane& L, int i, const uint8_t* host, uint64_t bytes, const uint8_t** where) {
     uint8_t* dst = L.d_frames + e->frame_stride * i;
     HIPCHK(hipMemcpyAsync(dst, host, bytes, hipMemcpyHostToDevice, L.stream));
@@ -1216,7 +1247,12 @@ extern "C" int wz_submit_host_fmt(wz_engine_t* e, int slot, int n, const uint8_t
                            e->max_w, e->max_h);
         const uint64_t bytes = wz_frame_bytes(w[i], h[i], fmt ? fmt[i] : WZ_FMT_RGB24);
         if (!bytes) return wz_fail(WZ_EINVAL, "frame %d: pixel format %d at %dx%d (NV12 / I420 need even sides)", i, fmt[i], w[i], h[i]);
-        // pageable source: the runtime stages it (slow, synchronous); registered / pinned source: one DMA
+        // pageable source: the runtime stages it (slow, synchronous); registered / pinned source: one DMA -- or no copy at all
+        const uint8_t* dv = read_in_place(e, h[i]) ? device_view(e, rgb[i], bytes) : nullptr;
+        if (dv) {
+            dptr[i] = dv;
+            continue;
+        }
         int rc = stage_frame(e, L, i, rgb[i], bytes, &dptr[i]);
         if (rc != WZ_OK) return rc;
     }
@@ -1230,13 +1266,28 @@ extern "C" int wz_submit_host_fmt(wz_engine_t* e, int slot, int n, const uint8_t
 extern "C" int wz_host_register(wz_engine_t* e, void* ptr, uint64_t bytes) {
     if (!e || !ptr || !bytes) return wz_fail(WZ_EINVAL, "wz_host_register: bad argument");
     HIPCHK(hipSetDevice(e->device));
-    HIPCHK(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    HIPCHK(hipHostRegister(ptr, bytes, hipHostRegisterMapped));
+    void* dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, ptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        dev = nullptr;                        // (not mapped on this platform: frames inside it are staged by DMA as before)
+    }
+    e->host_ranges.push_back({static_cast<const uint8_t*>(ptr), bytes, static_cast<const uint8_t*>(dev)});
+    for (auto& f : e->bound)                  // (a frame table bound before its memory was page-locked)
+        if (!f.dev) f.dev = device_view(e, f.host, f.bytes);
     return WZ_OK;
 }
 extern "C" int wz_host_unregister(wz_engine_t* e, void* ptr) {
     if (!e || !ptr) return wz_fail(WZ_EINVAL, "wz_host_unregister: bad argument");
     HIPCHK(hipSetDevice(e->device));
-    (void)sync_all(e);   // a copy in flight may still be reading the range
+    (void)sync_all(e);   // a copy (or a resize kernel reading in place) in flight may still be reading the range
+    for (size_t k = 0; k < e->host_ranges.size(); ++k)
+        if (e->host_ranges[k].host == ptr) {
+            e->host_ranges.erase(e->host_ranges.begin() + k);
+            break;
+        }
+    for (auto& f : e->bound)
+        if (f.dev && f.host >= static_cast<const uint8_t*>(ptr)) f.dev = device_view(e, f.host, f.bytes);   // (re-resolved: stale views must not survive)
     HIPCHK(hipHostUnregister(ptr));
     return WZ_OK;
 }
@@ -1262,7 +1313,7 @@ extern "C" int wz_bind_frames(wz_engine_t* e, int n, const uint8_t* const* pixel
         if (w[i] > e->max_w || h[i] > e->max_h || (size_t)w[i] * h[i] * 3 > e->frame_stride)
             return wz_fail(WZ_ELIMIT, "frame-table entry %d is %dx%d, engine was created for at most %dx%d", i, w[i], h[i], e->max_w, e->max_h);
         if (c >= WZ_MAX_CAMS) return wz_fail(WZ_ELIMIT, "camera id %d >= %d", c, WZ_MAX_CAMS);
-        tbl[i] = {pixels[i], w[i], h[i], pf, c < 0 ? -1 : c, bytes, rows[i]};
+        tbl[i] = {pixels[i], device_view(e, pixels[i], bytes), w[i], h[i], pf, c < 0 ? -1 : c, bytes, rows[i]};
     }
     for (int li = 0; li < e->n_lanes; ++li) e->lanes[li].bound_idx.clear();
     e->bound.swap(tbl);
@@ -1285,9 +1336,13 @@ extern "C" int wz_submit_bound(wz_engine_t* e, int slot, int n, const int32_t* e
     for (int i = 0; i < n; ++i) {
         const wz_engine::BoundFrame& f = e->bound[entries[i]];
         // (the filter of the frame's camera may have been set for another size since the table was built: fill_desc checks)
+        ws[i] = f.w; hs[i] = f.h; fmts[i] = f.fmt; cams[i] = f.cam;
+        if (f.dev && read_in_place(e, f.h)) {
+            dptr[i] = f.dev;
+            continue;
+        }
         int rc = stage_frame(e, L, i, f.host, f.bytes, &dptr[i]);
         if (rc != WZ_OK) return rc;
-        ws[i] = f.w; hs[i] = f.h; fmts[i] = f.fmt; cams[i] = f.cam;
     }
     int rc = fill_desc(e, slot, n, dptr.data(), ws.data(), hs.data(), fmts.data(), cams.data());
     if (rc != WZ_OK) return rc;
@@ -1547,7 +1602,7 @@ extern "C" int wz_stage_preprocess_fmt(wz_engine_t* e, const uint8_t* rgb, int w
     HIPCHK(hipMemcpyAsync(e->lanes[0].d_desc, e->lanes[0].h_desc, sizeof(WzFrameDesc), hipMemcpyHostToDevice, e->stream));
     const int S = (int)e->hdr.input_size;
     wz_launch_preprocess(e->lanes[0].d_desc, 1, S, e->lanes[0].tptr[input_tensor_index(e)], e->stream, input_is_pair(e), nullptr,
-                         e->hdr.resize_mode == 1);
+                         e->hdr.resize_mode == 1, nullptr, e->pre_rows ? e->pre_rows_lds : 0);
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipMemcpy(out_half, e->lanes[0].tptr[input_tensor_index(e)], tensor_frame_bytes(e, input_tensor_index(e)),
                      hipMemcpyDeviceToHost));
