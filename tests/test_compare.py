@@ -26,8 +26,8 @@ BASE = [(1, 0.9, (10, 10, 110, 210)), (3, 0.8, (300, 40, 420, 200)), (1, 0.5, (2
 
 
 def test_stated_box_tolerance():
-    assert cmp.box_tolerance_px(640, 480) == 2 and cmp.box_tolerance_px(1280, 720) == 4 and cmp.box_tolerance_px(1920, 1080) == 6
-    assert cmp.box_tolerance_px(100, 100) == 1
+    assert cmp.box_tolerance_px(640, 480) == 1 and cmp.box_tolerance_px(1280, 720) == 2 and cmp.box_tolerance_px(1920, 1080) == 2
+    assert cmp.box_tolerance_px(100, 100) == 1 and cmp.box_tolerance_px(3840, 2160) == 4
 
 
 def test_identical_rows_match_with_zero_deltas():
@@ -37,11 +37,13 @@ def test_identical_rows_match_with_zero_deltas():
 
 def test_score_and_box_deltas_are_measured_and_bounded():
     moved = [(1, 0.9004, (11, 10, 110, 212)), BASE[1], BASE[2]]
-    r = cmp.compare_rows(_rows(moved), _ref(BASE), (480, 640, 3))
+    r = cmp.compare_rows(_rows(moved), _ref(BASE), (1080, 1920, 3))
     assert r["max_dbox_px"] == 2 and abs(r["max_dscore"] - 4e-4) < 1e-9
-    cmp.assert_rows_match(_rows(moved), _ref(BASE), (480, 640, 3))
+    cmp.assert_rows_match(_rows(moved), _ref(BASE), (1080, 1920, 3))          # 2 px: inside the tolerance of a 1920x1080 frame ...
     with pytest.raises(AssertionError, match="dbox"):
-        cmp.assert_rows_match(_rows([(1, 0.9, (13, 10, 110, 210)), BASE[1], BASE[2]]), _ref(BASE), (480, 640, 3))
+        cmp.assert_rows_match(_rows(moved), _ref(BASE), (480, 640, 3))        # ... outside that of a 640x480 one
+    with pytest.raises(AssertionError, match="dbox"):
+        cmp.assert_rows_match(_rows([(1, 0.9, (13, 10, 110, 210)), BASE[1], BASE[2]]), _ref(BASE), (1080, 1920, 3))
     with pytest.raises(AssertionError, match="dscore"):
         cmp.assert_rows_match(_rows([(1, 0.902, (10, 10, 110, 210)), BASE[1], BASE[2]]), _ref(BASE), (480, 640, 3))
 

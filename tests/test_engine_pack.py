@@ -366,10 +366,11 @@ def test_builder_reports_the_channel_spread_and_warns_beyond_what_was_validated(
     assert "WARNING" not in capsys.readouterr().err
 
 
-def test_robust_program_packs_all_blocks_split_and_square_root_scaled(hp_blob, synth_weights):
-    """`build_engine(robust=True)`: all 17 blocks split-operand with flag 4 (square-root chunk buffer: depthwise weights carry
-    6 / 65535^2), every tensor between them a pair; block 13 reads block 12's pair output and stores the first SSD feature map as
-    its second output (plain fp16), like the default program's block 13."""
+def test_robust_program_packs_all_blocks_split_and_float_form_scaled(hp_blob, synth_weights):
+    """`build_engine(robust=True)`: all 17 blocks split-operand with flag 4 (float-form chunk buffer t = C + (x / 6) K: depthwise taps
+    carry 6 / K, the depthwise bias -C * (sum of the stored taps)), every tensor between them a pair; block 13 reads block 12's pair
+    output and stores the first SSD feature map as its second output (plain fp16), like the default program's block 13; block 16
+    stores its output twice (flag 8, a plain 640-channel tensor) and Conv_1 multiplies it with [hi | lo] halves of its weights."""
     rb = engine.build_engine(synth_weights, robust=True)
     hdr, tensors, ops = parse(rb)
     dhdr, dtensors, dops = parse(hp_blob)
@@ -381,16 +382,34 @@ def test_robust_program_packs_all_blocks_split_and_square_root_scaled(hp_blob, s
     for o, op in blocks:
         assert o["flags"] & 1 and o["flags"] & 4 and tensors[o["src"]]["flags"] == 1 and o["cin0"] > 0
         assert bool(o["flags"] & 2) == bool(tensors[o["dst"]]["flags"]) == (op.block < 16)
+        assert bool(o["flags"] & 8) == (op.block == 16) and tensors[o["dst"]]["c"] == (640 if op.block == 16 else o["cout"])
         dw = op.parts[-2]
-        wf, _ = engine.fold_batch_norm(synth_weights, dw)
+        wf, bf = engine.fold_batch_norm(synth_weights, dw)
         wd = np.frombuffer(rb, np.float32, 9 * o["cmid_pad"], hdr["weights_off"] + o["wd_off"]).reshape(9, -1)
-        np.testing.assert_allclose(wd[:, :o["cmid"]], wf.reshape(9, -1) * (6.0 / 65535.0 ** 2), rtol=1e-6, atol=0)
+        bd = np.frombuffer(rb, np.float32, o["cmid_pad"], hdr["weights_off"] + o["bd_off"])
+        C, K = 2.0 ** -7, (2.0 - 2.0 ** -13) - 2.0 ** -7
+        np.testing.assert_allclose(wd[:, :o["cmid"]], wf.reshape(9, -1) * (6.0 / K), rtol=1e-6, atol=0)
+        # what the kernel computes from stored codes: sum_t wd_t * t_t + bd with t = C + (x / 6) K  ==  sum_t w_t * x_t + b  (also on
+        # padding, where x = 0 is t = C)
+        x = np.random.default_rng(op.block).uniform(0, 6, (9, o["cmid"]))
+        x[:3] = 0.0
+        got = (wd[:, :o["cmid"]].astype(np.float64) * (C + x / 6.0 * K)).sum(0) + bd[:o["cmid"]]
+        np.testing.assert_allclose(got, (wf.reshape(9, -1) * x).sum(0) + bf, rtol=0, atol=2e-5)
     b13 = next(o for o, op in blocks if op.block == 13)
     assert (b13["cin0"], b13["kc0"], b13["cmid"], b13["cout"], b13["stride"]) == (96, 3, 576, 160, 2)
     assert tensors[b13["src"]]["name"] == "expanded_conv_12/output" and tensors[b13["src"]]["flags"] == 1
     t2 = tensors[b13["dst2"] - 1]
     assert (t2["name"], t2["c"], t2["flags"]) == ("expanded_conv_13/expand", 576, 0)
     assert next(o for o in ops if o["name"] == "BoxPredictor_0")["src"] == b13["dst2"] - 1
+    # Conv_1: K = 640 = [hi halves | lo halves] of the folded weights over the two copies of block 16's output
+    c1, d1 = next(o for o in ops if o["name"].endswith("Conv_1")), next(o for o in dops if o["name"].endswith("Conv_1"))
+    assert (c1["cin"], c1["kc"], d1["cin"], d1["kc"]) == (640, 20, 320, 10) and tensors[c1["src"]]["c"] == 640
+    w, _ = engine.fold_batch_norm(synth_weights, next(op for op in prog.ops if op.scope.endswith("Conv_1")))
+    frag = np.frombuffer(rb, np.float16, c1["n_pad"] * 640, hdr["weights_off"] + c1["w_off"]).reshape(c1["n_pad"] // 16, 20, 64, 8)
+    # lane l of N-tile t, chunk q holds W[k = q * 32 + (l >> 4) * 8 + j][n = t * 16 + (l & 15)] (csrc/wz_program.h)
+    k, n = 5 * 32 + 2 * 8 + 3, 7 * 16 + 9
+    hi, lo = float(frag[7, 5, 2 * 16 + 9, 3]), float(frag[7, 15, 2 * 16 + 9, 3])
+    assert hi == float(np.float16(w[0, 0, k, n])) and abs(hi + lo - w[0, 0, k, n]) <= 2.0 ** -21 * abs(w[0, 0, k, n]) + 1e-9
     # ... none of the default program's blocks carries flag 4; its blocks 13 .. 16 are plain
     assert not any(o["flags"] & 4 for o in dops)
     assert [bool(o["flags"] & 1) for o in dops if o["kind"] == arch.OP_MBCONV] == [True] * 13 + [False] * 4

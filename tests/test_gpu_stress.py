@@ -7,6 +7,7 @@ import pytest
 
 import parity_utils as pu
 from oracle import detect as odet
+from oracle.compare import assert_rows_match
 from watsor_amd import engine
 from watsor_amd.runtime import ROW_DTYPE
 from watsor_amd.synth import spread_channel_scales, synthetic_frame
@@ -48,11 +49,13 @@ def test_score_error_under_channel_spread(tmp_path, synth_weights, decades, bar1
     assert out[16][0] <= bar16                      # the fp16 engine: the tolerance up to what was validated, a sanity bound beyond
 
 
-@pytest.mark.parametrize("decades,bar", [(0.0, 5e-4), (1.0, 1e-3), (1.5, 1e-3), (2.0, 1.5e-3)])
+@pytest.mark.parametrize("decades,bar", [(0.0, 5e-4), (1.0, 1e-3), (1.5, 1e-3), (2.0, 1e-3)])
 def test_robust_program_holds_the_tolerance_under_channel_spread(tmp_path, synth_weights, decades, bar):
-    """`build_engine(robust=True)` -- all 17 blocks on the split-operand kernel, expanded tensors as unorm16 of sqrt(x / 6): the north
-    star's 1e-3 up to 1.5 decades of per-channel spread (where the default program is at 3e-3), measured beyond.  The frames go through
-    in ONE batch of mixed resolutions, so the lean builds behind the 19x19 maps run their multi-frame grids."""
+    """`build_engine(robust=True)` -- all 17 blocks on the split-operand kernel, expanded tensors in the 16-bit float form, Conv_1 with
+    split weights: the north star's 1e-3 at 0 / 1.0 / 1.5 / 2.0 decades of per-channel spread (the default program is at 3e-3 at 1.5),
+    on all 100 rows, boxes within the stated pixel tolerance and no unexplained row (oracle/compare.py).  BatchNorm's epsilon bounds
+    what folding can do to a channel at ~30x, i.e. 1.5 decades.  The frames go through in ONE batch of mixed resolutions, so the lean
+    builds behind the 19x19 maps run their multi-frame grids."""
     from watsor_amd.runtime import HipEngine
     from watsor_amd.share import DetectionArray
     W = spread_channel_scales(synth_weights, decades) if decades else synth_weights
@@ -71,10 +74,10 @@ def test_robust_program_holds_the_tolerance_under_channel_spread(tmp_path, synth
             got = np.frombuffer(r, dtype=ROW_DTYPE)
             b, c, s, _, _ = oracle.raw(f)
             ref = odet.rows_as_array(f.shape, b, c, s)
-            pairs, missing = pu.match_rows(got, ref, min_score=0.1)
-            assert len(pairs) >= 50
-            worst = max(worst, max(abs(p[3]) for p in pairs))
-            n += len(pairs)
+            r = assert_rows_match(got, ref, f.shape, tol=bar, what="spread %.1f, %dx%d" % (decades, f.shape[1], f.shape[0]))
+            assert len(r["pairs"]) >= 90
+            worst = max(worst, r["max_dscore"])
+            n += len(r["pairs"])
     finally:
         eng.close()
     print("\\nrobust program, channel spread %.1f decades: max |dscore| %.2e over %d rows" % (decades, worst, n))

@@ -83,6 +83,10 @@ class Op:
     block: int = -1            # OP_MBCONV: index of the inverted-residual block (expanded_conv_<block>)
     hp: bool = False           # OP_MBCONV on the split-operand kernel (csrc/k_mbconv_hp.hip): both matrix operands as
                                # hi + lo fp16 pairs, input (and residual) tensor stored as such a pair
+    dup_out: bool = False      # OP_MBCONV (split-operand kernel) whose output tensor holds the fp16 output TWICE per pixel (2 * cout plain
+                               # channels, [x | x]): the consumer below splits its WEIGHTS instead (the robust program's block 16 -> Conv_1)
+    split_w: bool = False      # OP_CONV reading such a tensor: cin = 2 * (the variable's input channels); K = [hi halves of the folded
+                               # weights over the first copy | lo halves over the second] -- W.x with ~22 significant bits of W on the plain kernels
     dst2: Optional[str] = None  # OP_MBCONV that also WRITES its expanded tensor (hin x win x cmid, plain fp16): block 13, whose expand
                                 # output is the first SSD feature map -- the block stores what it computes anyway, no launch of its own
 
@@ -110,7 +114,7 @@ class Program:
             if op.kind == OP_DW:
                 out[op.scope + "/depthwise_weights"] = (op.k, op.k, op.cin, 1)
             else:
-                out[op.scope + "/weights"] = (op.k, op.k, op.cin, op.cout)
+                out[op.scope + "/weights"] = (op.k, op.k, op.cin // 2 if op.split_w else op.cin, op.cout)
             if op.has_bn:
                 for v in ("gamma", "beta", "moving_mean", "moving_variance"):
                     out[op.scope + "/BatchNorm/" + v] = (op.cout,)
@@ -128,7 +132,7 @@ HP_ALL_BLOCKS = 16   # every inverted-residual block: the robust program (engine
 
 
 def build(size: int = INPUT_SIZE, fuse: bool = True, fuse_stem: bool = True, hp_upto: int = -1, input_pair: bool = False,
-          tap_in_block: bool = True) -> Program:
+          tap_in_block: bool = True, conv1_split: bool = False) -> Program:
     """input_pair: the network input is stored as a hi + lo pair of halves even without split-operand blocks (the `-p 32` program:
     one fp16 rounding of the resized image is otherwise the largest error of an engine that computes in fp32).
     hp_upto >= 0 (needs fuse and fuse_stem): blocks 0 .. hp_upto run on the split-operand kernel and the tensors
@@ -138,6 +142,9 @@ def build(size: int = INPUT_SIZE, fuse: bool = True, fuse_stem: bool = True, hp_
     in the stem-folded programs the block writes it itself, next to its own output (`dst2`; tap_in_block=False and the
     fuse_stem=False program keep the expand conv as a separate op, which block 13 then reads).  fuse=False: one op per layer (the
     program the per-layer parity tests walk); both programs compute bit-identical tensors.
+    conv1_split (needs hp_upto = 16, the robust program): Conv_1's folded weights travel as hi + lo halves too -- block 16 stores its
+    fp16 output twice per pixel (`dup_out`) and Conv_1 is a plain 1x1 conv with K = 640 over [hi weights | lo weights] (`split_w`): at two
+    decades of channel spread the single fp16 rounding of those 410 k weights is the largest error left (tools/err_budget.py).
     fuse_stem (with fuse): the stem conv becomes the expand stage of the first block -- input image to block
     output in one launch; the stem then runs on the matrix cores with fp16 weights, so this program matches
     the others to fp16 rounding, not bit for bit."""
@@ -183,7 +190,11 @@ def build(size: int = INPUT_SIZE, fuse: bool = True, fuse_stem: bool = True, hp_
         blk0.src, blk0.cin0, blk0.stem = "input", 32, True
         blk0.parts = [stem_op] + blk0.parts
         ops.pop(0)
-    ops.append(Op(OP_CONV, FE + "Conv_1", cur, "Conv_1", cin, 1280, 1, 1, ACT_RELU6, True))
+    if conv1_split:
+        if hp_upto != HP_ALL_BLOCKS or not (fuse and fuse_stem):
+            raise ValueError("conv1_split needs every block on the split-operand kernel (hp_upto = %d)" % HP_ALL_BLOCKS)
+        ops[-1].dup_out = True
+    ops.append(Op(OP_CONV, FE + "Conv_1", cur, "Conv_1", 2 * cin if conv1_split else cin, 1280, 1, 1, ACT_RELU6, True, split_w=conv1_split))
     cur, cin = "Conv_1", 1280
     taps = [tap0, "Conv_1"]
     for i, (d1, d2) in enumerate(_EXTRA_DEPTHS):
@@ -213,7 +224,7 @@ def build(size: int = INPUT_SIZE, fuse: bool = True, fuse_stem: bool = True, hp_
             op.stem_pad = (st, sl)
         op.hout, op.pad_t = tf_same(op.hin, op.k, op.stride)
         op.wout, op.pad_l = tf_same(op.win, op.k, op.stride)
-        p.tensors[op.dst] = Tensor(op.dst, op.hout, op.wout, op.cout, hp=op.hp and op.block < hp_upto)
+        p.tensors[op.dst] = Tensor(op.dst, op.hout, op.wout, 2 * op.cout if op.dup_out else op.cout, hp=op.hp and op.block < hp_upto)
         if op.dst2:
             p.tensors[op.dst2] = Tensor(op.dst2, op.hin, op.win, op.cmid)
 

@@ -55,14 +55,39 @@ __device__ __forceinline__ void wz_hp_split(const float v[8], half8_t& hi, half8
 
 typedef __attribute__((ext_vector_type(2))) float wz_f32x2_t;
 
-// eight unorm16 -> four pairs of floats (v_cvt_f32_u32 with SDWA word select)
+// The 16-bit FLOAT form of the chunk buffer (QE, the robust program): a value z = relu6(v) / 6 in [0, 1] is kept as
+//     t = C + z * K,   C = 2^-7,  K = (2 - 2^-13) - C      (t in [2^-7, 2): exactly eight binades)
+// rounded to 13 mantissa bits; the code is bits 10 .. 25 of t's fp32 pattern (3 exponent bits + 13 mantissa bits), i.e. a relative
+// step of 2^-13 whatever the channel's scale is, where unorm16 of z has an absolute step (a channel living at 0.03 keeps 8 bits) and
+// unorm16 of sqrt(z) (round 3) 10 - 11 bits for such a channel: 1.4e-3 of the scores at two decades of channel spread against 7e-4
+// (tools/err_budget.py, modes q / T).  z = 0 is code 0 (C is a power of two), so out-of-frame halo pixels stay all-zero words.
+// Decoding is two integer operations per value and NO arithmetic: the depthwise weights carry 6 / K and the depthwise bias
+// -(6 C / K) * (sum of the channel's nine taps) (watsor_amd/engine.py), exact also where taps fall on padding (code 0 decodes to C).
+#define WZ_HP_FC 0.0078125f
+#define WZ_HP_FK ((2.0f - 0.0001220703125f) - WZ_HP_FC)
+#define WZ_HP_FE 0x3C000000u   // exponent field of 2^-7 (120 << 23): code 0
+
+// eight 16-bit codes -> four pairs of floats.  Linear: v_cvt_f32_u32 with SDWA word select; float form: shift + mask-or per value.
 template <bool QE = false>
 __device__ __forceinline__ void wz_hp_unpack(const wz_u32x4_t t, wz_f32x2_t x[4]) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        x[r] = (wz_f32x2_t){(float)(t[r] & 0xffffu), (float)(t[r] >> 16)};
-        if constexpr (QE) x[r] = x[r] * x[r];   // the buffer holds square roots (v_pk_mul_f32)
+        if constexpr (QE)
+            x[r] = (wz_f32x2_t){__uint_as_float(((t[r] << 10) & 0x03FFFC00u) | WZ_HP_FE), __uint_as_float(((t[r] >> 6) & 0x03FFFC00u) | WZ_HP_FE)};
+        else
+            x[r] = (wz_f32x2_t){(float)(t[r] & 0xffffu), (float)(t[r] >> 16)};
     }
+}
+// four values d = v / 6 (before the clamp) -> two words of float-form codes
+__device__ __forceinline__ wz_u32x2_t wz_hp_fenc4(const float4_t d) {
+    unsigned q[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float z = __builtin_amdgcn_fmed3f(d[r], 0.0f, 1.0f);
+        const float t = __builtin_fmaf(z, WZ_HP_FK, WZ_HP_FC);
+        q[r] = (__float_as_uint(t) + (512u - WZ_HP_FE)) >> 10;      // round to 13 mantissa bits, rebias: 0 .. 65535
+    }
+    return (wz_u32x2_t){q[0] | (q[1] << 16), q[2] | (q[3] << 16)};
 }
 
 // d[0..3] += x[0..3] * (w0, w1) as four v_pk_fma_f32: the depthwise stage is bound by VALU issue, and a packed FMA
@@ -86,9 +111,9 @@ __device__ __forceinline__ void wz_hp_fma8(wz_f32x2_t d[4], const wz_f32x2_t x[4
 // SH (CS only): the halo fragments are fetched ONCE per workgroup -- each wave loads its share of the MPW x KCI x 2 fragments,
 // they meet in LDS, every wave reads all of them back -- instead of once per wave (8 or 12 times the same 13 .. 18 KiB through
 // the vector memory path of one CU: the prologue of the 19x19 blocks was bound by exactly that, profiles/r02zq_*).
-// QE: the chunk buffer holds unorm16 of sqrt(v / 6) instead of v / 6 (the ROBUST program, WzMbArgs::qenc): the step is 12 sqrt(v / 6) / 65535,
-// i.e. fine where the values are small -- what channels of very different scale need -- for one v_sqrt_f32 per
-// stored value and one multiply per tap; the depthwise weights then carry 6 / 65535^2.
+// QE: the chunk buffer holds the 16-bit FLOAT form of v / 6 (above) instead of unorm16 of v / 6 (the ROBUST program, WzMbArgs::qenc): a
+// relative step -- what channels of very different scale need.  Round 3 kept square roots there (one v_sqrt_f32
+// per stored value, one multiply per tap): coarser for small channels and slower to encode.
 // LEAN (CS + SH, one output m-tile): the shapes behind the 19x19 maps (block 13: 96 -> 576 -> 160 at stride 2; blocks 14 .. 16:
 // 160 -> 960 -> 160 / 320 on 10x10) do not fit 256 registers the way the others are written -- MPW x KCI x 2 halo fragments alone are
 // 144 / 120 of them -- so the halo fragments of ONE m-tile at a time come back from LDS inside the expand stage, and a workgroup
@@ -335,7 +360,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
         }
         __builtin_amdgcn_sched_barrier(0);   // (the loads above stay above: they have the whole expand stage to land)
         // ---- expand: E[p][ce] = in-frame ? unorm16(clamp((sum_k X[p][k] We[k][ce] + be[ce]) / 6, 0, 1)) : 0
-        // one 16 x 4 tile of expanded values of a lane -> the chunk buffer (QE: as sqrt)
+        // one 16 x 4 tile of expanded values of a lane -> the chunk buffer (QE: in the float form)
         auto put = [&](float4_t d, int i, int nt, bool keep) {
             if constexpr (TAP) {   // the second output: relu6 of the expanded value as plain fp16 (d carries the 1 / 6 of the chunk buffer)
                 if (own2[i] >= 0 && keep && ce0 + nt * 16 + g * 4 < a.cmid) {
@@ -345,13 +370,13 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
                     *reinterpret_cast<half4_t*>(a.out2 + (size_t)own2[i] * a.cmid + ce0 + nt * 16 + g * 4) = t2;
                 }
             }
-            if constexpr (QE) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) d[r] = __builtin_amdgcn_sqrtf(fmaxf(d[r], 0.0f));
-            }
             wz_u32x2_t o;
-            o[0] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pknorm_u16(d[0], d[1]));
-            o[1] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pknorm_u16(d[2], d[3]));
+            if constexpr (QE) {
+                o = wz_hp_fenc4(d);
+            } else {
+                o[0] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pknorm_u16(d[0], d[1]));
+                o[1] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pknorm_u16(d[2], d[3]));
+            }
             if (!keep) o[0] = o[1] = 0u;
             *reinterpret_cast<wz_u32x2_t*>(E + (i * 16 + r16) * ES + nt * 16 + g * 4) = o;
         };
@@ -555,7 +580,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
         }
         half_t* const dst = a.out + (size_t)op * ostride + n4;
         *reinterpret_cast<half4_t*>(dst) = oh;
-        if (a.hp_out) *reinterpret_cast<half4_t*>(dst + a.cout) = ol;
+        if (a.hp_out) *reinterpret_cast<half4_t*>(dst + a.cout) = a.hp_out == 2 ? oh : ol;   // 2: [hi | hi] for a consumer whose WEIGHTS are split
     };
 
     if constexpr (!CS) {
@@ -705,7 +730,7 @@ static int wz_hp_launch(WzMbArgs a, int n, hipStream_t s, bool prepare) {
     return 1;
 }
 
-// The ROBUST program (WzMbArgs::qenc, `python -m watsor_amd.engine --robust`): all 17 blocks on this kernel with the square-root chunk
+// The ROBUST program (WzMbArgs::qenc, `python -m watsor_amd.engine --robust`): all 17 blocks on this kernel with the float-form chunk
 // buffer, one launch shape per block shape -- the throughput defaults of the dispatcher below, plus the lean builds for blocks 13 .. 16.
 static int wz_launch_mbconv_hp_q(WzMbArgs a, int n, hipStream_t s, bool prepare) {
     const int nto = a.n_pad / 16;

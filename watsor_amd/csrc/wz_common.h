@@ -117,10 +117,11 @@ struct WzMbArgs {
     // split-operand blocks (k_mbconv_hp.hip): `in` / `res` are hi + lo pair tensors, `wd` points at float[9][cmid_pad]
     const half_t* we_lo;   // "lo" halves of the expand weights (we = "hi")
     const half_t* wp_lo;   // "lo" halves of the project weights
-    int32_t hp, hp_out;    // hp: this block runs on the split-operand kernel; hp_out: `out` is a hi + lo pair tensor
+    int32_t hp, hp_out;    // hp: this block runs on the split-operand kernel; hp_out: 1 = `out` is a hi + lo pair tensor, 2 = `out` has 2 * cout plain
+                           // channels holding the fp16 output TWICE ([hi | hi]: the consumer multiplies them with the hi and lo halves of its weights)
     half_t* out2;          // chunk-split kernel: where the expanded tensor is stored as well (hin x win x cmid fp16), or nullptr
     int32_t has_out2;      // the op has such a second output (out2 itself is null while a launcher is only asked to prepare)
-    int32_t qenc;          // split-operand kernel: the chunk buffer holds unorm16 of sqrt(v / 6) (the robust program; wd carries 6 / 65535^2)
+    int32_t qenc;          // split-operand kernel: the chunk buffer holds the 16-bit float form of v / 6 (the robust program; wd carries 6 / K, bd the offset)
 };
 
 // Per-camera filter state resident in HBM (see wz_set_camera_filter).

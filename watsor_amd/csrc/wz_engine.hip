@@ -82,10 +82,13 @@ struct wz_engine {
     bool tail_fuse = false;       // WZ_TAIL_FUSE=1: the convolutions on the <= 32-pixel maps in one launch (k_tail.hip); measured slower, off
     bool desc_by_value = true;    // the frame descriptors travel as arguments of the resize kernel (WZ_DESC_ARGS=0: zero-copy / copied)
     bool desc_zero_copy = true;   // the resize kernel reads the frame descriptors from page-locked host memory (WZ_DESC_COPY=1: copied first)
-    bool pre_rows = false;        // the resize kernel in its row-staged form (k_preprocess.hip: wz_k_preprocess_rows)
+    bool pre_rows = false;        // WZ_PRE_ROWS=1: every batch on the row-staged form of the resize kernel (k_preprocess.hip:
+                                  // wz_k_preprocess_rows); default: only batches with a frame that is read in place (the per-pixel form is
+                                  // faster out of HBM: 51.5 k against 48.0 k frames/s on the headline workload, profiles/r04_host_read_ab.txt)
     int pre_rows_lds = 0;         // ... and its LDS bytes for the widest frame this engine takes
-    int host_read = 0;            // page-locked host frames: 0 = staged by one DMA each, 1 = read in place by the resize kernel (no copy),
-                                  // 2 = read in place when the resize skips rows (down-scale >= 2 vertically), staged otherwise
+    int host_read = 2;            // page-locked host frames (WZ_HOST_READ): 0 = staged by one DMA each, 1 = read in place by the resize kernel
+                                  // (no copy), 2 (default) = read in place when the resize skips rows (vertical down-scale >= 2: 1080p RGB24
+                                  // 8.0 k -> 13.0 k frames/s, NV12 15.6 k -> 18.7 k), staged otherwise (640x480 in place: 26 k against 33 k)
     struct HostRange { const uint8_t* host; uint64_t bytes; const uint8_t* dev; };
     std::vector<HostRange> host_ranges;   // what wz_host_register page-locked, with the address the device sees it at
     int wide_cus = 128;        // CUs the wide head kernel's K slices are sized for when several lanes are in flight (WZ_WIDE_CUS)
@@ -143,7 +146,9 @@ struct wz_engine {
         std::vector<int32_t> bound_idx;      // frame-table entries of the batch in flight (empty: not a bound batch)
         hipEvent_t done = nullptr;
         int n = 0;
-        std::map<int, hipGraphExec_t> graphs;    // key = batch size
+        bool rows = false;                       // the batch being enqueued runs the row-staged resize kernel (a frame of it is read in place)
+        int key = 0;                             // graph key of the batch in flight: batch size | rows << 16
+        std::map<int, hipGraphExec_t> graphs;    // key = batch size | (row-staged resize kernel) << 16
         std::map<int, hipGraph_t> graph_src;     // the captured graph itself, kept where one of its node handles is
         std::map<int, hipGraphNode_t> pre_nodes; // ... and the resize kernel's node in that graph (its arguments carry the frame
                                                  // descriptors and are rewritten before every replay), if it takes them by value
@@ -210,7 +215,7 @@ static WzMbArgs mb_args(wz_engine* e, const Lane& L, const WzOpDesc& op) {
     a.cout = op.cout; a.n_pad = op.n_pad;
     a.stride = op.stride; a.pad_t = op.pad_t; a.pad_l = op.pad_l;
     a.hp = (op.flags & WZ_OPF_HP) ? 1 : 0;
-    a.hp_out = (op.flags & WZ_OPF_HP_OUT) ? 1 : 0;
+    a.hp_out = (op.flags & WZ_OPF_HP_OUT) ? 1 : (op.flags & WZ_OPF_DUP_OUT) ? 2 : 0;
     a.qenc = (op.flags & WZ_OPF_QENC) ? 1 : 0;
     a.out2 = (op.dst2 > 0 && !L.tptr.empty()) ? L.tptr[op.dst2 - 1] : nullptr;
     a.has_out2 = op.dst2 > 0 ? 1 : 0;
@@ -580,7 +585,7 @@ static void enqueue_batch(wz_engine* e, Lane& L, int n, StageTimer* t, int inner
     wz_launch_repeat = inner;
     wz_launch_preprocess(zero_copy ? L.h_desc_dev : L.d_desc, n, (int)e->hdr.input_size, L.tptr[input_tensor_index(e)], s,
                          input_is_pair(e), (zero_copy || by_value) ? L.d_desc : nullptr, e->hdr.resize_mode == 1,
-                         by_value ? L.h_desc : nullptr, e->pre_rows ? e->pre_rows_lds : 0);
+                         by_value ? L.h_desc : nullptr, L.rows ? e->pre_rows_lds : 0);
     if (t) t->mark();
     enqueue_network(e, L, n, t);
     wz_launch_repeat = 1;
@@ -594,8 +599,10 @@ static int run_batch(wz_engine* e, int slot, int n) {
         L.launch_failed = 0;
         return wz_fail(WZ_EFORMAT, "no split-operand kernel took op %d (%s) at batch %d", op, e->ops[op].name, n);
     };
+    const int key = n | (L.rows ? 1 << 16 : 0);
+    L.key = key;
     if (e->use_graph) {
-        auto it = L.graphs.find(n);
+        auto it = L.graphs.find(key);
         if (it == L.graphs.end()) {
             hipGraph_t g = nullptr;
             HIPCHK(hipStreamBeginCapture(L.stream, hipStreamCaptureModeThreadLocal));
@@ -606,32 +613,32 @@ static int run_batch(wz_engine* e, int slot, int n) {
                 return failed();
             }
             size_t nodes = 0;
-            if (hipGraphGetNodes(g, nullptr, &nodes) == hipSuccess) L.graph_nodes[n] = (int)nodes;
+            if (hipGraphGetNodes(g, nullptr, &nodes) == hipSuccess) L.graph_nodes[key] = (int)nodes;
             if (e->desc_by_value && n <= WZ_DESC_PACK && nodes > 0) {   // the resize kernel's node: its arguments are this batch's descriptors
                 std::vector<hipGraphNode_t> all(nodes);
-                const void* want = wz_preprocess_func(input_is_pair(e), e->pre_rows);
+                const void* want = wz_preprocess_func(input_is_pair(e), L.rows);
                 if (hipGraphGetNodes(g, all.data(), &nodes) == hipSuccess)
                     for (size_t k = 0; k < nodes; ++k) {
                         hipGraphNodeType ty;
                         hipKernelNodeParams kp;
                         if (hipGraphNodeGetType(all[k], &ty) == hipSuccess && ty == hipGraphNodeTypeKernel &&
                             hipGraphKernelNodeGetParams(all[k], &kp) == hipSuccess && kp.func == want) {
-                            L.pre_nodes[n] = all[k];
+                            L.pre_nodes[key] = all[k];
                             break;
                         }
                     }
-                if (!L.pre_nodes.count(n)) {
+                if (!L.pre_nodes.count(key)) {
                     (void)hipGraphDestroy(g);
                     return wz_fail(WZ_EHIP, "the resize kernel's node was not found in the captured graph");
                 }
             }
             hipGraphExec_t ge = nullptr;
             HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-            if (L.pre_nodes.count(n)) L.graph_src[n] = g;   // (the node handle lives as long as the graph it belongs to)
+            if (L.pre_nodes.count(key)) L.graph_src[key] = g;   // (the node handle lives as long as the graph it belongs to)
             else (void)hipGraphDestroy(g);
-            it = L.graphs.emplace(n, ge).first;
+            it = L.graphs.emplace(key, ge).first;
         }
-        auto pn = L.pre_nodes.find(n);
+        auto pn = L.pre_nodes.find(key);
         if (pn != L.pre_nodes.end()) {   // this batch's descriptors into the node's arguments
             memset(&L.pack, 0, sizeof(L.pack));
             memcpy(L.pack.d, L.h_desc, sizeof(WzFrameDesc) * n);
@@ -644,8 +651,8 @@ static int run_batch(wz_engine* e, int slot, int n) {
             L.pre_kp[3] = &L.pre_out; L.pre_kp[4] = &L.pre_keep; L.pre_kp[5] = &L.pre_half_pixel;
             hipKernelNodeParams kp;
             memset(&kp, 0, sizeof(kp));
-            kp.func = const_cast<void*>(wz_preprocess_func(input_is_pair(e), e->pre_rows));
-            if (e->pre_rows) {
+            kp.func = const_cast<void*>(wz_preprocess_func(input_is_pair(e), L.rows));
+            if (L.rows) {
                 kp.gridDim = dim3((unsigned)L.pre_size, n);
                 kp.blockDim = dim3(wz_preprocess_rows_threads());
                 kp.sharedMemBytes = (unsigned)e->pre_rows_lds;
@@ -749,6 +756,8 @@ static int load_blob(wz_engine* e, const char* path) {
         if (op.kind == WZ_OP_MBCONV && (op.flags & WZ_OPF_HP)) {
             if (!(e->tensors[op.src].flags & WZ_TENSOR_HP) || (op.res >= 0 && op.res != op.src) ||
                 ((op.flags & WZ_OPF_HP_OUT) != 0) != ((e->tensors[op.dst].flags & WZ_TENSOR_HP) != 0) ||
+                ((op.flags & WZ_OPF_DUP_OUT) && ((op.flags & WZ_OPF_HP_OUT) || e->tensors[op.dst].c != 2 * op.cout)) ||
+                (!(op.flags & WZ_OPF_DUP_OUT) && e->tensors[op.dst].c != op.cout) ||
                 op.we_lo_off <= 0 || (uint64_t)op.we_lo_off >= h.weights_bytes || op.w_lo_off <= 0 ||
                 (uint64_t)op.w_lo_off >= h.weights_bytes || (op.stem && e->tensors[op.src].c != 4))
                 return wz_fail(WZ_EFORMAT, "%s: op %u (%s): malformed split-operand block", path, i, op.name);
@@ -813,9 +822,8 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     e->tail_fuse = (env = wz_dev_getenv("WZ_TAIL_FUSE")) && atoi(env) != 0;
     e->pre_rows = (env = wz_dev_getenv("WZ_PRE_ROWS")) ? atoi(env) != 0 : e->pre_rows;
     e->host_read = (env = wz_dev_getenv("WZ_HOST_READ")) ? atoi(env) : e->host_read;
-    if (e->host_read) e->pre_rows = true;   // (in-place reads of host frames only pay in whole contiguous rows)
     e->pre_rows_lds = (int)wz_preprocess_rows_lds(max_width);
-    if (e->pre_rows_lds > 60 * 1024) e->pre_rows = false, e->host_read = 0;   // (frames wider than ~10 k pixels: the per-pixel form)
+    if (e->pre_rows_lds > 60 * 1024) e->pre_rows = false, e->host_read = 0;   // (frames wider than ~10 k pixels: the per-pixel form, staged)
     e->wide_T = (env = wz_dev_getenv("WZ_WIDE_T")) ? atoi(env) : 0;
     e->wide_min_m = (env = wz_dev_getenv("WZ_WIDE_MIN_M")) ? atoi(env) : 1;
     {
@@ -1110,6 +1118,7 @@ extern "C" int wz_submit_device_fmt(wz_engine_t* e, int slot, int n, const uint8
     HIPCHK(hipEventSynchronize(e->lanes[slot].done));   // the lane's previous batch has fully drained
     int rc = fill_desc(e, slot, n, d_rgb, w, h, fmt, cam);
     if (rc != WZ_OK) return rc;
+    e->lanes[slot].rows = e->pre_rows;
     return run_batch(e, slot, n);
 }
 extern "C" int wz_submit_device(wz_engine_t* e, int slot, int n, const uint8_t* const* d_rgb, const int* w,
@@ -1155,7 +1164,7 @@ extern "C" int wz_num_slots(wz_engine_t* e) { return e ? e->n_lanes : 0; }
 extern "C" int wz_graph_nodes(wz_engine_t* e, int slot) {
     if (!e || slot < 0 || slot >= e->n_lanes) return 0;
     const Lane& L = e->lanes[slot];
-    auto it = L.graph_nodes.find(L.n);
+    auto it = L.graph_nodes.find(L.key);
     return it == L.graph_nodes.end() ? 0 : it->second;
 }
 
@@ -1239,6 +1248,7 @@ extern "C" int wz_submit_host_fmt(wz_engine_t* e, int slot, int n, const uint8_t
     Lane& L = e->lanes[slot];
     HIPCHK(hipEventSynchronize(L.done));   // the lane's previous batch (and its reads of the staging area) drained
     if (!L.d_frames) return wz_fail(WZ_EINVAL, "wz_submit_host: lane %d has no staging area", slot);
+    bool in_place = false;
     std::vector<const uint8_t*> dptr(n);
     for (int i = 0; i < n; ++i) {
         if (!rgb[i] || w[i] < 1 || h[i] < 1) return wz_fail(WZ_EINVAL, "frame %d: bad pointer or size", i);
@@ -1251,6 +1261,7 @@ extern "C" int wz_submit_host_fmt(wz_engine_t* e, int slot, int n, const uint8_t
         const uint8_t* dv = read_in_place(e, h[i]) ? device_view(e, rgb[i], bytes) : nullptr;
         if (dv) {
             dptr[i] = dv;
+            in_place = true;
             continue;
         }
         int rc = stage_frame(e, L, i, rgb[i], bytes, &dptr[i]);
@@ -1258,6 +1269,7 @@ extern "C" int wz_submit_host_fmt(wz_engine_t* e, int slot, int n, const uint8_t
     }
     int rc = fill_desc(e, slot, n, dptr.data(), w, h, fmt, cam);
     if (rc != WZ_OK) return rc;
+    L.rows = e->pre_rows || in_place;
     return run_batch(e, slot, n);
 }
 
@@ -1331,6 +1343,7 @@ extern "C" int wz_submit_bound(wz_engine_t* e, int slot, int n, const int32_t* e
     Lane& L = e->lanes[slot];
     HIPCHK(hipEventSynchronize(L.done));   // the lane's previous batch (and its reads of the staging area) drained
     if (!L.d_frames) return wz_fail(WZ_EINVAL, "wz_submit_bound: lane %d has no staging area", slot);
+    bool in_place = false;
     std::vector<const uint8_t*> dptr(n);
     std::vector<int> ws(n), hs(n), fmts(n), cams(n);
     for (int i = 0; i < n; ++i) {
@@ -1339,6 +1352,7 @@ extern "C" int wz_submit_bound(wz_engine_t* e, int slot, int n, const int32_t* e
         ws[i] = f.w; hs[i] = f.h; fmts[i] = f.fmt; cams[i] = f.cam;
         if (f.dev && read_in_place(e, f.h)) {
             dptr[i] = f.dev;
+            in_place = true;
             continue;
         }
         int rc = stage_frame(e, L, i, f.host, f.bytes, &dptr[i]);
@@ -1346,6 +1360,7 @@ extern "C" int wz_submit_bound(wz_engine_t* e, int slot, int n, const int32_t* e
     }
     int rc = fill_desc(e, slot, n, dptr.data(), ws.data(), hs.data(), fmts.data(), cams.data());
     if (rc != WZ_OK) return rc;
+    L.rows = e->pre_rows || in_place;
     rc = run_batch(e, slot, n);
     if (rc != WZ_OK) return rc;
     L.bound_idx.assign(entries, entries + n);
@@ -1529,6 +1544,7 @@ extern "C" int wz_profile_stages(wz_engine_t* e, int n, const uint8_t* const* d_
     { int _rc = sync_all(e); if (_rc != WZ_OK) return _rc; }
     int rc = fill_desc(e, 0, n, d_rgb, w, h, nullptr, nullptr);
     if (rc != WZ_OK) return rc;
+    e->lanes[0].rows = e->pre_rows;
     const size_t ns = e->stage_names.size();
     std::vector<double> acc(ns, 0.0);
     StageTimer t;

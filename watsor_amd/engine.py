@@ -24,7 +24,7 @@ from . import arch
 from .anchors import ssd_anchor_table
 
 MAGIC = 0x35335A57
-FORMAT_VERSION = 9
+FORMAT_VERSION = 10
 BN_EPSILON = 1e-3          # watsor/test/model/prepare.py:48
 
 DEFAULT_POST = dict(max_total=100, max_per_class=100, score_threshold=1e-8, iou_threshold=0.6,
@@ -136,6 +136,8 @@ def split_halves(w: np.ndarray):
 
 
 UNORM16_PER_6 = 65535.0 / 6.0    # the split-operand blocks keep relu6 outputs in LDS as unorm16 of x / 6
+FLOAT_FORM_C = 2.0 ** -7         # ... the robust program as a 16-bit float of t = C + (x / 6) K (3 exponent + 13 mantissa bits; k_mbconv_hp.hip)
+FLOAT_FORM_K = (2.0 - 2.0 ** -13) - FLOAT_FORM_C
 
 
 def stem_k_rows(w: np.ndarray) -> np.ndarray:
@@ -256,7 +258,8 @@ def build_engine(weights: Dict[str, np.ndarray], precision: int = 16, model_widt
         raise ValueError("the robust program is the `-p 16` program with fused blocks")
     if hp_upto is None:
         hp_upto = (arch.HP_ALL_BLOCKS if robust else arch.HP_LAST_BLOCK) if (precision == 16 and fuse and fuse_stem) else -1
-    prog = arch.build(model_width, fuse=fuse, fuse_stem=fuse_stem, hp_upto=hp_upto, input_pair=precision == 32, tap_in_block=tap_in_block)
+    prog = arch.build(model_width, fuse=fuse, fuse_stem=fuse_stem, hp_upto=hp_upto, input_pair=precision == 32, tap_in_block=tap_in_block,
+                      conv1_split=robust)
     missing = [n for n in prog.variable_shapes() if n not in weights]
     if missing:
         raise KeyError("model is missing %d variables, e.g. %s" % (len(missing), missing[0]))
@@ -278,6 +281,10 @@ def build_engine(weights: Dict[str, np.ndarray], precision: int = 16, model_widt
 
     def put_conv(op):
         w, b = fold_batch_norm(weights, op)
+        if op.split_w:                                           # [hi halves | lo halves] along the input channels (arch.Op.split_w)
+            hi, lo = split_halves(w)
+            w = np.concatenate([hi.astype(np.float64), lo.astype(np.float64)], axis=2)
+            assert w.shape[2] == op.cin
         n_pad = _align(op.cout, 64 if op.cout >= 256 else 32)   # 64-wide wave tiles for the wide layers
         if precision == 32:
             kc = (op.cin + 15) // 16
@@ -325,10 +332,16 @@ def build_engine(weights: Dict[str, np.ndarray], precision: int = 16, model_widt
             wd, bd = fold_batch_norm(weights, dw)
             cmid_pad = _align(op.cmid, 32)
             wdp = np.zeros((9, cmid_pad), np.float32)
-            # (robust: the buffer holds u = 65535 sqrt(x / 6), the depthwise stage squares it: x = u^2 * 6 / 65535^2)
-            wdp[:, :op.cmid] = (wd.reshape(9, op.cmid) / (UNORM16_PER_6 * 65535.0 if robust else UNORM16_PER_6)).astype(np.float32)
             bdp = np.zeros(cmid_pad, np.float32)
-            bdp[:op.cmid] = bd
+            if robust:
+                # the buffer holds the 16-bit float form t = C + (x / 6) K (k_mbconv_hp.hip): x = (t - C) 6 / K, so the taps carry 6 / K
+                # and the bias takes -(6 C / K) * (sum of the channel's nine taps) -- exact on padding too, where t = C
+                w9 = wd.reshape(9, op.cmid)
+                wdp[:, :op.cmid] = (w9 * (6.0 / FLOAT_FORM_K)).astype(np.float32)
+                bdp[:op.cmid] = bd - FLOAT_FORM_C * wdp[:, :op.cmid].astype(np.float64).sum(0)      # (of the taps as stored: fp32, with 6 / K)
+            else:
+                wdp[:, :op.cmid] = (wd.reshape(9, op.cmid) / UNORM16_PER_6).astype(np.float32)
+                bdp[:op.cmid] = bd
             mb.update(cmid=op.cmid, cin0=op.cin0, cmid_pad=cmid_pad, wd_off=put(wdp), bd_off=put(bdp))
             w, b = fold_batch_norm(weights, pj)
             n_pad = _align(pj.cout, 64 if pj.cout >= 256 else 32)
@@ -337,7 +350,7 @@ def build_engine(weights: Dict[str, np.ndarray], precision: int = 16, model_widt
             bp = np.zeros(n_pad, np.float32)
             bp[:pj.cout] = b
             b_off = put(bp)
-            mb["flags"] = 1 | (2 if prog.tensors[op.dst].hp else 0) | (4 if robust else 0)
+            mb["flags"] = 1 | (2 if prog.tensors[op.dst].hp else 0) | (4 if robust else 0) | (8 if op.dup_out else 0)
             op_recs.append(_op_record(op, tindex, n_pad, kc, w_off, b_off, mb))
             continue
         if op.kind == arch.OP_MBCONV:
