@@ -380,7 +380,8 @@ def test_robust_program_packs_all_blocks_split_and_float_form_scaled(hp_blob, sy
     blocks = [(o, op) for o, op in zip(ops, prog.ops) if o["kind"] == arch.OP_MBCONV]
     assert len(blocks) == 17
     for o, op in blocks:
-        assert o["flags"] & 1 and o["flags"] & 4 and tensors[o["src"]]["flags"] == 1 and o["cin0"] > 0
+        assert o["flags"] & 1 and tensors[o["src"]]["flags"] == 1 and o["cin0"] > 0
+        assert bool(o["flags"] & 4) == (op.block <= 12)          # the float form in front of the first SSD feature map, linear behind it
         assert bool(o["flags"] & 2) == bool(tensors[o["dst"]]["flags"]) == (op.block < 16)
         assert bool(o["flags"] & 8) == (op.block == 16) and tensors[o["dst"]]["c"] == (640 if op.block == 16 else o["cout"])
         dw = op.parts[-2]
@@ -388,6 +389,10 @@ def test_robust_program_packs_all_blocks_split_and_float_form_scaled(hp_blob, sy
         wd = np.frombuffer(rb, np.float32, 9 * o["cmid_pad"], hdr["weights_off"] + o["wd_off"]).reshape(9, -1)
         bd = np.frombuffer(rb, np.float32, o["cmid_pad"], hdr["weights_off"] + o["bd_off"])
         C, K = 2.0 ** -7, (2.0 - 2.0 ** -13) - 2.0 ** -7
+        if not o["flags"] & 4:                                   # linear buffer: 6 / 65535 in the taps, the bias as it is
+            np.testing.assert_allclose(wd[:, :o["cmid"]], wf.reshape(9, -1) * (6.0 / 65535.0), rtol=1e-6, atol=0)
+            np.testing.assert_allclose(bd[:o["cmid"]], bf, rtol=1e-6, atol=1e-7)
+            continue
         np.testing.assert_allclose(wd[:, :o["cmid"]], wf.reshape(9, -1) * (6.0 / K), rtol=1e-6, atol=0)
         # what the kernel computes from stored codes: sum_t wd_t * t_t + bd with t = C + (x / 6) K  ==  sum_t w_t * x_t + b  (also on
         # padding, where x = 0 is t = C)

@@ -18,7 +18,7 @@ ap.add_argument("--precision", type=int, default=16)
 ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--unfused", action="store_true")
 ap.add_argument("--plain-fp16", action="store_true", help="the -p 16 program without split-operand blocks")
-ap.add_argument("--robust", action="store_true", help="the robust -p 16 program (all 17 blocks split, square-root chunk buffer)")
+ap.add_argument("--robust", action="store_true", help="the robust -p 16 program (all 17 blocks split, float-form chunk buffer up to block WZ_FLOAT_UPTO, default 12)")
 ap.add_argument("--tap-conv", action="store_true", help="block 13's expand conv as a launch of its own (the program before the block stored it itself)")
 ap.add_argument("--inner", type=int, default=1, help="launches per bracket (wz_profile_stages): > 1 = a launch incl. its in-stream boundary")
 ap.add_argument("--only", default="", help="print only the stages whose name contains this")
@@ -27,7 +27,8 @@ args = ap.parse_args()
 path = "/tmp/wz_stage_table/mi355x.bin"
 os.makedirs(os.path.dirname(path), exist_ok=True)
 eb.save_engine(eb.build_engine(synthetic_weights(1234), precision=args.precision, fuse=not args.unfused,
-                               hp_upto=-1 if args.plain_fp16 else None, robust=args.robust, tap_in_block=not args.tap_conv), path)
+                               hp_upto=-1 if args.plain_fp16 else None, robust=args.robust, tap_in_block=not args.tap_conv,
+                               float_form_upto=int(os.environ.get("WZ_FLOAT_UPTO", "12"))), path)
 eng = HipEngine(path, 0, args.batch, 640, 480)
 d = [eng.upload(synthetic_frame(640, 480, 1234 + i)) for i in range(args.batch)]
 for _ in range(20):

@@ -72,22 +72,34 @@ template <bool QE = false>
 __device__ __forceinline__ void wz_hp_unpack(const wz_u32x4_t t, wz_f32x2_t x[4]) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        if constexpr (QE)
-            x[r] = (wz_f32x2_t){__uint_as_float(((t[r] << 10) & 0x03FFFC00u) | WZ_HP_FE), __uint_as_float(((t[r] >> 6) & 0x03FFFC00u) | WZ_HP_FE)};
-        else
+        if constexpr (QE) {
+            // two instructions per value: isolate the 16 bits (v_and_b32 / v_bfe_u32), then v_lshl_or_b32 puts them at bits 10 .. 25
+            // under the exponent bits of 2^-7.  (Written as `(t << 10) & mask | FE` the compiler takes three for the low half.)
+            unsigned lo16, xlo;
+            const unsigned fe = WZ_HP_FE;
+            asm("v_and_b32 %0, 0xffff, %1" : "=v"(lo16) : "v"(t[r]));
+            asm("v_lshl_or_b32 %0, %1, 10, %2" : "=v"(xlo) : "v"(lo16), "v"(fe));
+            x[r] = (wz_f32x2_t){__uint_as_float(xlo), __uint_as_float(((t[r] >> 16) << 10) | WZ_HP_FE)};
+        } else
             x[r] = (wz_f32x2_t){(float)(t[r] & 0xffffu), (float)(t[r] >> 16)};
     }
 }
 // four values d = v / 6 (before the clamp) -> two words of float-form codes
+// (three instructions per value: the clamp as the output modifier of a packed multiply by one, a packed fma, then per value the
+// rounding add that also takes the exponent bias off, a shift, and one v_and_or_b32 per pair)
+__device__ __forceinline__ wz_f32x2_t wz_hp_clamp01_pk(const wz_f32x2_t d) {
+    wz_f32x2_t z;
+    asm("v_pk_mul_f32 %0, %1, 1.0 op_sel_hi:[1,0] clamp" : "=v"(z) : "v"(d));
+    return z;
+}
 __device__ __forceinline__ wz_u32x2_t wz_hp_fenc4(const float4_t d) {
-    unsigned q[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float z = __builtin_amdgcn_fmed3f(d[r], 0.0f, 1.0f);
-        const float t = __builtin_fmaf(z, WZ_HP_FK, WZ_HP_FC);
-        q[r] = (__float_as_uint(t) + (512u - WZ_HP_FE)) >> 10;      // round to 13 mantissa bits, rebias: 0 .. 65535
-    }
-    return (wz_u32x2_t){q[0] | (q[1] << 16), q[2] | (q[3] << 16)};
+    const wz_f32x2_t k2 = {WZ_HP_FK, WZ_HP_FK}, c2 = {WZ_HP_FC, WZ_HP_FC};
+    const wz_f32x2_t t01 = __builtin_elementwise_fma(wz_hp_clamp01_pk((wz_f32x2_t){d[0], d[1]}), k2, c2);
+    const wz_f32x2_t t23 = __builtin_elementwise_fma(wz_hp_clamp01_pk((wz_f32x2_t){d[2], d[3]}), k2, c2);
+    // round to 13 mantissa bits and take the exponent bias off: the code, 0 .. 65535, is then bits 10 .. 25
+    const unsigned a0 = __float_as_uint(t01[0]) + (512u - WZ_HP_FE), a1 = __float_as_uint(t01[1]) + (512u - WZ_HP_FE);
+    const unsigned a2 = __float_as_uint(t23[0]) + (512u - WZ_HP_FE), a3 = __float_as_uint(t23[1]) + (512u - WZ_HP_FE);
+    return (wz_u32x2_t){(a0 >> 10) | ((a1 << 6) & 0xffff0000u), (a2 >> 10) | ((a3 << 6) & 0xffff0000u)};
 }
 
 // d[0..3] += x[0..3] * (w0, w1) as four v_pk_fma_f32: the depthwise stage is bound by VALU issue, and a packed FMA
@@ -755,12 +767,7 @@ static int wz_launch_mbconv_hp_q(WzMbArgs a, int n, hipStream_t s, bool prepare)
         if (a.kc0 == 3 && nto == 6) return wz_hp_launch<8, true, false, 3, 1, 3, 6, 4, false, true, true, true>(a, n, s, prepare);
         return -1;
     }
-    // 10x10 maps: lean builds, 8 waves per 4 x 4 tile, 10 n-tiles per workgroup (block 16: two workgroups per tile).  Five n-tiles per
-    // workgroup and twice the workgroups was measured: blocks 14 / 15 18.9 -> 17.2 us alone, block 16 19.1 -> 34.3 us (288 workgroups that
-    // each take a whole CU: two rounds), 46.3 k -> 41.9 k frames/s (profiles/r03_robust_program.txt).
-    if (a.stride == 2) return (a.kc0 == 3 && nto == 10) ? wz_hp_launch<8, true, false, 6, 1, 3, 10, 2, false, true, true, true>(a, n, s, prepare) : -1;
-    if (a.kc0 == 5 && (nto == 10 || nto == 20)) return wz_hp_launch<8, true, false, 3, 1, 5, 10, 2, false, true, true, true>(a, n, s, prepare);
-    return -1;
+    return -1;   // (the 10x10 maps -- blocks 13 .. 16 -- keep the linear chunk buffer in the robust program: wz_launch_mbconv_hp below)
 }
 
 // Blocks 0 (with the stem) .. 12 of SSD-MobileNet-v2 300x300.  prepare: 0 = a kernel exists (its attributes are set),
@@ -805,6 +812,17 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
         return wz_hp_launch<4, false, true, 4, 2, 1, 2>(a, n, s, false);
     }
     if (a.cin0 == 0) return -1;
+    if (a.wout <= 10) {
+        // 10x10 maps (blocks 13 .. 16 of the ROBUST program; the default program runs them on wz_k_mbconv_cs): lean builds, 8 waves per
+        // 4 x 4 tile, 10 n-tiles per workgroup (block 16: two workgroups per tile), LINEAR chunk buffer -- with the float form in front of
+        // them the scores do not notice which form these four blocks use (tools/err_budget.py: 6.9e-4 both ways at two decades of channel
+        // spread), and the linear one is the cheapest to decode (robust program, round 4: 17.2 / 20.9 / 20.5 / 21.3 us in the float form).
+        // Five n-tiles per workgroup and twice the workgroups was measured in round 3: blocks 14 / 15 18.9 -> 17.2 us alone, block 16
+        // 19.1 -> 34.3 us (288 workgroups that each take a whole CU: two rounds), 46.3 k -> 41.9 k frames/s (profiles/r03_robust_program.txt).
+        if (a.stride == 2) return (a.kc0 == 3 && nto == 10) ? wz_hp_launch<8, true, false, 6, 1, 3, 10, 2, false, true, false, true>(a, n, s, prepare) : -1;
+        if (a.kc0 == 5 && (nto == 10 || nto == 20)) return wz_hp_launch<8, true, false, 3, 1, 5, 10, 2, false, true, false, true>(a, n, s, prepare);
+        return -1;
+    }
     if (a.wout > 19 && a.kc0 == 1 && nto == 2) {
         // Few frames (a single camera's frame at a time is the reference's normal load, detector.py:102-112): one wave per tile
         // would leave most CUs empty and every wave walking 5 - 6 chunks, ~2 us each -- there the chunks go to the waves of a

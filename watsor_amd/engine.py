@@ -231,7 +231,7 @@ def assign_slots(prog: "arch.Program", tensor_names: List[str]) -> List[int]:
 def build_engine(weights: Dict[str, np.ndarray], precision: int = 16, model_width: int = 300,
                  model_height: int = 300, post: Optional[dict] = None, fuse: bool = True,
                  fuse_stem: bool = True, hp_upto: Optional[int] = None, options: Optional[dict] = None,
-                 robust: bool = False, tap_in_block: bool = True) -> bytes:
+                 robust: bool = False, tap_in_block: bool = True, float_form_upto: int = 12) -> bytes:
     """Returns the engine image.  Mirrors `build_engine` of watsor/engine.py:17-51.
     fuse=False keeps one op per layer (used by the per-layer parity tests; same results, slower).
     hp_upto: last inverted-residual block on the split-operand kernel (default for the `-p 16` program with fused
@@ -240,6 +240,9 @@ def build_engine(weights: Dict[str, np.ndarray], precision: int = 16, model_widt
     robust (precision 16): ALL 17 blocks on the split-operand kernel and the expanded tensors kept as unorm16 of sqrt(x / 6) instead
     of x / 6 -- the program for weights whose channels live at very different scales (a folded trained BatchNorm), where the
     default program loses the tolerance.
+    float_form_upto (robust): the last block whose expanded tensor is kept in the 16-bit float form; the blocks behind it keep the
+    linear unorm16 buffer of the default program (tools/err_budget.py: blocks 13 .. 16 make no difference to the scores, the float form
+    costs them 2 us each).
     tap_in_block=False: block 13's expand conv -- the first SSD feature map -- as a launch of its own in front of the block instead of
     the block's second output (the program of rounds 1 .. 3; for A/B runs)."""
     if precision not in (16, 32):
@@ -333,7 +336,8 @@ def build_engine(weights: Dict[str, np.ndarray], precision: int = 16, model_widt
             cmid_pad = _align(op.cmid, 32)
             wdp = np.zeros((9, cmid_pad), np.float32)
             bdp = np.zeros(cmid_pad, np.float32)
-            if robust:
+            float_form = robust and op.block <= float_form_upto
+            if float_form:
                 # the buffer holds the 16-bit float form t = C + (x / 6) K (k_mbconv_hp.hip): x = (t - C) 6 / K, so the taps carry 6 / K
                 # and the bias takes -(6 C / K) * (sum of the channel's nine taps) -- exact on padding too, where t = C
                 w9 = wd.reshape(9, op.cmid)
@@ -350,7 +354,7 @@ def build_engine(weights: Dict[str, np.ndarray], precision: int = 16, model_widt
             bp = np.zeros(n_pad, np.float32)
             bp[:pj.cout] = b
             b_off = put(bp)
-            mb["flags"] = 1 | (2 if prog.tensors[op.dst].hp else 0) | (4 if robust else 0) | (8 if op.dup_out else 0)
+            mb["flags"] = 1 | (2 if prog.tensors[op.dst].hp else 0) | (4 if float_form else 0) | (8 if op.dup_out else 0)
             op_recs.append(_op_record(op, tindex, n_pad, kc, w_off, b_off, mb))
             continue
         if op.kind == arch.OP_MBCONV:
