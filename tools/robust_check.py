@@ -28,7 +28,7 @@ def worst(path, oracle_rows, frames):
             eng.detect_batch([f], [rows])
             got = np.frombuffer(rows, dtype=ROW_DTYPE)
             pairs, missing = pu.match_rows(got, ref, min_score=0.1)
-            w = max(w, max(abs(p[3]) for p in pairs))
+            w = max(w, max((abs(p[3]) for p in pairs), default=9.99))      # (9.99: no row found a partner)
             n += len(pairs)
     finally:
         eng.close()

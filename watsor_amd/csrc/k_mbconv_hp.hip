@@ -63,6 +63,9 @@ typedef __attribute__((ext_vector_type(2))) float wz_f32x2_t;
 // (tools/err_budget.py, modes q / T).  z = 0 is code 0 (C is a power of two), so out-of-frame halo pixels stay all-zero words.
 // Decoding is two integer operations per value and NO arithmetic: the depthwise weights carry 6 / K and the depthwise bias
 // -(6 C / K) * (sum of the channel's nine taps) (watsor_amd/engine.py), exact also where taps fall on padding (code 0 decodes to C).
+#ifndef WZ_HP_ASM_DEC
+#define WZ_HP_ASM_DEC 1   // 0: the decoder as the compiler writes it (three instructions for the low half)
+#endif
 #define WZ_HP_FC 0.0078125f
 #define WZ_HP_FK ((2.0f - 0.0001220703125f) - WZ_HP_FC)
 #define WZ_HP_FE 0x3C000000u   // exponent field of 2^-7 (120 << 23): code 0
@@ -72,7 +75,9 @@ template <bool QE = false>
 __device__ __forceinline__ void wz_hp_unpack(const wz_u32x4_t t, wz_f32x2_t x[4]) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        if constexpr (QE) {
+        if constexpr (QE && !WZ_HP_ASM_DEC) {
+            x[r] = (wz_f32x2_t){__uint_as_float(((t[r] << 10) & 0x03FFFC00u) | WZ_HP_FE), __uint_as_float(((t[r] >> 6) & 0x03FFFC00u) | WZ_HP_FE)};
+        } else if constexpr (QE) {
             // two instructions per value: isolate the 16 bits (v_and_b32 / v_bfe_u32), then v_lshl_or_b32 puts them at bits 10 .. 25
             // under the exponent bits of 2^-7.  (Written as `(t << 10) & mask | FE` the compiler takes three for the low half.)
             unsigned lo16, xlo;
@@ -85,12 +90,12 @@ __device__ __forceinline__ void wz_hp_unpack(const wz_u32x4_t t, wz_f32x2_t x[4]
     }
 }
 // four values d = v / 6 (before the clamp) -> two words of float-form codes
-// (three instructions per value: the clamp as the output modifier of a packed multiply by one, a packed fma, then per value the
-// rounding add that also takes the exponent bias off, a shift, and one v_and_or_b32 per pair)
+// (3.5 instructions per value: the clamp (v_max_f32 with the clamp modifier), a packed fma, then per value the rounding add that also
+// takes the exponent bias off, a shift, and one v_and_or_b32 per pair.  The clamp as the output modifier of a PACKED multiply by
+// one -- `v_pk_mul_f32 ..., 1.0 clamp`, half an instruction per value -- assembles and does not clamp on this part: measured, garbage
+// codes for negative pre-activations, profiles/r04_robust_program.txt.)
 __device__ __forceinline__ wz_f32x2_t wz_hp_clamp01_pk(const wz_f32x2_t d) {
-    wz_f32x2_t z;
-    asm("v_pk_mul_f32 %0, %1, 1.0 op_sel_hi:[1,0] clamp" : "=v"(z) : "v"(d));
-    return z;
+    return (wz_f32x2_t){__builtin_amdgcn_fmed3f(d[0], 0.0f, 1.0f), __builtin_amdgcn_fmed3f(d[1], 0.0f, 1.0f)};
 }
 __device__ __forceinline__ wz_u32x2_t wz_hp_fenc4(const float4_t d) {
     const wz_f32x2_t k2 = {WZ_HP_FK, WZ_HP_FK}, c2 = {WZ_HP_FC, WZ_HP_FC};
