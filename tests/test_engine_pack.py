@@ -381,7 +381,7 @@ def test_robust_program_packs_all_blocks_split_and_float_form_scaled(hp_blob, sy
     assert len(blocks) == 17
     for o, op in blocks:
         assert o["flags"] & 1 and tensors[o["src"]]["flags"] == 1 and o["cin0"] > 0
-        assert bool(o["flags"] & 4) == (op.block <= 12)          # the float form in front of the first SSD feature map, linear behind it
+        assert bool(o["flags"] & 4) == (op.block <= 9)           # the float form on the large maps, linear behind them (engine.build_engine: float_form_upto)
         assert bool(o["flags"] & 2) == bool(tensors[o["dst"]]["flags"]) == (op.block < 16)
         assert bool(o["flags"] & 8) == (op.block == 16) and tensors[o["dst"]]["c"] == (640 if op.block == 16 else o["cout"])
         dw = op.parts[-2]

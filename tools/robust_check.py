@@ -50,7 +50,8 @@ def main():
             b, c, s, _, _ = oracle.raw(f)
             refs.append(odet.rows_as_array(f.shape, b, c, s))
         line = "spread %.1f decades (measured %.2f, oracle %.0f s):" % (d, engine.channel_spread_decades(W), time.time() - t0)
-        for name, kw in (("default", {}), ("robust", {"robust": True, "float_form_upto": int(os.environ.get("WZ_FLOAT_UPTO", "12"))})):
+        for name, kw in (("default", {}), ("robust", {"robust": True, "float_form_upto": int(os.environ.get("WZ_FLOAT_UPTO", "9")),
+                                                    "conv1_split": os.environ.get("WZ_CONV1_SPLIT", "1") != "0"})):
             path = os.path.join(tmp, "%s_%s.bin" % (name, d))
             engine.save_engine(engine.build_engine(W, 16, **kw), path)
             e, n = worst(path, refs, frames)

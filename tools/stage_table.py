@@ -28,7 +28,8 @@ path = "/tmp/wz_stage_table/mi355x.bin"
 os.makedirs(os.path.dirname(path), exist_ok=True)
 eb.save_engine(eb.build_engine(synthetic_weights(1234), precision=args.precision, fuse=not args.unfused,
                                hp_upto=-1 if args.plain_fp16 else None, robust=args.robust, tap_in_block=not args.tap_conv,
-                               float_form_upto=int(os.environ.get("WZ_FLOAT_UPTO", "12"))), path)
+                               float_form_upto=int(os.environ.get("WZ_FLOAT_UPTO", "9")),
+                               conv1_split=(os.environ.get("WZ_CONV1_SPLIT", "1") != "0") if args.robust else None), path)
 eng = HipEngine(path, 0, args.batch, 640, 480)
 d = [eng.upload(synthetic_frame(640, 480, 1234 + i)) for i in range(args.batch)]
 for _ in range(20):

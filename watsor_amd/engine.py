@@ -231,7 +231,7 @@ def assign_slots(prog: "arch.Program", tensor_names: List[str]) -> List[int]:
 def build_engine(weights: Dict[str, np.ndarray], precision: int = 16, model_width: int = 300,
                  model_height: int = 300, post: Optional[dict] = None, fuse: bool = True,
                  fuse_stem: bool = True, hp_upto: Optional[int] = None, options: Optional[dict] = None,
-                 robust: bool = False, tap_in_block: bool = True, float_form_upto: int = 12) -> bytes:
+                 robust: bool = False, tap_in_block: bool = True, float_form_upto: int = 9, conv1_split: Optional[bool] = None) -> bytes:
     """Returns the engine image.  Mirrors `build_engine` of watsor/engine.py:17-51.
     fuse=False keeps one op per layer (used by the per-layer parity tests; same results, slower).
     hp_upto: last inverted-residual block on the split-operand kernel (default for the `-p 16` program with fused
@@ -241,8 +241,11 @@ def build_engine(weights: Dict[str, np.ndarray], precision: int = 16, model_widt
     of x / 6 -- the program for weights whose channels live at very different scales (a folded trained BatchNorm), where the
     default program loses the tolerance.
     float_form_upto (robust): the last block whose expanded tensor is kept in the 16-bit float form; the blocks behind it keep the
-    linear unorm16 buffer of the default program (tools/err_budget.py: blocks 13 .. 16 make no difference to the scores, the float form
-    costs them 2 us each).
+    linear unorm16 buffer of the default program.  Blocks 13 .. 16 make no difference to the scores (tools/err_budget.py) and the float
+    form costs them 2 us each; blocks 10 .. 12 buy 1e-4 at two decades of channel spread for 2.8 us (measured, round 4: up to block
+    9: 45.7 k frames/s, 7.6e-4 at 2.0 decades; up to block 12: 44.5 k, 6.7e-4).
+    conv1_split (robust, default on): Conv_1's weights as hi + lo halves over a doubled block-16 output (arch.build).  Off: +2.4 k
+    frames/s and 9.1e-4 instead of 7.6e-4 at two decades (6.9e-4 instead of 6.1e-4 at 1.5) -- inside the tolerance, without margin.
     tap_in_block=False: block 13's expand conv -- the first SSD feature map -- as a launch of its own in front of the block instead of
     the block's second output (the program of rounds 1 .. 3; for A/B runs)."""
     if precision not in (16, 32):
@@ -262,7 +265,7 @@ def build_engine(weights: Dict[str, np.ndarray], precision: int = 16, model_widt
     if hp_upto is None:
         hp_upto = (arch.HP_ALL_BLOCKS if robust else arch.HP_LAST_BLOCK) if (precision == 16 and fuse and fuse_stem) else -1
     prog = arch.build(model_width, fuse=fuse, fuse_stem=fuse_stem, hp_upto=hp_upto, input_pair=precision == 32, tap_in_block=tap_in_block,
-                      conv1_split=robust)
+                      conv1_split=robust if conv1_split is None else bool(conv1_split))
     missing = [n for n in prog.variable_shapes() if n not in weights]
     if missing:
         raise KeyError("model is missing %d variables, e.g. %s" % (len(missing), missing[0]))
