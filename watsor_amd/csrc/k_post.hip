@@ -350,7 +350,7 @@ __device__ __forceinline__ int wz_try_keep(NmsShared* S, int kept, const float4_
 
 // One band = all candidates whose score bits fall in histogram bins [lo_bin, hi_bin), `cnt` of them in
 // S->keys (unsorted composites).  Sort, gather boxes, walk.  Returns the new kept count (block-uniform).
-template <bool SIGNED>
+template <bool SIGNED, bool COUNT>
 __device__ int wz_nms_band(NmsShared* S, const WzPostBuffers& b, const WzPostConsts& k, int f, int cnt, int kept) {
     const int tid = threadIdx.x;
     const int A = k.num_anchors;
@@ -414,7 +414,7 @@ __device__ int wz_nms_band(NmsShared* S, const WzPostBuffers& b, const WzPostCon
     //      one-by-one walk keeps (a candidate's fate depends only on higher-scored boxes of its own class,
     //      so the members behind the cut cannot change the rows before it).
     const WzIouThr ithr = wz_iou_thr(k.iou_thr);
-    const bool count_classes = k.max_per_class < k.max_total;   // per-class cap can bind
+    constexpr bool count_classes = COUNT;   // k.max_per_class < k.max_total: the per-class cap can bind (a template parameter of the kernel)
     const int ncls = k.num_classes - 1;
     // the sort buffer that does not hold the sorted band is free: per-class tables live there
     int32_t* const first = reinterpret_cast<int32_t*>(sorted == S->keys2 ? S->keys : S->keys2);   // [ncls]
@@ -435,10 +435,11 @@ __device__ int wz_nms_band(NmsShared* S, const WzPostBuffers& b, const WzPostCon
                 S->cpre[i] = wz_pair_pre(0.0f, -1, ithr);
             }
         }
-        for (int c = tid; c < ncls; c += NMS_THREADS) {
-            first[c] = 0x7fffffff;
-            ccount[c] = 0;
-        }
+        if constexpr (count_classes)
+            for (int c = tid; c < ncls; c += NMS_THREADS) {
+                first[c] = 0x7fffffff;
+                ccount[c] = 0;
+            }
         if (tid < NMS_CHUNK / 64) S->keptmask[tid] = 0ull;
         __syncthreads();
         if (tid == 0 && base == 0) b.dbg[(size_t)f * 16 + 11] = wall_clock64();
@@ -476,7 +477,7 @@ __device__ int wz_nms_band(NmsShared* S, const WzPostBuffers& b, const WzPostCon
         if (tid < NMS_CHUNK) {   // words above the diagonal (members behind j) are empty
             for (int w = (tid >> 6) + 1; w < NMS_CHUNK / 64; ++w) S->supp[tid][w] = 0ull;
         }
-        if (count_classes) {   // per-class chains in band order (only needed when the per-class cap can bind)
+        if constexpr (count_classes) {   // per-class chains in band order (only needed when the per-class cap can bind)
             for (int j = tid; j < kept; j += NMS_THREADS) atomicAdd(&ccount[S->kcls[j]], 1);
             for (int i = tid; i < m; i += NMS_THREADS) {
                 atomicMin(&first[S->ccls[i]], i);
@@ -488,7 +489,7 @@ __device__ int wz_nms_band(NmsShared* S, const WzPostBuffers& b, const WzPostCon
         }
         __syncthreads();
         if (tid == 0 && base == 0) b.dbg[(size_t)f * 16 + 12] = wall_clock64();
-        if (!count_classes) {
+        if constexpr (!count_classes) {
             // Member j is kept iff it is not dead and no KEPT earlier member is in supp[j].  That is a
             // recurrence in band order with a unique solution; iterate "kept = alive & no kept suppressor"
             // from "everything alive is kept": after r rounds the first r members are final, and the
@@ -700,6 +701,9 @@ __device__ uint32_t wz_nms_scan_band(NmsShared* S, const WzPostBuffers& b, const
 // uses a slot of its class, but is no row --, then the kept boxes are clipped and the first max_total that still have an area are
 // the rows.  `status[f]` = 1 if the kept list filled up before max_total rows with an area were found (more than
 // NMS_KEEP_MAX - max_total selected boxes entirely outside the image: the frame's rows may be short; wz_collect reports it).
+// SELF / CLIP: the two run-time modes as template parameters (`self_scan`, WzPostConsts::clip_after): one copy of the band walk per
+// kernel instead of four inlined ones -- the kernel lives at 128 registers (1024 threads) and spills; what is not there cannot.
+template <bool SELF, bool CLIP, bool COUNT>
 __global__ __launch_bounds__(NMS_THREADS) void wz_k_nms(WzPostBuffers b, WzPostConsts kc,
                                                         const WzFrameDesc* __restrict__ frames,
                                                         const WzCamFilter* __restrict__ cams,
@@ -710,14 +714,14 @@ __global__ __launch_bounds__(NMS_THREADS) void wz_k_nms(WzPostBuffers b, WzPostC
     const int f = blockIdx.x, tid = threadIdx.x;
     const int out_total = kc.max_total;
     WzPostConsts k = kc;
-    if (kc.clip_after) k.max_total = NMS_KEEP_MAX;           // the walk's "enough" (and the kept list's capacity)
+    if (CLIP) k.max_total = NMS_KEEP_MAX;                    // the walk's "enough" (and the kept list's capacity)
     const int A = k.num_anchors;
 #define NMS_STAMP(i) do { if (tid == 0) b.dbg[(size_t)f * 16 + (i)] = wall_clock64(); } while (0)
     NMS_STAMP(0);
     uint32_t processed = 0;
     int kept = 0;
     if (tid == 0) S->kept = 0;
-    if (self_scan) {
+    if constexpr (SELF) {
         // the bit map of the listed candidates is requested before anything else: with the hint, the logits and the
         // validity bytes behind it the first band is a chain of global-memory latencies (~2 us each on a busy chip)
         constexpr int WPT = 8;                               // words per thread (the launcher checks that this covers the map)
@@ -790,7 +794,7 @@ __global__ __launch_bounds__(NMS_THREADS) void wz_k_nms(WzPostBuffers b, WzPostC
                 kept = wz_nms_band_serial(S, b, k, f, kept, (unsigned long long)((uint32_t)lo_bin << 20) << 32,
                                           (unsigned long long)((uint32_t)hi_bin << 20) << 32);
             else if (cnt > 0)
-                kept = kc.clip_after ? wz_nms_band<true>(S, b, k, f, (int)cnt, kept) : wz_nms_band<false>(S, b, k, f, (int)cnt, kept);
+                kept = wz_nms_band<CLIP, COUNT>(S, b, k, f, (int)cnt, kept);
             processed += cnt;
             if (first) { NMS_STAMP(3); if (tid == 0) { b.dbg[(size_t)f * 16 + 8] = cnt; b.dbg[(size_t)f * 16 + 9] = kept; } }
             first = false;
@@ -847,7 +851,7 @@ __global__ __launch_bounds__(NMS_THREADS) void wz_k_nms(WzPostBuffers b, WzPostC
             kept = wz_nms_band_serial(S, b, k, f, kept, (unsigned long long)((uint32_t)lo_bin << 20) << 32,
                                       (unsigned long long)((uint32_t)hi_bin << 20) << 32);
         else if (cnt_raw > 0)
-            kept = kc.clip_after ? wz_nms_band<true>(S, b, k, f, (int)cnt_raw, kept) : wz_nms_band<false>(S, b, k, f, (int)cnt_raw, kept);
+            kept = wz_nms_band<CLIP, COUNT>(S, b, k, f, (int)cnt_raw, kept);
         processed += cnt_raw;
         if (first) { NMS_STAMP(3); if (tid == 0) { b.dbg[(size_t)f * 16 + 8] = cnt_raw; b.dbg[(size_t)f * 16 + 9] = kept; } }
         if (kept >= k.max_total || processed >= total || lo_bin == 0) break;
@@ -863,7 +867,7 @@ __global__ __launch_bounds__(NMS_THREADS) void wz_k_nms(WzPostBuffers b, WzPostC
     const float* oscore = S->kscore;
     const int32_t* ocls = S->kcls;
     uint32_t overflow = 0;
-    if (kc.clip_after) {
+    if constexpr (CLIP) {
         for (int i = tid; i < NMS_KEEP_MAX; i += NMS_THREADS) {
             float4_t c = {0.f, 0.f, 0.f, 0.f};
             bool ok = false;
@@ -1060,14 +1064,27 @@ void wz_launch_compact(const WzPostBuffers& b, const WzPostConsts& c, int n, hip
     hipLaunchKernelGGL(wz_k_compact, grid, dim3(256), 0, s, b, c);
 }
 void wz_post_init() {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wz_k_nms), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)sizeof(NmsShared));
+#define WZ_NMS_ATTR(SELF, CLIP, COUNT) \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wz_k_nms<SELF, CLIP, COUNT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(NmsShared))
+    WZ_NMS_ATTR(true, false, false); WZ_NMS_ATTR(true, false, true); WZ_NMS_ATTR(true, true, false); WZ_NMS_ATTR(true, true, true);
+    WZ_NMS_ATTR(false, false, false); WZ_NMS_ATTR(false, false, true); WZ_NMS_ATTR(false, true, false); WZ_NMS_ATTR(false, true, true);
+#undef WZ_NMS_ATTR
 }
 void wz_launch_nms(const WzPostBuffers& b, const WzPostConsts& c, int n, hipStream_t s, const WzFrameDesc* d_frames,
                    const WzCamFilter* d_cams, wz_detection_t* rows, uint8_t* pass, bool self_scan, bool listed, uint32_t* status) {
     if (((c.num_anchors * c.num_classes + 31) >> 5) > 8 * NMS_THREADS) listed = false;   // bit map larger than one pass: scan instead
-    hipLaunchKernelGGL(wz_k_nms, dim3(n), dim3(NMS_THREADS), sizeof(NmsShared), s, b, c, d_frames, d_cams, rows, pass,
-                       self_scan ? 1 : 0, (self_scan && listed) ? 1 : 0, status);
+    const int ls = (self_scan && listed) ? 1 : 0;
+    const bool count = c.max_per_class < c.max_total;   // the per-class cap can bind: one thread per class walks its chain (wz_nms_band)
+#define WZ_NMS_GO(SELF, CLIP, COUNT) \
+    hipLaunchKernelGGL((wz_k_nms<SELF, CLIP, COUNT>), dim3(n), dim3(NMS_THREADS), sizeof(NmsShared), s, b, c, d_frames, d_cams, rows, pass, SELF ? 1 : 0, SELF ? ls : 0, status)
+    if (self_scan) {
+        if (!c.clip_after) { if (!count) WZ_NMS_GO(true, false, false); else WZ_NMS_GO(true, false, true); }
+        else { if (!count) WZ_NMS_GO(true, true, false); else WZ_NMS_GO(true, true, true); }
+    } else {
+        if (!c.clip_after) { if (!count) WZ_NMS_GO(false, false, false); else WZ_NMS_GO(false, false, true); }
+        else { if (!count) WZ_NMS_GO(false, true, false); else WZ_NMS_GO(false, true, true); }
+    }
+#undef WZ_NMS_GO
 }
 void wz_launch_rows(const WzPostBuffers& b, const WzFrameDesc* d_frames, const WzCamFilter* d_cams, int n,
                     int max_total, wz_detection_t* rows, uint8_t* pass, hipStream_t s) {
