@@ -356,22 +356,31 @@ __device__ int wz_nms_band(NmsShared* S, const WzPostBuffers& b, const WzPostCon
     const int A = k.num_anchors;
     unsigned long long* sorted = S->keys;
     if (cnt <= NMS_RANK_MAX) {
-        // rank sort: keys are unique (the tie index is), so rank = #larger keys is a permutation.
-        // Every thread streams the whole list from LDS, 8 keys per step (same address = broadcast).
+        // rank sort: keys are unique (the tie index is), so rank = #larger keys is a permutation.  A key's rank is counted by P threads
+        // (a power of two: the P threads of a key are neighbours in one wavefront), each over its share of the list -- 8 keys per step
+        // from LDS, same address = broadcast; 64-bit compares run at a quarter of the rate, and with one thread per key a few hundred
+        // candidates left 3/4 of the workgroup idle through 270 of them -- and the partial ranks are summed with shuffles.
         const int cnt8 = (cnt + 7) & ~7;
+        int P = 1;
+        while (P < 16 && cnt * (P * 2) <= NMS_THREADS) P *= 2;
+        const int share = (((cnt8 + P - 1) / P) + 7) & ~7;    // keys per part, a multiple of 8
         for (int i = cnt + tid; i < cnt8; i += NMS_THREADS) S->keys[i] = 0ull;   // 0 is never "larger"
         __syncthreads();
-        for (int i = tid; i < cnt; i += NMS_THREADS) {
+        for (int t0 = 0; t0 < cnt * P; t0 += NMS_THREADS) {   // (one trip unless the list is longer than the workgroup)
+            const int t = t0 + tid;
+            const int i = min(t / P, cnt - 1), part = t & (P - 1);
             const unsigned long long mine = S->keys[i];
+            const int j0 = part * share, j1 = min(j0 + share, cnt8);
             int r = 0;
-            for (int j = 0; j < cnt8; j += 8) {
+            for (int j = j0; j < j1; j += 8) {
                 unsigned long long kk[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) kk[u] = S->keys[j + u];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) r += (kk[u] > mine) ? 1 : 0;
             }
-            S->keys2[r] = mine;
+            for (int o = 1; o < P; o <<= 1) r += __shfl_xor(r, o);
+            if (part == 0 && t < cnt * P) S->keys2[r] = mine;
         }
         __syncthreads();
         sorted = S->keys2;
@@ -419,8 +428,195 @@ __device__ int wz_nms_band(NmsShared* S, const WzPostBuffers& b, const WzPostCon
     // the sort buffer that does not hold the sorted band is free: per-class tables live there
     int32_t* const first = reinterpret_cast<int32_t*>(sorted == S->keys2 ? S->keys : S->keys2);   // [ncls]
     int32_t* const ccount = first + 4096;                                                          // [ncls]
-    for (int base = 0; base < cnt && kept < k.max_total; base += NMS_CHUNK) {
-        const int m = min(NMS_CHUNK, cnt - base);
+    // (a FIRST chunk of 128 candidates was tried: a quarter of the pair work when it is the only one -- but the benchmark's scenes keep
+    // 100 of ~270 candidates, the second chunk then costs its fixed part again: 27 -> 37 us; profiles/r04_nms_pair_list.txt)
+    for (int base = 0, m = 0; base < cnt && kept < k.max_total; base += m) {
+        m = min(NMS_CHUNK, cnt - base);
+        if constexpr (!count_classes) {
+            // ---- the chunk as a list of same-class PAIRS (round 4).  Only members of one class can suppress each other, and the blocks
+            // of the 256 x 256 pair matrix hold all classes mixed: walked block by block (the COUNT path below, rounds 1 .. 3) every
+            // lane tests 128 earlier members on average, ~30 instructions each, whatever their class -- 10.6 us of a 28 us kernel,
+            // dealt out statically over the SIMDs.  Here the members are grouped by class (a counting sort with LDS atomics: the order
+            // INSIDE a class is whatever the atomics made it -- which of two members is the earlier one is read from their band indices),
+            // the same-class pairs are numbered class after class, and the pair numbers are dealt out evenly: every wavefront takes a
+            // run of them, its lanes consecutive pairs (neighbouring lanes read neighbouring members: no bank conflicts, the later
+            // member of a pair mostly a broadcast).  A trained detector's scene (dozens of classes in a band): 10.5 -> 2 - 3 us; one class
+            // holding everything: the same pairs as before.  Classes are bucketed modulo 128 (two classes in one bucket only cost
+            // pair tests: the test compares classes).
+            int32_t* const posn = first + 256;      // [256]  rank inside its bucket, then its position in class order
+            int32_t* const bcnt = first + 512;      // [128]  members per bucket
+            int32_t* const bstart = first + 640;    // [128]  first position of a bucket
+            int32_t* const pstart = first + 768;    // [129]  pairs in front of a bucket's own (exclusive prefix), [128] = all
+            int32_t* const orig = S->cnext;         // [256]  band index of the member at a position
+            uint32_t* const supp32 = reinterpret_cast<uint32_t*>(&S->supp[0][0]);   // [256][8]: bit a of row b = "a suppresses b"
+            if (tid < 128) bcnt[tid] = 0;
+            S->supp[tid >> 2][tid & 3] = 0ull;      // (NMS_THREADS == NMS_CHUNK * NMS_CHUNK / 64: one word each)
+            if (tid < NMS_CHUNK / 64) S->keptmask[tid] = 0ull;
+            if (tid < 8) S->hist[tid] = 0u;
+            if (tid < NMS_CHUNK) S->cdead[tid] = 0u;
+            __syncthreads();
+            int my_cls = -1;
+            if (tid < m) {
+                const uint32_t tie = 0xFFFFFFFFu - (uint32_t)(sorted[base + tid] & 0xFFFFFFFFull);
+                my_cls = (int)(tie / (uint32_t)A);
+                posn[tid] = atomicAdd(&bcnt[my_cls & 127], 1);
+            }
+            __syncthreads();
+            if (tid < 64) {   // buckets 2 l, 2 l + 1: starts (exclusive prefix of the counts) and pair prefix, one wavefront
+                const int n0 = bcnt[2 * tid], n1 = bcnt[2 * tid + 1];
+                const int ms = n0 + n1, ps = n0 * (n0 - 1) / 2 + n1 * (n1 - 1) / 2;
+                int mi = ms, pi = ps;                                     // inclusive scans over the lanes
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int um = __shfl_up(mi, o), up = __shfl_up(pi, o);
+                    if (tid >= o) { mi += um; pi += up; }
+                }
+                bstart[2 * tid] = mi - ms;
+                bstart[2 * tid + 1] = mi - ms + n0;
+                pstart[2 * tid] = pi - ps;
+                pstart[2 * tid + 1] = pi - ps + n0 * (n0 - 1) / 2;
+                if (tid == 63) pstart[128] = pi;
+            }
+            __syncthreads();
+            if (tid < NMS_CHUNK) {
+                if (tid < m) {
+                    const int p = bstart[my_cls & 127] + posn[tid];
+                    posn[tid] = p;
+                    float ar;
+                    S->ccls[p] = my_cls;
+                    S->cnorm[p] = wz_norm_box(S->sbox[base + tid], ar);
+                    S->carea[p] = ar;
+                    S->cpre[p] = wz_pair_pre(ar, my_cls, ithr);
+                    orig[p] = tid;
+                } else {
+                    S->ccls[tid] = -1;
+                    S->cpre[tid] = wz_pair_pre(0.0f, -1, ithr);
+                }
+            }
+            __syncthreads();
+            if (tid == 0 && base == 0) b.dbg[(size_t)f * 16 + 11] = wall_clock64();
+            for (int p = tid; p < m * kept; p += NMS_THREADS) {          // vs boxes kept before this chunk
+                const int i = p / kept, j = p - i * kept;
+                if (wz_pair_suppresses<SIGNED>(S->cnorm[i], S->cpre[i], S->knorm[j], S->kpre[j], ithr))
+                    S->cdead[i] = 1u;                                    // benign race: every writer stores 1
+            }
+            {   // pair numbers: wave w takes [w * run, (w + 1) * run), lane l of it the numbers w * run + l, + 64, + 128, ...
+                const int total = pstart[128];
+                const int run = (((total + NMS_THREADS / 64 - 1) / (NMS_THREADS / 64)) + 63) & ~63;
+                int Q = (tid >> 6) * run + (tid & 63);
+                const int Q1 = min(((tid >> 6) + 1) * run, total);
+                if (Q < Q1) {
+                    auto bucket_of = [&](int Qx) {                        // the bucket holding pair Qx: pstart[c] <= Qx < pstart[c + 1]
+                        int lo = 0, hi = 128;                             // (seven dependent LDS reads; walking the buckets one by one
+                        while (hi - lo > 1) {                             //  across the empty ones of a 90-class table cost up to 70)
+                            const int mid = (lo + hi) >> 1;
+                            if (pstart[mid] <= Qx) lo = mid; else hi = mid;
+                        }
+                        return lo;
+                    };
+                    int c = bucket_of(Q);
+                    int pb = bstart[c], pend = pstart[c + 1];
+                    const int q = Q - pstart[c];                          // pair (a < b) number q of this bucket: q = b (b - 1) / 2 + a
+                    int bb = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)q)) * 0.5f);
+                    while (bb * (bb - 1) / 2 > q) --bb;
+                    while ((bb + 1) * bb / 2 <= q) ++bb;
+                    int aa = q - bb * (bb - 1) / 2;
+                    for (;;) {
+                        const int pa = pb + aa, pbb = pb + bb;
+                        if (wz_pair_suppresses<SIGNED>(S->cnorm[pbb], S->cpre[pbb], S->cnorm[pa], S->cpre[pa], ithr)) {
+                            const bool a_first = orig[pa] < orig[pbb];    // the earlier one in the band suppresses the later one
+                            const int pe = a_first ? pa : pbb, pl = a_first ? pbb : pa;
+                            atomicOr(&supp32[pl * 8 + (pe >> 5)], 1u << (pe & 31));
+                        }
+                        Q += 64;
+                        if (Q >= Q1) break;
+                        aa += 64;
+                        if (Q >= pend) {                                  // into a later bucket
+                            c = bucket_of(Q);
+                            pb = bstart[c];
+                            aa = Q - pstart[c];
+                            bb = 1;
+                            pend = pstart[c + 1];
+                        }
+                        while (aa >= bb) {                                // row b of the triangle holds b pairs
+                            aa -= bb;
+                            ++bb;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid == 0 && base == 0) b.dbg[(size_t)f * 16 + 12] = wall_clock64();
+            // Member p (class order) is kept iff it is not dead and no KEPT earlier member is in supp[p]: the recurrence of the COUNT
+            // path below, in class order -- a member only depends on earlier members of its own class, which precede it here as well.
+            if (tid < 64) {
+                unsigned long long row[NMS_CHUNK / 64][NMS_CHUNK / 64];
+                bool alive[NMS_CHUNK / 64];
+                unsigned long long km[NMS_CHUNK / 64];
+#pragma unroll
+                for (int q = 0; q < NMS_CHUNK / 64; ++q) {
+                    const int j = tid + 64 * q;
+#pragma unroll
+                    for (int w = 0; w < NMS_CHUNK / 64; ++w) row[q][w] = S->supp[j][w];
+                    alive[q] = j < m && !S->cdead[j];
+                    km[q] = __ballot(alive[q]);
+                }
+                for (int round = 0; round <= NMS_CHUNK; ++round) {
+                    unsigned long long nk[NMS_CHUNK / 64];
+                    bool same = true;
+#pragma unroll
+                    for (int q = 0; q < NMS_CHUNK / 64; ++q) {
+                        unsigned long long hit = 0ull;
+#pragma unroll
+                        for (int w = 0; w < NMS_CHUNK / 64; ++w) hit |= row[q][w] & km[w];
+                        nk[q] = __ballot(alive[q] && hit == 0ull);
+                        same = same && nk[q] == km[q];
+                    }
+#pragma unroll
+                    for (int q = 0; q < NMS_CHUNK / 64; ++q) km[q] = nk[q];
+                    if (same) break;
+                }
+                // the kept bits in BAND order (the rows come out by score): member p sets the bit of its band index
+#pragma unroll
+                for (int q = 0; q < NMS_CHUNK / 64; ++q) {
+                    const int pp = tid + 64 * q;
+                    if ((km[q] >> tid) & 1ull) atomicOr(&S->hist[orig[pp] >> 5], 1u << (orig[pp] & 31));
+                }
+            }
+            __syncthreads();
+            if (tid == 0 && base == 0) b.dbg[(size_t)f * 16 + 13] = wall_clock64();
+            unsigned long long bandmask[NMS_CHUNK / 64];
+            int total_new = 0;
+#pragma unroll
+            for (int w = 0; w < NMS_CHUNK / 64; ++w) {
+                bandmask[w] = (unsigned long long)S->hist[2 * w] | ((unsigned long long)S->hist[2 * w + 1] << 32);
+                total_new += __popcll(bandmask[w]);
+            }
+            for (int i = tid; i < m; i += NMS_THREADS) {                 // materialise the newly kept rows, band order
+                unsigned long long mine = 0ull;
+                int before = 0;
+#pragma unroll
+                for (int w = 0; w < NMS_CHUNK / 64; ++w) {
+                    if (w == (i >> 6)) mine = bandmask[w];
+                    if (w < (i >> 6)) before += __popcll(bandmask[w]);
+                }
+                if (!((mine >> (i & 63)) & 1ull)) continue;
+                before += __popcll(mine & ((1ull << (i & 63)) - 1ull));
+                const int j = kept + before;
+                if (j >= k.max_total) continue;
+                const int p = posn[i];
+                const unsigned long long comp = sorted[base + i];
+                S->kbox[j] = S->sbox[base + i];
+                S->knorm[j] = S->cnorm[p];
+                S->karea[j] = S->carea[p];
+                S->kpre[j] = S->cpre[p];
+                S->kcls[j] = S->ccls[p];
+                S->kscore[j] = __uint_as_float((uint32_t)(comp >> 32));
+            }
+            __syncthreads();
+            kept = min(kept + total_new, k.max_total);
+            continue;
+        }
         for (int i = tid; i < NMS_CHUNK; i += NMS_THREADS) {
             S->cdead[i] = 0u;
             if (i < m) {
