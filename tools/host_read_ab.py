@@ -25,7 +25,10 @@ from watsor_amd.synth import synthetic_frame, synthetic_weights      # noqa: E40
 MODES = [("per-pixel kernel, staged", dict(WZ_PRE_ROWS="0", WZ_HOST_READ="0")),
          ("row kernel, staged", dict(WZ_PRE_ROWS="1", WZ_HOST_READ="0")),
          ("row kernel, in place", dict(WZ_HOST_READ="1")),
-         ("row kernel, in place if >= 2x", dict(WZ_HOST_READ="2"))]
+         ("row kernel, in place if >= 2x", dict(WZ_HOST_READ="2")),
+         ("defaults (per-pixel kernel for staged batches, row kernel in place for frames >= 2x)", dict())]
+# (tried and removed, round 4: the staged frames of a batch as ONE hipMemcpyBatchAsync -- 32.6 k against 32.7 k frames/s at 640x480,
+# the runtime issues the same copies one by one; profiles/r04_host_read_ab.txt)
 
 
 def throughput(eng, submit, n, steps, warm=16):
@@ -58,8 +61,8 @@ def main():
     for i in range(8):
         nv[i] = big[i].reshape(-1)[:nv[i].size].reshape(1620, 1920)
     ref_rows = {}
-    for label, env in MODES:
-        for k in ("WZ_PRE_ROWS", "WZ_HOST_READ"):
+    for label, env in (MODES[-1:] if "--defaults" in sys.argv else MODES):
+        for k in ("WZ_PRE_ROWS", "WZ_HOST_READ", "WZ_BATCH_COPY"):
             os.environ.pop(k, None)
         os.environ.update(env)
         eng = HipEngine(path, 0, 16, 1920, 1080, dev=True)
