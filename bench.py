@@ -46,6 +46,13 @@ SCORE_TOLERANCE = 1e-3       # BASELINE.json north_star: "box scores within 1e-3
 MIN_ROUNDS, MAX_ROUNDS, ROUNDS_BUDGET_S = 25, 400, 1.0
 RING = 5                     # batches of distinct frames the timed loop cycles through (coprime with the 4 lanes)
 PROFILE_INNER = 8            # launches per bracket in the stage profile (wz_profile_stages)
+# The program the headline is timed on: the ROBUST `-p 16` program (all 17 blocks on split operands, float-form chunk buffer on the
+# large maps, Conv_1 with split weights) -- the one `python -m watsor_amd.engine` builds for weights whose BatchNorm-folded channels are
+# spread over more than 0.45 decades, i.e. for a TRAINED checkpoint (per-channel ranges of a folded MobileNet-v2 differ by orders of
+# magnitude -- the reason per-tensor quantisation of this network needs cross-layer equalisation).  It holds the north star's 1e-3 at
+# 0 / 1 / 1.5 / 2 decades of spread (tests/test_gpu_stress.py); the default program, faster, holds it only on weights whose channels live
+# at one scale -- such as this benchmark's seeded random-init weights -- and is reported beside it (`default_program_engine`).
+HEADLINE_PROGRAM = dict(robust=True)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -88,10 +95,11 @@ def algorithmic_cost(op, n):
         return 2.0 * M * c * 9, 2.0 * (n * op["hin"] * op["win"] * c + 9 * c + M * c)
     if op["kind"] == arch.OP_STEM:
         return 2.0 * M * 32 * 27, 2.0 * (n * op["hin"] * op["win"] * 4 + M * 32) + 27 * 32 * 4
-    K = op["ksize"] ** 2 * op["cin"]
+    cin = op["cin"] // 2 if (op["name"].endswith("Conv_1") and op["cin"] == 640) else op["cin"]   # (split weights double K, not the layer)
+    K = op["ksize"] ** 2 * cin
     N = op["cout"]
     out_bytes = 4.0 if op["name"].startswith("BoxPredictor") else 2.0     # head outputs are fp32
-    return 2.0 * M * N * K, 2.0 * (n * op["hin"] * op["win"] * op["cin"] + K * N) + out_bytes * M * N
+    return 2.0 * M * N * K, 2.0 * (n * op["hin"] * op["win"] * cin + K * N) + out_bytes * M * N
 
 
 def fused_min_bytes(op, n, hp, hp_out):
@@ -292,7 +300,7 @@ def schedule_child():
     d = "/tmp/wz_sched_child_%d" % os.getpid()
     os.makedirs(d, exist_ok=True)
     path = os.path.join(d, "mi355x.bin")
-    builder.save_engine(builder.build_engine(synthetic_weights(1234)), path)
+    builder.save_engine(builder.build_engine(synthetic_weights(1234), **HEADLINE_PROGRAM), path)
     eng = HipEngine(path, int(os.environ.get("LOCAL_RANK", "0")), BATCH, WIDTH, HEIGHT)
     try:
         dfr = [eng.upload(synthetic_frame(WIDTH, HEIGHT, 1234 + i)) for i in range(RING * BATCH)]
@@ -328,7 +336,7 @@ def pmc_child():
     d = "/tmp/wz_pmc_child_%d" % os.getpid()
     os.makedirs(d, exist_ok=True)
     path = os.path.join(d, "mi355x.bin")
-    builder.save_engine(builder.build_engine(synthetic_weights(1234)), path)
+    builder.save_engine(builder.build_engine(synthetic_weights(1234), **HEADLINE_PROGRAM), path)
     eng = HipEngine(path, int(os.environ.get("LOCAL_RANK", "0")), BATCH, WIDTH, HEIGHT)
     try:
         fr = [eng.upload(synthetic_frame(WIDTH, HEIGHT, 1234 + i)) for i in range(BATCH)]
@@ -651,7 +659,7 @@ def busy_scene_leg(frames, rank):
     d = "/tmp/wz_bench_busy_%d_%d" % (os.getpid(), rank)
     os.makedirs(d, exist_ok=True)
     path = os.path.join(d, "mi355x.bin")
-    builder.save_engine(builder.build_engine(synthetic_weights(1234, class_gain=1.3)), path)
+    builder.save_engine(builder.build_engine(synthetic_weights(1234, class_gain=1.3), **HEADLINE_PROGRAM), path)
     eng = HipEngine(path, int(os.environ.get("LOCAL_RANK", "0")), BATCH, WIDTH, HEIGHT)
     try:
         dfr = [eng.upload(f) for f in frames[:RING * BATCH]]
@@ -742,41 +750,49 @@ def plain_fp16_leg(weights, frames, rank):
     return r
 
 
-def robust_engine_leg(weights, frames, rank):
-    """The `--robust` program (all 17 blocks split, square-root chunk buffer) on the headline workload, and what it is for: the scores of
-    both `-p 16` programs against the oracle on weights whose channels are spread over 1.5 decades (watsor_amd/synth.py:
+def default_program_leg(weights, frames, rank):
+    """The DEFAULT `-p 16` program (blocks 0 .. 12 split, linear chunk buffer, blocks 13 .. 16 plain fp16) on the headline workload --
+    what the builder packs for weights whose channels live at one scale, like this benchmark's -- and why it is not the headline: the
+    scores of both programs against the oracle on weights whose channels are spread over 1.5 and 2.0 decades (watsor_amd/synth.py:
     spread_channel_scales -- what folding a trained BatchNorm does to the channel amplitudes)."""
     from watsor_amd import engine as builder
     from watsor_amd.runtime import HipEngine
     from watsor_amd.synth import spread_channel_scales
-    d = "/tmp/wz_bench16r_%d_%d" % (os.getpid(), rank)
+    d = "/tmp/wz_bench16d_%d_%d" % (os.getpid(), rank)
     os.makedirs(d, exist_ok=True)
     path = os.path.join(d, "mi355x.bin")
     dev = int(os.environ.get("LOCAL_RANK", "0"))
     r = {}
     try:
-        spread = spread_channel_scales(weights, 1.5)
-        for name, w, kw in (("headline", weights, dict(robust=True)), ("spread_default", spread, {}), ("spread_robust", spread, dict(robust=True))):
+        runs = [("headline", weights, {})]
+        for dec in (1.5, 2.0):
+            sw = spread_channel_scales(weights, dec)
+            runs += [("default_%s" % str(dec).replace(".", "p"), sw, {}), ("robust_%s" % str(dec).replace(".", "p"), sw, dict(robust=True))]
+        for name, w, kw in runs:
             builder.save_engine(builder.build_engine(w, **kw), path)
             eng = HipEngine(path, dev, BATCH, WIDTH, HEIGHT)
             try:
-                dfr = [eng.upload(f) for f in frames[:BATCH]]
+                dfr = [eng.upload(f) for f in frames[:RING * BATCH]]
                 if name == "headline":
-                    r = throughput(eng, lambda lane, s: eng.submit_device(lane, dfr, [WIDTH] * BATCH, [HEIGHT] * BATCH), BATCH, steps=600, warm=60)
+                    nb = len(dfr) // BATCH
+                    r = throughput(eng, lambda lane, s: eng.submit_device(lane, dfr[(s % nb) * BATCH:(s % nb + 1) * BATCH], [WIDTH] * BATCH, [HEIGHT] * BATCH),
+                                   BATCH, steps=600, warm=60)
                 par = parity_leg(eng, frames, dfr, w)
             finally:
                 eng.close()
             if name == "headline":
-                r.update(dtype="f16", max_dscore=par["max_dscore"], within_tolerance=par["within_tolerance"])
+                r.update(dtype="f16", max_dscore=par["max_dscore"], max_dbox_px=par["max_dbox_px"], within_tolerance=par["within_tolerance"])
             else:
-                r["max_dscore_%s_program_weights_spread_1p5_decades" % name.split("_")[1]] = par["max_dscore"]
-        r["channel_spread_decades"] = dict(headline=round(builder.channel_spread_decades(weights), 2), spread=round(builder.channel_spread_decades(spread), 2))
+                prog, dec = name.split("_")
+                r["max_dscore_%s_program_weights_spread_%s_decades" % (prog, dec)] = par["max_dscore"]
+        r["channel_spread_decades_of_the_benchmark_weights"] = round(builder.channel_spread_decades(weights), 2)
     finally:
         if os.path.exists(path):
             os.remove(path)
         os.rmdir(d)
-    r["workload"] = ("the headline workload on the --robust program (what `python -m watsor_amd.engine` builds when the folded weights spread their "
-                     "channels over more than %.2f decades); max_dscore_*: both programs against the oracle on such weights" % builder.SPREAD_VALIDATED_DECADES)
+    r["workload"] = ("the headline workload on the DEFAULT -p 16 program (what `python -m watsor_amd.engine` builds when the folded weights keep their "
+                     "channels within %.2f decades); max_dscore_*: both programs against the oracle on weights spread over 1.5 / 2.0 decades"
+                     % builder.SPREAD_VALIDATED_DECADES)
     return r
 
 
@@ -967,7 +983,7 @@ def main():
         open(engine_path, "wb").close()
     else:
         weights = synthetic_weights(1234)
-        builder.save_engine(builder.build_engine(weights), engine_path)     # the default -p 16 program
+        builder.save_engine(builder.build_engine(weights, **HEADLINE_PROGRAM), engine_path)     # the robust -p 16 program (HEADLINE_PROGRAM)
 
     note("engine file built")
     eng = HipEngine(engine_path, local_rank, BATCH, WIDTH, HEIGHT)
@@ -1092,7 +1108,9 @@ def main():
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": "1 synthetic 640x480 RGB stream per GPU, batch=8 frames, SSD-MobileNet-v2 300x300 "
                                    "(seeded random-init weights), frames resident in HBM, rows copied back to host",
-                       "engine": "-p 16 (fp16 MFMA; stem + blocks 0..%d with split hi+lo operands, the rest plain fp16)" % (hp_blocks - 1)
+                       "engine": ("-p 16 --robust (fp16 MFMA; all 17 blocks with split hi+lo operands, 16-bit float-form chunk buffer up to block 9, "
+                                  "Conv_1 with split weights): the program built for trained, BatchNorm-folded weights") if hp_blocks == 17
+                                 else "-p 16 (fp16 MFMA; stem + blocks 0..%d with split hi+lo operands, the rest plain fp16)" % (hp_blocks - 1)
                                  if hp_blocks else "-p 16 --plain-fp16",
                        "batch": BATCH, "frame": "%dx%d" % (WIDTH, HEIGHT), "parallelism": "replica-per-gpu x%d" % world, "batches_in_flight": lanes,
                        "graph_nodes_per_batch": graph_nodes, "detections_per_frame": detections_per_frame},
@@ -1123,7 +1141,7 @@ def main():
             note("worker legs done")
             out["legs"] = legs
         if world == 1 and not args.no_fp32_leg:
-            out["robust_engine"] = robust_engine_leg(weights, host_frames, rank)
+            out["default_program_engine"] = default_program_leg(weights, host_frames, rank)
             out["plain_fp16_engine"] = plain_fp16_leg(weights, host_frames, rank)
             out["fp32_engine"] = fp32_engine_leg(weights, host_frames, rank)
             note("other-precision legs done")
