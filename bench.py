@@ -209,6 +209,10 @@ def roofline_object(table, overhead, single_table, inner):
     single = {r["kernel"]: r for r in single_table}.get(dom["kernel"])
     if single:       # the same kernel with ONE launch per bracket (the cost of the event pair estimated, not amortised)
         roof["avg_launch_us_single_bracket"] = round(single["avg_us"], 3)
+    sk = skeleton_ratio(dom["kernel"], dom["launches"])
+    if sk:           # what the same launches take with their arithmetic removed (committed measurement, profiles/hp_skeleton.json): the
+        roof["arithmetic_free_skeleton"] = sk      # ceiling of THIS decomposition into tiles and chunks -- frac could rise by that ratio at most
+        roof["frac_if_arithmetic_were_free"] = round(roof["frac"] * sk["real_over_skeleton"], 5)
     rp = rocprof_avg_us(dom["kernel"])
     if rp:           # ... and at the duration the committed rocprofv3 kernel trace of this command reports
         roof["avg_launch_us_rocprof"] = rp
@@ -347,6 +351,17 @@ def pmc_child():
         eng.close()
         os.remove(path)
         os.rmdir(d)
+
+
+def skeleton_ratio(kernel, launches):
+    """The committed skeleton measurement of the dominant kernel (profiles/hp_skeleton.json; tools/r4_skel.sh): real / skeleton duration."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "hp_skeleton.json"))).get(kernel)
+        prog = t["robust_program"] if launches == t["robust_program"]["launches"] else t["default_program"]
+        return dict(avg_us_real=prog["avg_us_real"], avg_us_skeleton=prog["avg_us_skeleton"],
+                    real_over_skeleton=round(prog["avg_us_real"] / prog["avg_us_skeleton"], 3), source=t["source"])
+    except (OSError, ValueError, KeyError, TypeError):
+        return None
 
 
 def rocprof_avg_us(kernel):

@@ -55,6 +55,23 @@ __device__ __forceinline__ void wz_hp_split(const float v[8], half8_t& hi, half8
 
 typedef __attribute__((ext_vector_type(2))) float wz_f32x2_t;
 
+// WZ_HP_SKELETON=1 (a measurement build, never shipped: tools/micro/README.md): every global load, LDS access,
+// barrier and store of the kernel stays, the ARITHMETIC goes -- a matrix instruction becomes one add that consumes its operands, a
+// depthwise tap one packed add, the decoder nothing.  What such a launch takes is what this decomposition of the block into tiles
+// and chunks costs in data movement, synchronisation and latency alone: the ceiling the arithmetic could at best hide under.
+#ifndef WZ_HP_SKELETON
+#define WZ_HP_SKELETON 0
+#endif
+#if WZ_HP_SKELETON
+__device__ __forceinline__ float4_t wz_hp_skel_mfma(const half8_t a, const half8_t b, float4_t c) {
+    c[0] += (float)a[0] + (float)b[0];
+    return c;
+}
+#define WZ_HP_MFMA(a, b, c) wz_hp_skel_mfma(a, b, c)
+#else
+#define WZ_HP_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#endif
+
 // The 16-bit FLOAT form of the chunk buffer (QE, the robust program): a value z = relu6(v) / 6 in [0, 1] is kept as
 //     t = C + z * K,   C = 2^-7,  K = (2 - 2^-13) - C      (t in [2^-7, 2): exactly eight binades)
 // rounded to 13 mantissa bits; the code is bits 10 .. 25 of t's fp32 pattern (3 exponent bits + 13 mantissa bits), i.e. a relative
@@ -73,6 +90,11 @@ typedef __attribute__((ext_vector_type(2))) float wz_f32x2_t;
 // eight 16-bit codes -> four pairs of floats.  Linear: v_cvt_f32_u32 with SDWA word select; float form: shift + mask-or per value.
 template <bool QE = false>
 __device__ __forceinline__ void wz_hp_unpack(const wz_u32x4_t t, wz_f32x2_t x[4]) {
+#if WZ_HP_SKELETON
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[r] = (wz_f32x2_t){__uint_as_float(t[r]), 0.0f};
+    return;
+#endif
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         if constexpr (QE && !WZ_HP_ASM_DEC) {
@@ -110,6 +132,12 @@ __device__ __forceinline__ wz_u32x2_t wz_hp_fenc4(const float4_t d) {
 // d[0..3] += x[0..3] * (w0, w1) as four v_pk_fma_f32: the depthwise stage is bound by VALU issue, and a packed FMA
 // is one issue for two of them
 __device__ __forceinline__ void wz_hp_fma8(wz_f32x2_t d[4], const wz_f32x2_t x[4], const float4_t w0, const float4_t w1) {
+#if WZ_HP_SKELETON
+    d[0] = d[0] + x[0] + x[1];
+    d[1] = d[1] + x[2] + x[3];
+    d[2] = d[2] + (wz_f32x2_t){w0[0], w1[0]};
+    return;
+#endif
     d[0] = __builtin_elementwise_fma(x[0], __builtin_shufflevector(w0, w0, 0, 1), d[0]);
     d[1] = __builtin_elementwise_fma(x[1], __builtin_shufflevector(w0, w0, 2, 3), d[1]);
     d[2] = __builtin_elementwise_fma(x[2], __builtin_shufflevector(w1, w1, 0, 1), d[2]);
@@ -419,15 +447,15 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
 #pragma unroll
                 for (int c = 0; c < KCI; ++c)
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) d[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wal[nt][c], fh[c], d[nt], 0, 0, 0);
+                    for (int nt = 0; nt < 2; ++nt) d[nt] = WZ_HP_MFMA(wal[nt][c], fh[c], d[nt]);
 #pragma unroll
                 for (int c = 0; c < KCI; ++c)
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) d[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wah[nt][c], fl[c], d[nt], 0, 0, 0);
+                    for (int nt = 0; nt < 2; ++nt) d[nt] = WZ_HP_MFMA(wah[nt][c], fl[c], d[nt]);
 #pragma unroll
                 for (int c = 0; c < KCI; ++c)
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) d[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wah[nt][c], fh[c], d[nt], 0, 0, 0);
+                    for (int nt = 0; nt < 2; ++nt) d[nt] = WZ_HP_MFMA(wah[nt][c], fh[c], d[nt]);
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) put(d[nt], i, nt, (interior || inimg[i]) && have[nt]);
             }
@@ -443,18 +471,18 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
             for (int i = 0; i < MPW; ++i) {
                 d[i] = bv;                        // the bias is the accumulators' initial value (the MFMA's C operand)
 #pragma unroll
-                for (int c = 0; c < KCI; ++c) d[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wal[nt][c], xh[i][c], d[i], 0, 0, 0);
+                for (int c = 0; c < KCI; ++c) d[i] = WZ_HP_MFMA(wal[nt][c], xh[i][c], d[i]);
             }
             __builtin_amdgcn_sched_barrier(0);   // (left alone, the scheduler re-serialises the chains to save registers)
 #pragma unroll
             for (int i = 0; i < MPW; ++i)
 #pragma unroll
-                for (int c = 0; c < KCI; ++c) d[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wah[nt][c], xl[i][c], d[i], 0, 0, 0);
+                for (int c = 0; c < KCI; ++c) d[i] = WZ_HP_MFMA(wah[nt][c], xl[i][c], d[i]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < MPW; ++i)
 #pragma unroll
-                for (int c = 0; c < KCI; ++c) d[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wah[nt][c], xh[i][c], d[i], 0, 0, 0);
+                for (int c = 0; c < KCI; ++c) d[i] = WZ_HP_MFMA(wah[nt][c], xh[i][c], d[i]);
             __builtin_amdgcn_sched_barrier(0);
             if (interior && have) {
 #pragma unroll
@@ -547,11 +575,11 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
             half8_t bh, bl;
             wz_hp_split(v, bh, bl);
 #pragma unroll
-            for (int nt = 0; nt < NTO; ++nt) acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wpl[nt], bh, acc[j][nt], 0, 0, 0);
+            for (int nt = 0; nt < NTO; ++nt) acc[j][nt] = WZ_HP_MFMA(wpl[nt], bh, acc[j][nt]);
 #pragma unroll
-            for (int nt = 0; nt < NTO; ++nt) acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wph[nt], bl, acc[j][nt], 0, 0, 0);
+            for (int nt = 0; nt < NTO; ++nt) acc[j][nt] = WZ_HP_MFMA(wph[nt], bl, acc[j][nt]);
 #pragma unroll
-            for (int nt = 0; nt < NTO; ++nt) acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wph[nt], bh, acc[j][nt], 0, 0, 0);
+            for (int nt = 0; nt < NTO; ++nt) acc[j][nt] = WZ_HP_MFMA(wph[nt], bh, acc[j][nt]);
         }
         if (WZ_HP_STAMPS) {
             const long long tc3 = __builtin_readcyclecounter();
