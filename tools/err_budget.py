@@ -67,6 +67,22 @@ def quant(x, mode):
         b = y.view(torch.int32).to(torch.int64)
         b = ((b + (1 << 10)) >> 11) << 11
         return b.to(torch.int32).view(torch.float32).to(torch.float64) - c
+    if mode == "t":      # e3m13 float of t = c + z*K (c = 2^-7, top 2 - 2^-13), TRUNCATED to 13 mantissa bits, mean bias taken out by one factor
+        c = 2.0 ** -7
+        K = (2.0 - 2.0 ** -13) - c
+        t = (c + torch.clamp(x, 0.0, 6.0) / 6.0 * K).to(torch.float32)
+        b = t.view(torch.int32).to(torch.int64)
+        b = (b >> 10) << 10
+        tq = b.to(torch.int32).view(torch.float32).to(torch.float64) * (1.0 + 0.72 * 2.0 ** -14)
+        return (tq - c) / K * 6.0
+    if mode == "T":      # the same, rounded to nearest
+        c = 2.0 ** -7
+        K = (2.0 - 2.0 ** -13) - c
+        t = (c + torch.clamp(x, 0.0, 6.0) / 6.0 * K).to(torch.float32)
+        b = t.view(torch.int32).to(torch.int64)
+        b = ((b + 512) >> 10) << 10
+        tq = b.to(torch.int32).view(torch.float32).to(torch.float64)
+        return (tq - c) / K * 6.0
     raise ValueError(mode)
 
 

@@ -93,6 +93,8 @@ for n in range(2, 17):
     PLANS["hp%dx" % n] = hp(n, dw_in="x")
     PLANS["hp%dq" % n] = hp(n, dw_in="q")
     PLANS["hp%de" % n] = hp(n, dw_in="e")
+    for m in "tT":                                # round 4: the 16-bit float form, truncated / rounded (err_budget.py: quant)
+        PLANS["hp%d%s" % (n, m)] = hp(n, dw_in=m)
 
 
 def hp_tail(n, exp=("h", "h", "h"), dep=("h", "h", "h"), pro=("h", "h", "h"), dw_in="x", rest=("h", "h", "h")):
@@ -200,3 +202,49 @@ def hp_mixed_buffer(first_q):
 
 for n in (1, 2, 4, 7):
     PLANS["mixq%d" % n] = hp_mixed_buffer(n)
+
+
+# ---- round 4: which blocks need the float form, and what Conv_1's split weights are worth (profiles/r04_err_budget_float_form.txt)
+PLANS["x_rest_x"] = hp_rest(16, dw_in="x", conv1=X, extras=X, heads=X)
+PLANS["x_conv1_s"] = hp_rest(16, dw_in="x", conv1=S)
+for tag, c1 in (("s", S), ("hss", ("h", "s", "s")), ("shs", ("s", "h", "s"))):
+    PLANS["T_conv1_" + tag] = hp_rest(16, dw_in="T", conv1=c1)
+
+
+def hp_mixed2(spec, conv1=("s", "h", "s")):
+    """spec: list of (last_block, mode) in order, e.g. [(12,'T'),(16,'q')]"""
+    plans_ = [(last, hp_rest(16, dw_in=m, conv1=conv1)) for last, m in spec]
+
+    def plan(spec_, groups):
+        cfgs = [(last, p(spec_, groups)) for last, p in plans_]
+        cfg = {}
+        for lab, names in groups.items():
+            i = _idx(lab)
+            for nm in names:
+                chosen = cfgs[-1][1]
+                if i is not None:
+                    for last, c in cfgs:
+                        if i <= last:
+                            chosen = c
+                            break
+                cfg[nm] = chosen[nm]
+        return cfg
+    return plan
+
+
+PLANS["mx_T12_q16"] = hp_mixed2([(12, "T"), (16, "q")])
+PLANS["mx_T12_u16"] = hp_mixed2([(12, "T"), (16, "u")])
+PLANS["mx_T6_q16"] = hp_mixed2([(6, "T"), (16, "q")])
+PLANS["mx_T3_q16"] = hp_mixed2([(3, "T"), (16, "q")])
+PLANS["mx_q3_T16"] = hp_mixed2([(3, "q"), (16, "T")])
+PLANS["mx_q6_T16"] = hp_mixed2([(6, "q"), (16, "T")])
+PLANS["mx_T12_q16_c1h"] = hp_mixed2([(12, "T"), (16, "q")], conv1=("h", "h", "h"))
+PLANS["mx_T16_c1h"] = hp_mixed2([(16, "T")], conv1=("h", "h", "h"))
+PLANS["mx_T12_u16_c1h"] = hp_mixed2([(12, "T"), (16, "u")], conv1=("h", "h", "h"))
+PLANS["mx_T3_u16"] = hp_mixed2([(3, "T"), (16, "u")])
+PLANS["mx_T6_u16"] = hp_mixed2([(6, "T"), (16, "u")])
+PLANS["mx_T9_u16"] = hp_mixed2([(9, "T"), (16, "u")])
+PLANS["mx_T10_u16"] = hp_mixed2([(10, "T"), (16, "u")])
+for k in (8, 9, 10, 11, 12):
+    PLANS["mx_T%d_u16_c1h" % k] = hp_mixed2([(k, "T"), (16, "u")], conv1=("h", "h", "h"))
+    PLANS["mx_T%d_u16_c1s" % k] = hp_mixed2([(k, "T"), (16, "u")])
