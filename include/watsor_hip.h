@@ -111,7 +111,9 @@ int wz_submit_host_fmt(wz_engine_t* e, int slot, int n, const uint8_t* const* fr
                        const int* fmt, const int* cam);
 uint64_t wz_frame_bytes(int w, int h, int fmt);   /* bytes of one frame; 0 for a format / size the engine does not take */
 /* Page-lock / release a host range that frames are handed over from (the reference's FrameBuffer arenas,
- * watsor/stream/share.py:35-41): copies out of it become DMA transfers at PCIe rate. */
+ * watsor/stream/share.py:35-41): copies out of it become DMA transfers at PCIe rate, and a frame whose height is at least twice the
+ * network's input (the bilinear resize then skips rows) is not copied at all -- the resize kernel reads its tap rows IN PLACE through
+ * the range's device mapping.  Either way a submitted frame must stay unchanged until its batch is collected. */
 int wz_host_register(wz_engine_t* e, void* ptr, uint64_t bytes);
 int wz_host_unregister(wz_engine_t* e, void* ptr);
 int wz_collect(wz_engine_t* e, int slot, wz_detection_t* const* out, uint8_t* const* pass);

@@ -27,10 +27,11 @@ def one(batch, lanes):
     from watsor_amd import engine as eb
     from watsor_amd.runtime import HipEngine
     from watsor_amd.synth import synthetic_frame, synthetic_weights
-    path = "/tmp/wz_sweep/mi355x.bin"
+    default_program = os.environ.get("WZ_SWEEP_DEFAULT_PROGRAM", "0") != "0"    # (the headline's robust program unless asked otherwise)
+    path = "/tmp/wz_sweep/mi355x_%s.bin" % ("default" if default_program else "robust")
     os.makedirs(os.path.dirname(path), exist_ok=True)
     if not os.path.isfile(path):
-        eb.save_engine(eb.build_engine(synthetic_weights(1234)), path)
+        eb.save_engine(eb.build_engine(synthetic_weights(1234), **({} if default_program else bench.HEADLINE_PROGRAM)), path)
     eng = HipEngine(path, 0, batch, 640, 480)
     d = [eng.upload(synthetic_frame(640, 480, 1234 + i % 16)) for i in range(batch)]
     ws, hs = [640] * batch, [480] * batch

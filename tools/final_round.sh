@@ -10,3 +10,8 @@ timeout 400 python bench.py --table $OUT/stage_table_b8.json > $OUT/bench_b8.jso
 timeout 700 tools/profile_bench.sh ${TAG}_lanes4 > $OUT/prof4.log 2>&1
 WZ_LANES=1 timeout 700 tools/profile_bench.sh ${TAG}_lanes1 > $OUT/prof1.log 2>&1
 timeout 300 python tools/batch_sweep.py --out $OUT/batch_sweep.json > $OUT/batch_sweep.txt 2>&1; grep "^batch" $OUT/batch_sweep.txt
+WZ_SWEEP_DEFAULT_PROGRAM=1 timeout 300 python tools/batch_sweep.py --batches 8,16,32 --out $OUT/batch_sweep_default_program.json > $OUT/batch_sweep_default_program.txt 2>&1; grep "^batch" $OUT/batch_sweep_default_program.txt
+timeout 200 python tools/stage_table.py --robust --throughput > $OUT/stage_table_robust.txt 2>&1; tail -2 $OUT/stage_table_robust.txt
+timeout 200 python tools/stage_table.py --throughput > $OUT/stage_table_default.txt 2>&1; tail -2 $OUT/stage_table_default.txt
+timeout 200 python tools/nms_probe.py > $OUT/nms_probe.txt 2>&1; tail -2 $OUT/nms_probe.txt
+timeout 300 python tools/parity_report.py --robust --frames 4 > $OUT/parity_report_robust.txt 2>&1; tail -4 $OUT/parity_report_robust.txt
