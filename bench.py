@@ -1157,6 +1157,20 @@ def main():
             out["legs"] = legs
         if world == 1 and not args.no_fp32_leg:
             out["default_program_engine"] = default_program_leg(weights, host_frames, rank)
+            try:     # the dominant kernel of THAT program under the same rule (13 launches of wz_k_mbconv_hp: the large and the 19x19 maps only)
+                builder.save_engine(builder.build_engine(weights), engine_path)
+                prof = HipEngine(engine_path, local_rank, BATCH, WIDTH, HEIGHT, dev=True)
+                pd = [prof.upload(f) for f in host_frames[:BATCH]]
+                st = prof.profile_device(pd, ws, hs, reps=10, inner=PROFILE_INNER)
+                tb, ov = aggregate_stages(st, prof.ops(), BATCH, WIDTH * HEIGHT * 3, prof.input_size, prof.hp_blocks, PROFILE_INNER)
+                prof.close()
+                r2 = roofline_object(tb, ov, [], PROFILE_INNER)
+                out["default_program_engine"]["roofline"] = {k: r2[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_us",
+                                                                                 "launches_per_step", "algorithmic_bytes_per_launch") if k in r2}
+                if "arithmetic_free_skeleton" in r2:
+                    out["default_program_engine"]["roofline"]["frac_if_arithmetic_were_free"] = r2["frac_if_arithmetic_were_free"]
+            except Exception as e:
+                out["default_program_engine"]["roofline"] = dict(error=repr(e))
             out["plain_fp16_engine"] = plain_fp16_leg(weights, host_frames, rank)
             out["fp32_engine"] = fp32_engine_leg(weights, host_frames, rank)
             note("other-precision legs done")
