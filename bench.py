@@ -616,8 +616,8 @@ def worker_legs(model_dir, device=0, only_8cams=False):
     if only_8cams:
         return legs
     leg("worker_spawned_16cams", n_cams=16, seconds=3.0)
-    # configs[3..4] put 16+ cameras on a GPU: the worker drains up to max_batch payloads per turn, so batch 16 is an operating point an
-    # operator can choose (`hip_options={"max_batch": 16}`) -- more frames/s for a longer enqueue -> latch time; both are reported
+    # configs[3..4] put 16+ cameras on a GPU: the worker drains up to max_batch payloads per turn without waiting, and the factory
+    # sets max_batch 16 for more than 8 cameras (`hip_detector_options`) -- the leg above, with the limit held at 8, is the comparison
     leg("worker_spawned_16cams_max_batch16", n_cams=16, seconds=3.0, max_batch=16)
     leg("worker_spawned_32cams_max_batch16", n_cams=32, seconds=3.0, max_batch=16, producers=4)
     leg("worker_spawned_8cams_per_batch_descriptions", n_cams=8, seconds=2.0, frame_table=False)

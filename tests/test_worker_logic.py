@@ -217,6 +217,11 @@ def test_options_follow_the_frame_buffers():
     assert hip_detector_options(cams, {"hip_options": {"max_width": 4096, "max_batch": 16}}) == \
         {"max_width": 4096, "max_height": 48, "max_batch": 16}
     assert hip_detector_options({}, {}) == {}
+    # more than 8 cameras: batches of up to 16 unless the installation says otherwise
+    many = {"cam%d" % i: cams["cam0"] for i in range(9)}
+    assert hip_detector_options(many, {})["max_batch"] == 16
+    assert hip_detector_options(many, {"hip_options": {"max_batch": 4}})["max_batch"] == 4
+    assert "max_batch" not in hip_detector_options({"cam%d" % i: cams["cam0"] for i in range(8)}, {})
 
 
 def test_plain_plugin_without_batch_or_async_api():

@@ -337,6 +337,11 @@ def hip_detector_options(frame_buffers, kwargs):
     if widths:
         opts.setdefault("max_width", max(widths))
         opts.setdefault("max_height", max(heights))
+    # More than 8 cameras: batches of up to 16.  The worker never WAITS for a batch to fill (it takes what is queued), so the limit
+    # only matters once that many frames are waiting -- and then one batch of 16 is both faster and sooner done than two of 8
+    # (16 cameras, one MI355X: 40.1 k frames/s at 0.24 ms enqueue-to-latch against 34.1 k at 1.31 ms).
+    if len(frame_buffers) > 8:
+        opts.setdefault("max_batch", 16)
     return opts
 
 
@@ -349,7 +354,8 @@ def create_object_detectors(delegate_class, stop_event, log_queue, frame_queue, 
     Optional entries of `kwargs` (all consumed inside the detector processes):
       hip_cameras  {camera name: normalised camera config}  -> the camera's Confidence / Area / Mask filters run on the GPU
       hip_drop     True: rows failing those filters come back as all-zero rows (for `hip_detection_sieve()`)
-      hip_options  dict(max_batch=, max_width=, max_height=) overriding what is derived from the frame buffers;
+      hip_options  dict(max_batch=, max_width=, max_height=) overriding what is derived from the frame buffers (the largest
+                   frame; max_batch 16 for more than 8 cameras, else the plugin's 8);
                    pixel_format= "rgb24" | "nv12" | "yuv420p" (or {camera name: ...}): what the decoders write (hip_gpu.py)
       hip_lanes    batches kept in flight per GPU by the worker (default: the engine's lanes, 4)
       hip_metric_interval  seconds of batches folded into one `inference_time` observation (default 0.005; 0: one per batch)
