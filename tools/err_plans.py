@@ -248,3 +248,7 @@ PLANS["mx_T10_u16"] = hp_mixed2([(10, "T"), (16, "u")])
 for k in (8, 9, 10, 11, 12):
     PLANS["mx_T%d_u16_c1h" % k] = hp_mixed2([(k, "T"), (16, "u")], conv1=("h", "h", "h"))
     PLANS["mx_T%d_u16_c1s" % k] = hp_mixed2([(k, "T"), (16, "u")])
+# the float form only where it is cheap (the large maps of blocks 0 .. 3 pay most for its encoder): linear in front as well
+for k0 in (0, 1, 2, 3):
+    PLANS["mx_u%d_T9_u16" % k0] = hp_mixed2([(k0, "u"), (9, "T"), (16, "u")])
+    PLANS["mx_u%d_T12_u16" % k0] = hp_mixed2([(k0, "u"), (12, "T"), (16, "u")])

@@ -16,7 +16,7 @@ from watsor_amd.synth import synthetic_frame, synthetic_weights
 from watsor_amd.runtime import HipEngine
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 path = "/tmp/wz_probe/mi355x.bin"; os.makedirs("/tmp/wz_probe", exist_ok=True)
-eb.save_engine(eb.build_engine(synthetic_weights(1234)), path)
+eb.save_engine(eb.build_engine(synthetic_weights(1234), robust=os.environ.get("WZ_PROBE_ROBUST", "0") == "1"), path)   # WZ_PROBE_ROBUST=1: all 17 blocks
 e = HipEngine(path, 0, B, 640, 480)
 d = [e.upload(synthetic_frame(640, 480, 1234 + i)) for i in range(B)]
 for it in range(3):

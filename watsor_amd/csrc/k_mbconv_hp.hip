@@ -272,10 +272,13 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
     // SH: fragment f = (i * KCI + c) * 2 + (0: hi, 1: lo) is fetched by wave f % NW and parked at f KiB of the halo area
     constexpr int NFRAG = MPW * KCI * 2;
     unsigned char* const halo_l = wz_hp_smem + REGION + (size_t)a.cmid_pad * (LDSW ? 44 : 8);
+    // (its LDS stores wait for the loads: they come behind the ISSUE of the staging loads and of the first expand weights below -- the
+    //  prologue of these kernels used to take two memory round trips one after the other, `s_waitcnt vmcnt(0)` in front of the halo's
+    //  ds_write and again in front of the staged biases', round 4)
+    constexpr int PERW = SH ? (NFRAG + NW - 1) / NW : 1;
+    half8_t part[PERW];
     if constexpr (SH) {
         static_assert(!STEM && CS, "shared halo: chunk-split kernels only");
-        constexpr int PERW = (NFRAG + NW - 1) / NW;
-        half8_t part[PERW];
 #pragma unroll
         for (int k = 0; k < PERW; ++k) {
             const int f = wave + k * NW;     // wave-uniform
@@ -291,12 +294,16 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
                 if (kok) part[k] = *reinterpret_cast<const half8_t*>(src + (lo ? a.cin0 : 0) + k0);
             }
         }
-#pragma unroll
-        for (int k = 0; k < PERW; ++k) {
-            const int f = wave + k * NW;
-            if (f < NFRAG) *reinterpret_cast<half8_t*>(halo_l + (size_t)f * 1024 + lane * 16) = part[k];
-        }
     }
+    auto park_halo = [&]() {
+        if constexpr (SH) {
+#pragma unroll
+            for (int k = 0; k < PERW; ++k) {
+                const int f = wave + k * NW;
+                if (f < NFRAG) *reinterpret_cast<half8_t*>(halo_l + (size_t)f * 1024 + lane * 16) = part[k];
+            }
+        }
+    };
 
     // a tile whose halo lies inside the frame needs no per-pixel masking of the expanded values (wave-uniform; rows of
     // the last m-tile beyond the halo are never read by the depthwise stage, whatever they hold)
@@ -329,7 +336,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
     };
     constexpr bool WA_AHEAD = !((LEAN || !CS) && OCC >= 4);   // the next pass's expand fragments requested a stage ahead (4 waves per SIMD: at the
                                                      // top of the pass instead -- the other waves cover the wait, the registers are not there)
-    if (WA_AHEAD && ps0 < nk32) load_wa(ps0);
+    if (!SH && WA_AHEAD && ps0 < nk32) load_wa(ps0);
     {   // biases (and, LDSW, depthwise weights) into LDS: every load of a thread in flight before its first store
         constexpr int NT = NW * 64;
         constexpr int WD_IT = LEAN ? 5 : NW >= 8 ? 3 : 8;   // 9 * cmid_pad / 4 float4s over NT threads: at most this many each (checked by the launcher)
@@ -346,6 +353,12 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
         const bool hb = ib < nb4;
         sb = hb ? *reinterpret_cast<const float4_t*>(a.bd + ib * 4) : (float4_t){0.f, 0.f, 0.f, 0.f};
         se = (hb && ib * 4 < a.nmid_pad) ? *reinterpret_cast<const float4_t*>(a.be + ib * 4) : (float4_t){0.f, 0.f, 0.f, 0.f};
+        if constexpr (SH) {   // shared halo: the first expand weights are requested LAST (nothing in front of the barrier waits for them) ...
+            __builtin_amdgcn_sched_barrier(0);
+            if (WA_AHEAD && ps0 < nk32) load_wa(ps0);
+            __builtin_amdgcn_sched_barrier(0);
+            park_halo();      // ... and the halo fragments, requested first, are parked now
+        }
         if constexpr (LDSW) {
 #pragma unroll
             for (int k = 0; k < WD_IT; ++k) {
