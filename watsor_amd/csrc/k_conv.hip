@@ -426,15 +426,21 @@ __global__ __launch_bounds__(256) void wz_k_conv(const WzConvArgs a) {
 // feeding the next one): the 8 waves of a workgroup share ONE 32-pixel x 32-channel tile and each walks an eighth of
 // the K chunks; the eight accumulator sets meet in LDS and are summed in wave order (deterministic).  No partial sums
 // in HBM and no reduce launch behind the convolution -- on this chain a kernel boundary costs as much as the kernel.
-template <int KS>
-__global__ __launch_bounds__(512) void wz_k_conv_ws(const WzConvArgs a) {
-    constexpr int MT = 2, NT = 2, U = 4, WAVES = 8;
+// WM x WN: the workgroup's tile is WM x WN such 32 x 32 tiles and K is cut 8 / (WM WN) ways; U: K chunks per load group (two groups in flight);
+// WGS_PER_CU = 2 holds the kernel to 128 registers (U = 2: 109) so that two workgroups share a CU -- what Conv_1's 500 .. 1 000 tiles need
+// (wz_launch_conv_ws); the extras chain's launches have fewer workgroups than the chip has CUs and keep U = 4.
+template <int KS, int WM = 1, int WN = 1, int U = 4, int WGS_PER_CU = 1>
+__global__ __launch_bounds__(512, WGS_PER_CU) void wz_k_conv_ws(const WzConvArgs a) {
+    constexpr int MT = 2, NT = 2, WAVES = 8, KSPL = WAVES / (WM * WN);
+    static_assert(KSPL * WM * WN == WAVES, "eight waves: sub-tiles x K slices");
     __shared__ float4_t red[WAVES][MT * NT][64];   // 32 KiB
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15, g = lane >> 4;
-    const int m_base = blockIdx.x * (MT * 16);
-    const int nt0 = blockIdx.y * NT;
+    const int sub = wave / KSPL, ks = wave - sub * KSPL;   // which 32 x 32 tile of the workgroup's, which K slice of it
+    const int m_base = ((int)blockIdx.x * WM + sub / WN) * (MT * 16);
+    const int nt0 = ((int)blockIdx.y * WN + sub % WN) * NT;
+    const bool tile_live = m_base < a.M && nt0 * 16 < a.n_pad;   // (wave-uniform; a dead tile still takes the barrier)
 
     const int hw = a.hout * a.wout;
     int iy0[MT], ix0[MT], boff[MT];
@@ -456,9 +462,9 @@ __global__ __launch_bounds__(512) void wz_k_conv_ws(const WzConvArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
-    const int per = (a.kchunks + WAVES - 1) / WAVES;
-    const int q0 = wave * per, q1 = min(q0 + per, a.kchunks);
-    if (q0 < q1) {
+    const int per = (a.kchunks + KSPL - 1) / KSPL;
+    const int q0 = ks * per, q1 = min(q0 + per, a.kchunks);
+    if (tile_live && q0 < q1) {
         const half_t* wlane = a.w + (size_t)lane * 8;
         const int cg8 = g * 8;
         int ql = q0, t = (KS == 1) ? 0 : q0 / a.kc, c = (KS == 1) ? q0 : q0 - t * a.kc;
@@ -479,15 +485,19 @@ __global__ __launch_bounds__(512) void wz_k_conv_ws(const WzConvArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) red[wave][mt * NT + nt][lane] = acc[mt][nt];
     __syncthreads();
-    if (wave < MT * NT) {   // wave w finishes tile w: sum over the eight K slices in wave order, then the epilogue
-        float4_t v = red[0][wave][lane];
+    // K slice ks of a tile finishes its 16 x 16 sub-tiles ks, ks + KSPL, ...: the sum over the slices in slice order, then the epilogue
+    // (eight slices: waves 0 .. 3 one sub-tile each, as before; two slices: two each)
+    if (tile_live) {
+        for (int tl = ks; tl < MT * NT; tl += KSPL) {
+            float4_t v = red[sub * KSPL][tl][lane];
 #pragma unroll
-        for (int z = 1; z < WAVES; ++z) {
-            const float4_t p = red[z][wave][lane];
+            for (int z = 1; z < KSPL; ++z) {
+                const float4_t p = red[sub * KSPL + z][tl][lane];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += p[r];
+                for (int r = 0; r < 4; ++r) v[r] += p[r];
+            }
+            wz_epilogue4(a, m_base + (tl / NT) * 16 + r16, (nt0 + tl % NT) * 16 + g * 4, v);
         }
-        wz_epilogue4(a, m_base + (wave / NT) * 16 + r16, (nt0 + wave % NT) * 16 + g * 4, v);
     }
 }
 
@@ -922,6 +932,16 @@ bool wz_conv_ws_applies(const WzConvArgs& a) {
     return on && a.out_mode == WZ_OUT_ACT && a.M <= 1024 && a.kchunks >= 8 && a.n_pad % 32 == 0;
 }
 void wz_launch_conv_ws(const WzConvArgs& a, hipStream_t s) {
+    // Many pixels x many channels (Conv_1: 800 x 1 280 at batch 8): 1 000 tiles of 32 x 32 at 173 registers are one workgroup per CU and FOUR
+    // rounds of workgroups that each wait out their operands' latency (13.3 us with split weights, K = 640).  32 x 64 tiles, K in four slices,
+    // two chunks per load group (109 registers: two workgroups per CU) are 500 workgroups in ONE round: 6.9 us.  Measured beside it
+    // (profiles/r04_conv1_tiles.txt): 32 x 32 at 109 registers 8.1 us, 64 x 64 (K in halves) 11.9 us, 64 x 64 at 173 registers 12.8 us (260
+    // workgroups on 256 CUs: a second round for four of them).  WZ_CONV_WS64=0: the 32 x 32 tiles everywhere.
+    static const int wide_tiles = wz_env_int("WZ_CONV_WS64", 1);
+    if (wide_tiles && a.ksize == 1 && a.M >= 512 && a.n_pad >= 512 && a.n_pad % 64 == 0 && a.kchunks >= 8) {
+        WZ_LAUNCH((wz_k_conv_ws<1, 1, 2, 2, 2>), dim3((a.M + 31) / 32, a.n_pad / 64), dim3(512), 0, s, a);
+        return;
+    }
     const dim3 grid((a.M + 31) / 32, a.n_pad / 32);
     if (a.ksize == 1)
         WZ_LAUNCH(wz_k_conv_ws<1>, grid, dim3(512), 0, s, a);
