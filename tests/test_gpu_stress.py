@@ -82,3 +82,35 @@ def test_robust_program_holds_the_tolerance_under_channel_spread(tmp_path, synth
         eng.close()
     print("\\nrobust program, channel spread %.1f decades: max |dscore| %.2e over %d rows" % (decades, worst, n))
     assert worst <= bar
+
+
+@pytest.mark.parametrize("batch", [1, 2, 3])
+def test_robust_program_with_channel_groups_over_workgroups(tmp_path, synth_weights, batch):
+    """Few frames in a batch: the 10x10 split blocks deal their chunks out over 2 - 4 WORKGROUPS per tile whose partial sums meet through
+    the workspace (a ticket per tile, the last arriver adds the groups in order: `wz_k_mbconv_hp`'s CG builds; one frame: 3 groups for
+    block 13, 4 for blocks 14 .. 16; two and three frames: 2 - 4).  Same tolerance as any other launch shape, and the same rows every time."""
+    from watsor_amd.runtime import HipEngine
+    from watsor_amd.share import DetectionArray
+    W = spread_channel_scales(synth_weights, 1.0)
+    frames = [synthetic_frame(640, 480, 5200 + i) for i in range(batch)]
+    path = str(tmp_path / "robust" / "mi355x.bin")
+    engine.save_engine(engine.build_engine(W, robust=True), path)
+    oracle = odet.OracleObjectDetector(weights=W)
+    eng = HipEngine(path, 0, 4, 640, 480)
+    try:
+        first = None
+        for rep in range(3):
+            rows = [DetectionArray() for _ in frames]
+            eng.detect_batch(frames, rows)
+            got = [np.frombuffer(r, dtype=ROW_DTYPE).copy() for r in rows]
+            if first is None:
+                first = got
+                for f, g in zip(frames, got):
+                    b, c, s, _, _ = oracle.raw(f)
+                    r = assert_rows_match(g, odet.rows_as_array(f.shape, b, c, s), f.shape, tol=1e-3, what="batch of %d" % batch)
+                    assert len(r["pairs"]) >= 90
+            else:
+                for a, g in zip(first, got):
+                    assert a.tobytes() == g.tobytes()           # fixed summation order: bit for bit
+    finally:
+        eng.close()

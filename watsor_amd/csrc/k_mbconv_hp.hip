@@ -32,6 +32,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int wz_u32x4_t;
 typedef __attribute__((ext_vector_type(2))) unsigned int wz_u32x2_t;
 
 #define HP_CS_WAVES 8
+#define WZ_HP_TICKETS 4096   // per-tile counters a launch may use (wz_engine.hip: WZ_TICKETS per lane)
 #ifndef WZ_HP_STAMPS
 #define WZ_HP_STAMPS 0   // 1: cycle counts of the first workgroup's wave 0 into WzMbArgs::dbg (tools/hp_probe.py)
 #endif
@@ -164,10 +165,16 @@ __device__ __forceinline__ void wz_hp_fma8(wz_f32x2_t d[4], const wz_f32x2_t x[4
 // 144 / 120 of them -- so the halo fragments of ONE m-tile at a time come back from LDS inside the expand stage, and a workgroup
 // finishes NTO of the block's n-tiles: blockIdx.x % nsplit picks which (the expand and depthwise stages are repeated per group:
 // these launches have a third of a chip's worth of workgroups, the repeat costs no time and halves the accumulators).
+// CG (lean builds at two waves per SIMD: the 10x10 maps): the block's chunks are dealt out over WzMbArgs::cgroups WORKGROUPS per tile as well.
+// A workgroup of these blocks streams all of the block's split weights (1.3 MB) through one CU's vector memory path, whatever the batch
+// (profiles/r04_hp_stamps_late_blocks.txt): with G workgroups each streams a G-th.  Their partial outputs meet through the workspace: every
+// workgroup publishes its sums write-through and takes a ticket on the tile's counter; the one that finds the others there adds the groups
+// in group order (deterministic) and finishes the outputs -- the in-launch reduction of the head kernels (k_conv_rs.h), no second launch.
 template <int NW, bool CS, bool STEM, int MPW, int MQW, int KCI, int NTO, int OCC = 2, bool ONEPASS = false, bool SH = false,
-          bool QE = false, bool LEAN = false>
+          bool QE = false, bool LEAN = false, bool CG = false>
 __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a) {
     static_assert(!LEAN || (CS && SH && !ONEPASS && !STEM && MQW == 1), "lean: chunk-split, shared halo, 4 x 4 tiles");
+    static_assert(!CG || (LEAN && OCC == 2), "channel groups over workgroups: the lean builds of the 10x10 maps");
     extern __shared__ __attribute__((aligned(16))) unsigned char wz_hp_smem[];
     const long long t_entry = WZ_HP_STAMPS ? __builtin_readcyclecounter() : 0;
     constexpr bool LDSW = CS || OCC > 2;                 // depthwise weights staged in LDS (else: registers, from L2)
@@ -196,8 +203,11 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
     // ---- the tile of this wave (CS: of this workgroup); wave-uniform, kept in scalar registers
     const int tiles = a.tiles_x * a.tiles_y;
     const int ngrp = LEAN ? a.nsplit : 1;                 // workgroups per tile, each with NTO of the n-tiles
-    const int nt0 = LEAN ? ((int)blockIdx.x % ngrp) * NTO : 0;
-    const int wt = LEAN ? (int)blockIdx.x / ngrp : CS ? (int)blockIdx.x : (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave);
+    const int cgn = CG ? a.cgroups : 1;                   // ... times that many channel groups
+    const int bidx = CG ? (int)blockIdx.x / cgn : (int)blockIdx.x;   // (tile, n-group): the unit that has one ticket counter
+    const int cg = CG ? (int)blockIdx.x - bidx * cgn : 0;
+    const int nt0 = LEAN ? (bidx % ngrp) * NTO : 0;
+    const int wt = LEAN ? bidx / ngrp : CS ? (int)blockIdx.x : (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave);
     const bool live = wt < tiles * a.nb;                  // wave-uniform; dead waves still take the barrier below
     const int wtc = live ? wt : 0;
     const int b = wtc / tiles, t = wtc - b * tiles;
@@ -320,7 +330,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
     const int nk32 = a.cmid_pad >> 5;                     // 32-channel chunks in all
     const int ntiles_e = a.nmid_pad >> 4;
     constexpr int STEP = CS ? NW : 1;
-    const int ps0 = CS ? wave : 0;
+    const int cpg = (nk32 + cgn - 1) / cgn;               // chunks of this workgroup: [c_lo, c_hi)
+    const int c_lo = CG ? cg * cpg : 0, c_hi = CG ? min(nk32, c_lo + cpg) : nk32;
+    const int ps0 = CS ? c_lo + wave : 0;
     half8_t wah[2][KCI], wal[2][KCI];
     auto load_wa = [&](int ps) {
 #pragma unroll
@@ -336,7 +348,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
     };
     constexpr bool WA_AHEAD = !((LEAN || !CS) && OCC >= 4);   // the next pass's expand fragments requested a stage ahead (4 waves per SIMD: at the
                                                      // top of the pass instead -- the other waves cover the wait, the registers are not there)
-    if (!SH && WA_AHEAD && ps0 < nk32) load_wa(ps0);
+    if (!SH && WA_AHEAD && ps0 < c_hi) load_wa(ps0);
     {   // biases (and, LDSW, depthwise weights) into LDS: every load of a thread in flight before its first store
         constexpr int NT = NW * 64;
         constexpr int WD_IT = LEAN ? 5 : NW >= 8 ? 3 : 8;   // 9 * cmid_pad / 4 float4s over NT threads: at most this many each (checked by the launcher)
@@ -355,7 +367,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
         se = (hb && ib * 4 < a.nmid_pad) ? *reinterpret_cast<const float4_t*>(a.be + ib * 4) : (float4_t){0.f, 0.f, 0.f, 0.f};
         if constexpr (SH) {   // shared halo: the first expand weights are requested LAST (nothing in front of the barrier waits for them) ...
             __builtin_amdgcn_sched_barrier(0);
-            if (WA_AHEAD && ps0 < nk32) load_wa(ps0);
+            if (WA_AHEAD && ps0 < c_hi) load_wa(ps0);
             __builtin_amdgcn_sched_barrier(0);
             park_halo();      // ... and the halo fragments, requested first, are parked now
         }
@@ -381,7 +393,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
         t_loop = __builtin_readcyclecounter();
     }
 
-    for (int ps = ps0; ps < nk32; ps += STEP) {
+    for (int ps = ps0; ps < c_hi; ps += STEP) {
         const long long tc0 = WZ_HP_STAMPS ? __builtin_readcyclecounter() : 0;
         const int ce0 = ps * 32;
         const int coff = ce0 + g * 8;
@@ -508,7 +520,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
         }
         if constexpr (WP_LATE) load_wp();
         if constexpr (!ONEPASS && WA_AHEAD)
-            if (ps + STEP < nk32) load_wa(ps + STEP);   // next pass's expand fragments, in flight under the depthwise stage
+            if (ps + STEP < c_hi) load_wa(ps + STEP);   // next pass's expand fragments, in flight under the depthwise stage
         // the wave's own LDS writes are ordered before its reads by the LDS queue; keep the compiler from moving the reads up
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -723,20 +735,73 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
             for (int nt = 0; nt < NTO; ++nt)
                 *reinterpret_cast<float4_t*>(red + ((size_t)((wave * MQW + j) * NTO + nt) * 64 + lane) * 4) = acc[j][nt];
         __syncthreads();
+        float4_t vs[PER];
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int pr = wave + k * NW;
+            vs[k] = (float4_t){0.f, 0.f, 0.f, 0.f};
             if (pr >= MQW * NTO) break;
             const int j = pr / NTO, nt = pr - j * NTO;
-            float4_t v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
                 const float4_t pz = *reinterpret_cast<const float4_t*>(red + ((size_t)((w * MQW + j) * NTO + nt) * 64 + lane) * 4);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += pz[r];
+                for (int r = 0; r < 4; ++r) vs[k][r] += pz[r];
             }
+        }
+        if constexpr (CG) {
+            if (cgn > 1) {
+                // this group's sums of the tile -> its slab of the workspace ([unit][group][MQW * NTO fragments of 1 KiB], lane l's four values
+                // at l * 16: whole lines), write-through; then the ticket
+                constexpr int FR = MQW * NTO;
+                float* const slab0 = a.ws + (size_t)bidx * cgn * FR * 256;
+#pragma unroll
+                for (int k = 0; k < PER; ++k) {
+                    const int pr = wave + k * NW;
+                    if (pr >= FR) break;
+                    float* const dst = slab0 + ((size_t)cg * FR + pr) * 256 + lane * 4;
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(vs[k]) : "memory");
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();                       // every wave's stores have landed (and nobody reads `red` any more)
+                int* const flag = reinterpret_cast<int*>(bd_l);   // (the staged biases are dead behind the chunk loop)
+                if (threadIdx.x == 0) {
+                    int32_t* const tk = a.tickets + bidx;
+                    const int tt = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (tt == cgn - 1) {
+                        __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                        // this CU reads the slabs fresh
+                    }
+                    *flag = tt;
+                }
+                __syncthreads();
+                if (*flag != cgn - 1) return;
+                // the last arriver: the groups' sums in group order, all of a fragment's loads requested before the first add
+#pragma unroll
+                for (int k = 0; k < PER; ++k) {
+                    const int pr = wave + k * NW;
+                    if (pr >= FR) break;
+                    float4_t pz[4];
+#pragma unroll
+                    for (int z = 0; z < 4; ++z)
+                        pz[z] = z < cgn ? *reinterpret_cast<const float4_t*>(slab0 + ((size_t)z * FR + pr) * 256 + lane * 4) : (float4_t){0.f, 0.f, 0.f, 0.f};
+                    float4_t v = pz[0];
+#pragma unroll
+                    for (int z = 1; z < 4; ++z)
+                        if (z < cgn) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += pz[z][r];
+                        }
+                    vs[k] = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int pr = wave + k * NW;
+            if (pr >= MQW * NTO) break;
             if (sop[k] < 0) continue;
-            finish(v, sd[k], sop[k], sn4[k]);
+            finish(vs[k], sd[k], sop[k], sn4[k]);
         }
     }
     if (WZ_HP_STAMPS && a.dbg && blockIdx.x == (WZ_HP_STAMP_LAST ? gridDim.x - 1 : 0) && threadIdx.x == 0) {
@@ -747,7 +812,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
         a.dbg[2] = (unsigned long long)(t_first - t_loop);     // first chunk
         a.dbg[3] = (unsigned long long)(t_chunks - t_loop);    // all chunks of this wave
         a.dbg[4] = (unsigned long long)(t_end - t_chunks);     // (reduce through LDS,) epilogue, stores landed
-        a.dbg[5] = (unsigned long long)((nk32 - ps0 + STEP - 1) / STEP);
+        a.dbg[5] = (unsigned long long)((c_hi - ps0 + STEP - 1) / STEP);
         a.dbg[6] = (unsigned long long)cy_expand;   // per-phase sums over this wave's chunks (each stamp is an lgkmcnt(0): phases do not overlap here)
         a.dbg[7] = (unsigned long long)cy_dw;
         a.dbg[9] = (unsigned long long)cy_proj;
@@ -761,7 +826,7 @@ static int wz_hp_env(const char* name, int dflt) {
 }
 
 template <int NW, bool CS, bool STEM, int MPW, int MQW, int KCI, int NTO, int OCC = 2, bool ONEPASS = false, bool SH = false,
-          bool QE = false, bool LEAN = false>
+          bool QE = false, bool LEAN = false, bool CG = false>
 static int wz_hp_launch(WzMbArgs a, int n, hipStream_t s, bool prepare) {
     if (ONEPASS && (a.cmid_pad >> 5) > NW) return -1;
     if (QE != (a.qenc != 0)) return -1;
@@ -778,13 +843,14 @@ static int wz_hp_launch(WzMbArgs a, int n, hipStream_t s, bool prepare) {
     const size_t region = (size_t)(NW * EB > RED ? NW * EB : RED);
     const size_t lds = region + (size_t)a.cmid_pad * ((CS || OCC > 2) ? 8 + 36 : 8) + (SH ? (size_t)MPW * KCI * 2 * 1024 : 0);
     if ((a.cmid_pad >> 2) > NW * 64 || 9 * (a.cmid_pad >> 2) > (LEAN ? 5 : NW >= 8 ? 3 : 8) * NW * 64) return -1;   // the staging code's fixed trip counts
-    auto k = wz_k_mbconv_hp<NW, CS, STEM, MPW, MQW, KCI, NTO, OCC, ONEPASS, SH, QE, LEAN>;
+    auto k = wz_k_mbconv_hp<NW, CS, STEM, MPW, MQW, KCI, NTO, OCC, ONEPASS, SH, QE, LEAN, CG>;
     if (prepare) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return lds <= 160 * 1024 ? 0 : -1;
     }
     const int tiles = a.tiles_x * a.tiles_y * n;
-    WZ_LAUNCH(k, dim3(CS ? tiles * a.nsplit : (tiles + 3) / 4), dim3(NW * 64), lds, s, a);
+    if (!CG) a.cgroups = 1;
+    WZ_LAUNCH(k, dim3(CS ? tiles * a.nsplit * a.cgroups : (tiles + 3) / 4), dim3(NW * 64), lds, s, a);
     return 1;
 }
 
@@ -865,8 +931,39 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
         // spread), and the linear one is the cheapest to decode (robust program, round 4: 17.2 / 20.9 / 20.5 / 21.3 us in the float form).
         // Five n-tiles per workgroup and twice the workgroups was measured in round 3: blocks 14 / 15 18.9 -> 17.2 us alone, block 16
         // 19.1 -> 34.3 us (288 workgroups that each take a whole CU: two rounds), 46.3 k -> 41.9 k frames/s (profiles/r03_robust_program.txt).
-        if (a.stride == 2) return (a.kc0 == 3 && nto == 10) ? wz_hp_launch<8, true, false, 6, 1, 3, 10, 2, false, true, false, true>(a, n, s, prepare) : -1;
-        if (a.kc0 == 5 && (nto == 10 || nto == 20)) return wz_hp_launch<8, true, false, 3, 1, 5, 10, 2, false, true, false, true>(a, n, s, prepare);
+        //
+        // Channel groups over workgroups (round 4, wz_k_mbconv_hp's CG): G workgroups per tile share the block's chunks, G the smallest number
+        // that gets a wave's chunk walk as short as a launch of at most 128 of these whole-CU workgroups allows (256 under the latency
+        // schedule).  Alone such a block is much faster (17 -> 9.5 us with 4 groups, 14 us with 2) -- but its workgroups own their CUs, and with
+        // four lanes in flight at batch 8 twice the workgroups cost more than the shorter launches bring (46.9 k -> 44.7 k frames/s with groups
+        // everywhere), so the groups are for the launches that leave the chip empty: ONE camera's frame at a time, the reference's normal
+        // load (4 groups: 10 986 -> 11 830 frames/s, p50 0.328 -> 0.300 ms), 2 frames (20.6 -> 21.6 k), 4 frames (same frames/s, p50 -3 %);
+        // batch 8 runs as before.  profiles/r04_channel_groups.txt.  WZ_HP_CGROUPS=1: never; 2 .. 4: at most that many.
+        static const int cg_env = wz_hp_env("WZ_HP_CGROUPS", 0);
+        static const int cg_cap = wz_hp_env("WZ_HP_CG_CAP", wz_latency_schedule() ? 256 : 128);   // workgroups such a launch may have
+        const int units = ((a.hout + 3) / 4) * ((a.wout + 3) / 4) * n * (nto / 10);   // (tile, n-group) pairs = ticket counters
+        int G = 1;
+        if (!prepare && a.ws && a.tickets && cg_env != 1 && units <= WZ_HP_TICKETS &&
+            (size_t)units * 4 * 10 * 1024 <= (size_t)(a.ws_bytes >> 1)) {
+            int best = (nk32 + 7) / 8;                                       // chunks a wave walks with one group
+            for (int g = 2; g <= 4; ++g) {
+                if (units * g > cg_cap || (cg_env > 1 && g > cg_env)) break;
+                const int walk = ((nk32 + g - 1) / g + 7) / 8;
+                if (walk < best) { best = walk; G = g; }
+            }
+        }
+        a.cgroups = G;
+        if (a.stride == 2) {
+            if (!(a.kc0 == 3 && nto == 10)) return -1;
+            if (prepare) (void)wz_hp_launch<8, true, false, 6, 1, 3, 10, 2, false, true, false, true, true>(a, n, s, true);
+            return G > 1 ? wz_hp_launch<8, true, false, 6, 1, 3, 10, 2, false, true, false, true, true>(a, n, s, false)
+                         : wz_hp_launch<8, true, false, 6, 1, 3, 10, 2, false, true, false, true>(a, n, s, prepare);
+        }
+        if (a.kc0 == 5 && (nto == 10 || nto == 20)) {
+            if (prepare) (void)wz_hp_launch<8, true, false, 3, 1, 5, 10, 2, false, true, false, true, true>(a, n, s, true);
+            return G > 1 ? wz_hp_launch<8, true, false, 3, 1, 5, 10, 2, false, true, false, true, true>(a, n, s, false)
+                         : wz_hp_launch<8, true, false, 3, 1, 5, 10, 2, false, true, false, true>(a, n, s, prepare);
+        }
         return -1;
     }
     if (a.wout > 19 && a.kc0 == 1 && nto == 2) {

@@ -122,6 +122,8 @@ struct WzMbArgs {
     half_t* out2;          // chunk-split kernel: where the expanded tensor is stored as well (hin x win x cmid fp16), or nullptr
     int32_t has_out2;      // the op has such a second output (out2 itself is null while a launcher is only asked to prepare)
     int32_t qenc;          // split-operand kernel: the chunk buffer holds the 16-bit float form of v / 6 (the robust program; wd carries 6 / K, bd the offset)
+    int32_t cgroups;       // split-operand kernel, 10x10 maps: workgroups per tile that share the block's chunks (filled in by the launcher; 1 = no sharing)
+    int32_t* tickets;      // ... and their per-tile counters (the lane's block of them, zero between launches), or nullptr
 };
 
 // Per-camera filter state resident in HBM (see wz_set_camera_filter).

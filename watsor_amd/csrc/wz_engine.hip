@@ -307,6 +307,7 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
             a.M = n * op.hout * op.wout;
             a.ws = e->use_splitk ? L.d_ws : nullptr;
             a.ws_bytes = ws_top;
+            a.tickets = e->use_splitk ? L.d_tickets : nullptr;   // (channel groups over workgroups of the 10x10 split blocks: k_mbconv_hp.hip)
             a.dbg = e->d_mbdbg ? e->d_mbdbg + (size_t)i * 16 : nullptr;
             int groups = a.hp ? wz_launch_mbconv_hp(a, n, s, false)   // split-operand blocks (the `-p 16` program's first 13)
                               : wz_launch_mbconv_wave(a, n, s, false);   // large maps: one wavefront per pixel tile
