@@ -427,9 +427,8 @@ __global__ __launch_bounds__(256) void wz_k_conv(const WzConvArgs a) {
 // the K chunks; the eight accumulator sets meet in LDS and are summed in wave order (deterministic).  No partial sums
 // in HBM and no reduce launch behind the convolution -- on this chain a kernel boundary costs as much as the kernel.
 // WM x WN: the workgroup's tile is WM x WN such 32 x 32 tiles and K is cut 8 / (WM WN) ways; U: K chunks per load group (two groups in flight);
-// WGS_PER_CU = 2 holds the kernel to 128 registers (U = 2: 109) so that two workgroups share a CU -- what Conv_1's 500 .. 1 000 tiles need
-// (wz_launch_conv_ws); the extras chain's launches have fewer workgroups than the chip has CUs and keep U = 4.
-template <int KS, int WM = 1, int WN = 1, int U = 4, int WGS_PER_CU = 1>
+// WGS_PER_CU = 2 holds the kernel to 128 registers (U = 2: 109) so that two workgroups share a CU (U = 4: 173 registers, a CU per workgroup).
+template <int KS, int WM = 1, int WN = 1, int U = 2, int WGS_PER_CU = 2>
 __global__ __launch_bounds__(512, WGS_PER_CU) void wz_k_conv_ws(const WzConvArgs a) {
     constexpr int MT = 2, NT = 2, WAVES = 8, KSPL = WAVES / (WM * WN);
     static_assert(KSPL * WM * WN == WAVES, "eight waves: sub-tiles x K slices");
@@ -939,10 +938,13 @@ void wz_launch_conv_ws(const WzConvArgs& a, hipStream_t s) {
     // workgroups on 256 CUs: a second round for four of them).  WZ_CONV_WS64=0: the 32 x 32 tiles everywhere.
     static const int wide_tiles = wz_env_int("WZ_CONV_WS64", 1);
     if (wide_tiles && a.ksize == 1 && a.M >= 512 && a.n_pad >= 512 && a.n_pad % 64 == 0 && a.kchunks >= 8) {
-        WZ_LAUNCH((wz_k_conv_ws<1, 1, 2, 2, 2>), dim3((a.M + 31) / 32, a.n_pad / 64), dim3(512), 0, s, a);
+        WZ_LAUNCH((wz_k_conv_ws<1, 1, 2>), dim3((a.M + 31) / 32, a.n_pad / 64), dim3(512), 0, s, a);
         return;
     }
     const dim3 grid((a.M + 31) / 32, a.n_pad / 32);
+    // (two K chunks per load group, 109 registers, two workgroups per CU for every launch of this kernel since late round 4: with U = 4 and 173
+    //  registers a workgroup owned its CU -- the extras chain's launches 4.5 / 6.0 -> 4.0 / 5.1 us and, with four lanes in flight, 46.9 -> 47.4 k
+    //  frames/s: what a launch keeps other lanes' workgroups from using counts, profiles/r04_conv1_tiles.txt)
     if (a.ksize == 1)
         WZ_LAUNCH(wz_k_conv_ws<1>, grid, dim3(512), 0, s, a);
     else
