@@ -538,13 +538,30 @@ __global__ __launch_bounds__(256) void wz_k_splitk_reduce_group(const WzReduceGr
     const WzConvArgs& a = g.a[e];
     const float* __restrict__ ws = g.ws[e];
     const int tid = ((int)blockIdx.x - g.first[e]) * 256 + threadIdx.x;
-    const int n4s = a.n_pad >> 2;
-    if (tid >= a.M * n4s) return;
-    const int m = tid / n4s, n4 = (tid - m * n4s) * 4;
+    int m, n4;
+    size_t off, zstride;
+    if (a.frag_ws) {   // partials in fragment order (WzConvArgs::frag_ws): a wavefront reads one 1 KiB fragment per slice
+        const int mtt = (a.M + 15) >> 4, ntt = a.n_pad >> 4;
+        const int frag = tid >> 6, lane = tid & 63;
+        if (frag >= mtt * ntt) return;
+        const int fm = frag / ntt;
+        m = fm * 16 + (lane & 15);
+        n4 = (frag - fm * ntt) * 16 + (lane >> 4) * 4;
+        if (m >= a.M) return;
+        off = (size_t)frag * 256 + lane * 4;
+        zstride = (size_t)mtt * ntt * 256;
+    } else {
+        const int n4s = a.n_pad >> 2;
+        if (tid >= a.M * n4s) return;
+        m = tid / n4s;
+        n4 = (tid - m * n4s) * 4;
+        off = (size_t)m * a.n_pad + n4;
+        zstride = (size_t)a.M * a.n_pad;
+    }
     if (n4 >= a.cout) return;   // padding columns: nothing is stored for them (and the wide tile kernel does not write their partials)
     float4_t v = {0.f, 0.f, 0.f, 0.f};
     for (int z = 0; z < a.splitk; ++z) {
-        const float4_t p = *reinterpret_cast<const float4_t*>(ws + ((size_t)z * a.M + m) * a.n_pad + n4);
+        const float4_t p = *reinterpret_cast<const float4_t*>(ws + (size_t)z * zstride + off);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += p[r];
     }
@@ -1010,7 +1027,8 @@ void wz_reduce_group_add(WzReduceGroup& g, const WzConvArgs& a, const float* ws)
     const int i = g.n++;
     g.a[i] = a;
     g.ws[i] = ws;
-    g.first[i + 1] = g.first[i] + (a.M * (a.n_pad >> 2) + 255) / 256;
+    const int threads = a.frag_ws ? ((a.M + 15) >> 4) * (a.n_pad >> 4) * 64 : a.M * (a.n_pad >> 2);
+    g.first[i + 1] = g.first[i] + (threads + 255) / 256;
 }
 void wz_launch_splitk_reduce_group(const WzReduceGroup& g, hipStream_t s) {
     WZ_LAUNCH(wz_k_splitk_reduce_group, dim3(g.first[g.n]), dim3(256), 0, s, g);

@@ -325,6 +325,21 @@ __device__ __forceinline__ void wz_conv_wide_body(const WzConvArgs& a, unsigned 
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     float* const ws = reinterpret_cast<float*>(a.out);
+    if (a.frag_ws) {
+        // fragment order: an accumulator tile is 1 KiB in one piece (lane l's four values at l * 16) -- whole lines per store instruction, where
+        // [slice][pixel][column] order makes sixteen 64-byte pieces of it, one per pixel row (the epilogue of a workgroup was 9.9 k cycles
+        // of a 65 k-cycle launch: profiles/r02zf_wide_heads_phase_cycles.txt).  The grouped reduce reads the fragments back the same way.
+        const int mtt = (a.M + 15) >> 4, ntt = a.n_pad >> 4;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            if (nt >= cnt) break;   // wave-uniform
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt) {
+                const int mtg = (m_base >> 4) + mt;
+                if (mtg < mtt) *reinterpret_cast<float4_t*>(ws + (((size_t)bz * mtt + mtg) * ntt + (nt_w + nt)) * 256 + lane * 4) = acc[mt][nt];
+            }
+        }
+    } else {
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         if (nt >= cnt) break;   // wave-uniform
@@ -334,6 +349,7 @@ __device__ __forceinline__ void wz_conv_wide_body(const WzConvArgs& a, unsigned 
             const int m = m_base + mt * 16 + r16;
             if (m < a.M) *reinterpret_cast<float4_t*>(ws + ((size_t)bz * a.M + m) * a.n_pad + n4) = acc[mt][nt];
         }
+    }
     }
     if (WZ_WIDE_STAMPS) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -66,6 +66,7 @@ struct WzConvArgs {
     int32_t nt_base;            // tile kernel: first 16-channel tile this launch entry serves (a head split along N, see wz_conv_rs_group_add)
     int32_t nt_live, nt_group;  // wide tile kernel (k_conv_wide.hip): 16-channel tiles that hold real columns / tiles per workgroup
     int32_t inline_reduce;
+    int32_t frag_ws;            // the K slices' partial sums lie in FRAGMENT order: [z][M / 16][n_pad / 16][64 lanes][4] (wide tile kernel -> grouped reduce)
     int32_t fin_flags;          // bit 0: decode the boxes, bit 1: mark the NMS candidates (see WzHeadFinish)
     int32_t* tickets;           // one counter per output tile of this convolution, zero between launches
     const struct WzHeadFinish* fin;   // device-resident, per lane

@@ -72,6 +72,7 @@ struct wz_engine {
     const WzOpDesc* ops = nullptr;
     int max_batch = 0, max_w = 0, max_h = 0;
     bool no_reuse = false, use_graph = true, use_splitk = true;
+    bool wide_frag = true;     // the wide head kernel's partial sums in fragment order (WZ_WIDE_FRAG=0: [slice][pixel][column])
     bool list_cands = true;    // WZ_LIST_CANDS=0: the self-scanning NMS kernel always scans
     bool post_self = true;     // WZ_POST_SELF=0: histogram + compaction kernels in front of the NMS kernel
     bool fuse_decode = true;   // WZ_FUSE_DECODE=0: keep wz_k_decode as its own launch
@@ -449,14 +450,16 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
             if (e->use_splitk)
                 sk = wz_conv_use_lds(a) ? wz_choose_splitk_lds(a.M, a.n_pad, a.kchunks) : wz_choose_splitk(a.M, a.n_pad, a.kchunks);
             bool to_wide = wide_T > 0 && wide.n < WZ_CONV_GROUP_MAX && wz_conv_wide_applies(a) && a.M >= e->wide_min_m;
+            const size_t m16 = ((size_t)a.M + 15) & ~(size_t)15;   // (the wide kernel's partials are whole 16-pixel fragments)
             if (to_wide) {   // its partial sums always go through the grouped reduce, also with a single K slice
                 const int wsk = ((a.kchunks >> 1) + wide_T - 1) / wide_T;
-                if (heads.n < WZ_REDUCE_GROUP_MAX && ((((size_t)wsk * a.M * a.n_pad * 4) + 255) & ~(size_t)255) + (e->ws_bytes >> 1) <= ws_top)
+                if (heads.n < WZ_REDUCE_GROUP_MAX && ((((size_t)wsk * m16 * a.n_pad * 4) + 255) & ~(size_t)255) + (e->ws_bytes >> 1) <= ws_top)
                     sk = wsk;
                 else
                     to_wide = false;
             }
-            const size_t slab = (((size_t)sk * a.M * a.n_pad * 4) + 255) & ~(size_t)255;
+            a.frag_ws = (to_wide && e->wide_frag) ? 1 : 0;
+            const size_t slab = (((size_t)sk * (to_wide ? m16 : (size_t)a.M) * a.n_pad * 4) + 255) & ~(size_t)255;
             if ((sk > 1 || to_wide) && e->defer_heads && op.out_mode != WZ_OUT_ACT && heads.n < WZ_REDUCE_GROUP_MAX &&
                 slab + (e->ws_bytes >> 1) <= ws_top) {   // keep at least half of the workspace for the other ops
                 ws_top -= slab;
@@ -481,6 +484,7 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
                 if (makes_boxes) ++box_ops_grouped;
                 continue;
             }
+            a.frag_ws = 0;   // (only the wide kernel and the grouped reduce behind it know that order)
             if ((sk > 1 || a.M < 128) && wz_conv_ws_applies(a)) {   // the K split happens inside the workgroups: nothing to reduce
                 // (on the 2x2 and 1x1 maps also where one wave per tile would walk all of K alone)
                 a.splitk = 1;
@@ -812,6 +816,7 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     e->no_reuse = (env = wz_dev_getenv("WZ_NO_BUFFER_REUSE")) && atoi(env) != 0;
     e->use_graph = !((env = getenv("WZ_GRAPH")) && atoi(env) == 0);
     e->use_splitk = !((env = wz_dev_getenv("WZ_SPLITK")) && atoi(env) == 0);
+    e->wide_frag = !((env = wz_dev_getenv("WZ_WIDE_FRAG")) && atoi(env) == 0);
     e->defer_heads = !((env = wz_dev_getenv("WZ_DEFER_HEADS")) && atoi(env) == 0);
     e->fuse_decode = !((env = wz_dev_getenv("WZ_FUSE_DECODE")) && atoi(env) == 0);
     e->post_self = !((env = wz_dev_getenv("WZ_POST_SELF")) && atoi(env) == 0);
