@@ -18,7 +18,8 @@
 // a wave's fragments are needed by no other wave), activations global -> VGPR -> LDS in full 128-byte lines through a
 // buffer descriptor (out-of-frame taps read zeros), same XOR-swizzled LDS image (conflict-free fragment reads), same
 // K order (channel pair outermost, tap innermost), same XCD-aware tile order.
-// Output: fp32 partial sums [K slice][M][n_pad] for wz_k_splitk_reduce_group -- always, also with one K slice: this
+// Output: fp32 partial sums for wz_k_splitk_reduce_group, in fragment order [K slice][M / 16][n_pad / 16][64 lanes][4] (WzConvArgs::frag_ws;
+// [K slice][M][n_pad] without it) -- always, also with one K slice: this
 // kernel only serves the heads, whose epilogue (bias, scatter, box decode, candidate marking) lives in that launch.
 #include "wz_common.h"
 
