@@ -32,7 +32,6 @@ typedef __attribute__((ext_vector_type(4))) unsigned int wz_u32x4_t;
 typedef __attribute__((ext_vector_type(2))) unsigned int wz_u32x2_t;
 
 #define HP_CS_WAVES 8
-#define WZ_HP_TICKETS 4096   // per-tile counters a launch may use (wz_engine.hip: WZ_TICKETS per lane)
 #ifndef WZ_HP_STAMPS
 #define WZ_HP_STAMPS 0   // 1: cycle counts of the first workgroup's wave 0 into WzMbArgs::dbg (tools/hp_probe.py)
 #endif

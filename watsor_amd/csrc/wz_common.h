@@ -127,6 +127,8 @@ struct WzMbArgs {
     int32_t* tickets;      // ... and their per-tile counters (the lane's block of them, zero between launches), or nullptr
 };
 
+#define WZ_HP_TICKETS 4096   // per-tile counters a channel-group launch of the split-operand kernel may use (of the lane's WZ_TICKETS, wz_engine.hip)
+
 // Per-camera filter state resident in HBM (see wz_set_camera_filter).
 struct WzCamFilter {
     int32_t enabled, width, height, n_zones;   // enabled: bit 0 = filters on, bit 1 = drop mode (failing rows zeroed)

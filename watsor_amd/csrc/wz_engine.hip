@@ -47,6 +47,7 @@ int wz_set_error(int code, const char* fmt, ...) {
     } while (0)
 
 #define WZ_TICKETS 8192   // tile counters per lane: first half the tile-kernel heads, second half the small ones
+static_assert(WZ_HP_TICKETS <= WZ_TICKETS, "the split-operand blocks' channel groups count on the lane's counters");
 
 struct StageTimer {
     std::vector<hipEvent_t> ev;
