@@ -246,9 +246,39 @@ __global__ __launch_bounds__(WZ_PRE_ROWS_THREADS) void wz_k_preprocess_rows(cons
             }
         }
     }
+    // All runs as ONE list of 16-byte chunks dealt out over the threads, a thread's loads (up to four per trip) requested before its first
+    // store: a workgroup waits out one PCIe round trip, not one per run (run by run a 1080p NV12 row was four of them in a row).
+    {
+        // (a plain vector type for the chunks in flight: an array of HIP's uint4 structs is kept in scratch memory)
+        typedef unsigned int wz_u32x4 __attribute__((ext_vector_type(4)));
+        auto gran = [](const WzRowRun& r) { return reinterpret_cast<const wz_u32x4*>(reinterpret_cast<uintptr_t>(r.src) & ~(uintptr_t)15); };
+        auto count = [](const WzRowRun& r) { return r.bytes ? (int)((reinterpret_cast<uintptr_t>(r.src) & 15) + r.bytes + 15) >> 4 : 0; };
+        const int f1 = count(run[0]), f2 = f1 + count(run[1]), f3 = f2 + count(run[2]), f4 = f3 + count(run[3]), f5 = f4 + count(run[4]);
+        const int total = f5 + count(run[5]);
+        for (int c0 = 0; c0 < total; c0 += 4 * WZ_PRE_ROWS_THREADS) {
+            wz_u32x4 v[4];
+            int where[4];
 #pragma unroll
-    for (int r = 0; r < 6; ++r)
-        if (run[r].bytes) wz_stage_run(run[r], wz_pre_lds, tid, WZ_PRE_ROWS_THREADS);
+            for (int k = 0; k < 4; ++k) {
+                const int c = c0 + k * WZ_PRE_ROWS_THREADS + tid;
+                where[k] = -1;
+                if (c < total) {
+                    const wz_u32x4* gp = gran(run[0]);
+                    int off = c, l = run[0].lds;
+                    if (c >= f1) { gp = gran(run[1]); off = c - f1; l = run[1].lds; }
+                    if (c >= f2) { gp = gran(run[2]); off = c - f2; l = run[2].lds; }
+                    if (c >= f3) { gp = gran(run[3]); off = c - f3; l = run[3].lds; }
+                    if (c >= f4) { gp = gran(run[4]); off = c - f4; l = run[4].lds; }
+                    if (c >= f5) { gp = gran(run[5]); off = c - f5; l = run[5].lds; }
+                    v[k] = gp[off];
+                    where[k] = l + off * 16;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (where[k] >= 0) *reinterpret_cast<wz_u32x4*>(wz_pre_lds + where[k]) = v[k];
+        }
+    }
     __syncthreads();
 
     for (int ox = tid; ox < size; ox += WZ_PRE_ROWS_THREADS) {
