@@ -175,6 +175,7 @@ void wz_launch_preprocess(const WzFrameDesc* d_frames, int n, int size, half_t* 
                           WzFrameDesc* keep = nullptr, bool half_pixel = false, const WzFrameDesc* by_value = nullptr, int rows_lds = 0);
 // rows_lds > 0: the row-staged form of the kernel (one workgroup per output row, `rows_lds` bytes of LDS = wz_preprocess_rows_lds(widest frame))
 size_t wz_preprocess_rows_lds(int max_w);
+int wz_preprocess_flags(bool half_pixel, int rows_lds);   // the resize kernels' last argument (k_preprocess.hip)
 int wz_preprocess_rows_threads();
 const void* wz_preprocess_func(bool hp, bool rows = false);   // the kernel's host-side address (to find its node in a captured graph)
 void wz_launch_stem(const half_t* in, const float* w, const float* bias, half_t* out, int n, int hin, int win,

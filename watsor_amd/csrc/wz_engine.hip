@@ -652,7 +652,7 @@ static int run_batch(wz_engine* e, int slot, int n) {
             L.pre_size = (int)e->hdr.input_size;
             L.pre_out = L.tptr[input_tensor_index(e)];
             L.pre_keep = L.d_desc;
-            L.pre_half_pixel = e->hdr.resize_mode == 1 ? 1 : 0;
+            L.pre_half_pixel = wz_preprocess_flags(e->hdr.resize_mode == 1, L.rows ? e->pre_rows_lds : 0);
             L.pre_kp[0] = &L.pre_frames; L.pre_kp[1] = &L.pack; L.pre_kp[2] = &L.pre_size;
             L.pre_kp[3] = &L.pre_out; L.pre_kp[4] = &L.pre_keep; L.pre_kp[5] = &L.pre_half_pixel;
             hipKernelNodeParams kp;
@@ -830,7 +830,7 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     e->pre_rows = (env = wz_dev_getenv("WZ_PRE_ROWS")) ? atoi(env) != 0 : e->pre_rows;
     e->host_read = (env = wz_dev_getenv("WZ_HOST_READ")) ? atoi(env) : e->host_read;
     e->pre_rows_lds = (int)wz_preprocess_rows_lds(max_width);
-    if (e->pre_rows_lds > 60 * 1024) e->pre_rows = false, e->host_read = 0;   // (frames wider than ~10 k pixels: the per-pixel form, staged)
+    if (e->pre_rows_lds > 96 * 1024) e->pre_rows = false, e->host_read = 0;   // (frames wider than ~10 k pixels: the per-pixel form, staged)
     e->wide_T = (env = wz_dev_getenv("WZ_WIDE_T")) ? atoi(env) : 0;
     e->wide_min_m = (env = wz_dev_getenv("WZ_WIDE_MIN_M")) ? atoi(env) : 1;
     {
