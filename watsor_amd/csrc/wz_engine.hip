@@ -830,7 +830,7 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     e->pre_rows = (env = wz_dev_getenv("WZ_PRE_ROWS")) ? atoi(env) != 0 : e->pre_rows;
     e->host_read = (env = wz_dev_getenv("WZ_HOST_READ")) ? atoi(env) : e->host_read;
     e->pre_rows_lds = (int)wz_preprocess_rows_lds(max_width);
-    if (e->pre_rows_lds > 96 * 1024) e->pre_rows = false, e->host_read = 0;   // (frames wider than ~10 k pixels: the per-pixel form, staged)
+    if (e->pre_rows_lds > 60 * 1024) e->pre_rows = false, e->host_read = 0;   // (frames wider than ~6 800 pixels need more LDS than a launch gets by default: the per-pixel form, staged)
     e->wide_T = (env = wz_dev_getenv("WZ_WIDE_T")) ? atoi(env) : 0;
     e->wide_min_m = (env = wz_dev_getenv("WZ_WIDE_MIN_M")) ? atoi(env) : 1;
     {
