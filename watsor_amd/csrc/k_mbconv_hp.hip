@@ -115,7 +115,7 @@ __device__ __forceinline__ void wz_hp_unpack(const wz_u32x4_t t, wz_f32x2_t x[4]
 // (3.5 instructions per value: the clamp (v_max_f32 with the clamp modifier), a packed fma, then per value the rounding add that also
 // takes the exponent bias off, a shift, and one v_and_or_b32 per pair.  The clamp as the output modifier of a PACKED multiply by
 // one -- `v_pk_mul_f32 ..., 1.0 clamp`, half an instruction per value -- assembles and does not clamp on this part: measured, garbage
-// codes for negative pre-activations, profiles/r04_robust_program.txt.)
+// codes for negative pre-activations, profiles/r04_robust_program_variants.txt.)
 __device__ __forceinline__ wz_f32x2_t wz_hp_clamp01_pk(const wz_f32x2_t d) {
     return (wz_f32x2_t){__builtin_amdgcn_fmed3f(d[0], 0.0f, 1.0f), __builtin_amdgcn_fmed3f(d[1], 0.0f, 1.0f)};
 }
