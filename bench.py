@@ -626,7 +626,7 @@ def worker_legs(model_dir, device=0, only_8cams=False):
     return legs
 
 
-def all_rank_legs(engine_path, model_dir, local_rank, host_frames, dist, world, plan=None):
+def all_rank_legs(engine_path, model_dir, local_rank, host_frames, dist, world, plan=None, rank_info=None):
     """world > 1: the HOST-side legs on EVERY rank at the same time (a barrier in front of each).  Replicas whose frames sit in HBM
     scale trivially; what an 8-GPU Watsor box shares is the host -- PCIe root complex, memory bandwidth, cores for the worker
     processes and their producers -- and that only shows when all ranks move host frames together.  -> {leg: [per-rank dict]}"""
@@ -640,6 +640,8 @@ def all_rank_legs(engine_path, model_dir, local_rank, host_frames, dist, world, 
             mine.update(fn())
         except Exception as e:
             mine[name] = dict(error=repr(e))
+    if rank_info is not None:
+        mine["_rank"] = rank_info                    # where this rank ran: GPU's PCI address, NUMA node, CPUs it was pinned to
     gathered = [None] * world
     dist.all_gather_object(gathered, mine)
     return gathered
@@ -648,7 +650,11 @@ def all_rank_legs(engine_path, model_dir, local_rank, host_frames, dist, world, 
 def summarise_rank_legs(gathered):
     """[per-rank {leg: dict}] -> {leg: {per_rank: [frames/s], sum, min, p50_ms_per_rank, workload}}"""
     out = {}
+    if any("_rank" in g for g in gathered):
+        out["ranks"] = [g.get("_rank") for g in gathered]
     for name in gathered[0]:
+        if name == "_rank":
+            continue
         vals = [g.get(name, {}).get("value") for g in gathered]
         entry = dict(per_rank=vals)
         if all(isinstance(v, (int, float)) for v in vals):
@@ -917,26 +923,57 @@ def note(msg):
         print("[bench %7.2fs] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
 
 
-def spawn_ranks(n, argv):
+RANK_START_TIMEOUT_S = 120     # rendezvous: a rank that is not there by then never will be (gloo's own default is 30 minutes)
+RANK_POLL_S = 0.2
+
+
+def spawn_ranks(n, argv, poll_s=RANK_POLL_S):
     """`--gpus N` without a launcher: one process per device ordinal 0 .. N-1 (the reference starts one detector
     process per device, `watsor/detection/detector.py:34-50`); gloo rendezvous on 127.0.0.1 for the barrier and the
-    max-over-ranks; rank 0's JSON line is this process's output."""
+    max-over-ranks; rank 0's JSON line is this process's output.
+    A WATCHDOG polls the children: the moment any rank exits non-zero (no such device, engine creation failed, out of memory ...)
+    the others are killed and the run fails with that rank's code -- without it rank 0 would sit in the rendezvous or in a barrier
+    until gloo's timeout, i.e. for the driver's whole budget."""
+    import signal
+    import tempfile
+    import threading
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
+    out_file = tempfile.TemporaryFile()
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out = procs[0].communicate()[0].decode()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        rc = p.wait() or rc
-    sys.stdout.write(out)
+                                      stdout=out_file if r == 0 else subprocess.DEVNULL, start_new_session=True))
+    failed = None
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                failed = bad[0]
+                break
+            if all(c == 0 for c in codes):
+                break
+            time.sleep(poll_s)
+    finally:
+        for p in procs:                                   # (also on KeyboardInterrupt / a driver's SIGTERM: no orphan holds a GPU)
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)      # each rank leads its own session: its worker / producer children go with it
+                except (ProcessLookupError, PermissionError):
+                    p.kill()
+        for p in procs:
+            p.wait()
+    if failed is not None:
+        print("[bench] rank %d exited with code %d: the other ranks were stopped" % failed, file=sys.stderr, flush=True)
+        return failed[1] if failed[1] > 0 else 1
+    out_file.seek(0)
+    sys.stdout.write(out_file.read().decode())
     sys.stdout.flush()
-    return rc
+    return 0
 
 
 def main():
@@ -953,6 +990,8 @@ def main():
     ap.add_argument("--no-live-pmc", action="store_true", help="take roofline.traffic from the committed profiles/pmc_traffic.json instead of two rocprofv3 --pmc passes of this run")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--schedule-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-numa", action="store_true", help="N > 1: do not pin the ranks to their GPUs' NUMA nodes")
+    ap.add_argument("--fail-rank", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--dry-run", action="store_true",
                     help="harness self-test without a GPU: a stub engine that sleeps 2 ms per step (used by the "
                          "world_size-2 tests; its output is marked invalid)")
@@ -987,8 +1026,18 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import datetime
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=RANK_START_TIMEOUT_S))
         note("process group up (gloo)")
+
+    numa_info = None
+    if world > 1 and not args.dry_run and not args.no_numa:
+        # one process per GPU on a two-socket host: run (and first-touch every page-locked block) on the GPU's own NUMA node
+        from watsor_amd import numa
+        numa_info = numa.pin_to_gpu_node(local_rank)
+        note("rank %d: GPU %s on NUMA node %d, pinned to %d CPUs" % (rank, numa_info["pci"], numa_info["numa_node"], numa_info["cpus"]))
+    if args.fail_rank is not None and rank == args.fail_rank:      # (harness self-test: a rank that dies before the rendezvous)
+        sys.exit(3)
 
     model_dir = "/tmp/wz_bench_%d_%d" % (os.getpid(), rank)
     os.makedirs(model_dir, exist_ok=True)
@@ -1179,7 +1228,8 @@ def main():
             note("cpu baseline done")
     if world > 1 and not args.no_legs:
         stub = [("stub", lambda: {"host_frames_pinned_b8": dict(value=1000.0 + rank, p50_ms=1.0, workload="dry-run stub")})] if args.dry_run else None
-        gathered = all_rank_legs(engine_path, model_dir, local_rank, host_frames, dist, world, plan=stub)
+        gathered = all_rank_legs(engine_path, model_dir, local_rank, host_frames, dist, world, plan=stub,
+                                 rank_info=numa_info or dict(device=local_rank, numa_node=-1, pinned=False))
         if out is not None:
             out["legs_all_ranks_concurrently"] = summarise_rank_legs(gathered)
             note("host-side legs on all ranks done")

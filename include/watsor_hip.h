@@ -61,6 +61,20 @@ typedef struct wz_engine wz_engine_t;
 /* ---- device enumeration: what `cuda_gpus()` does with pycuda (watsor/detection/devices.py:28-77) */
 int wz_device_count(void);
 int wz_device_name_of(int device, char* buf, int buflen);
+/* PCI address of a device ("0000:c1:00.0"; buflen >= 16): the key of /sys/bus/pci/devices/<id>/numa_node and local_cpulist, by which
+ * a detector process pins itself -- and with it the first-touch placement of the frame memory it page-locks -- to the GPU's NUMA node
+ * (the reference starts one detector process per device, watsor/detection/detector.py:34-50, watsor/main.py:414-418). */
+int wz_device_pci_bus_id(int device, char* buf, int buflen);
+
+/* ---- the schedule of this process: which of two sets of launch shapes its engines use.  THROUGHPUT (default): most frames per second
+ * with every lane busy.  LATENCY: the shortest lone batch -- the reference's normal load is one frame at a time per detector
+ * (`_next_frame`, detector.py:102-112).  Process-wide; call before the first wz_create (the shapes are fixed when first asked for;
+ * afterwards only the value already in force is accepted).  Unset: WZ_SCHEDULE in the environment decides.  Plugin option:
+ * hip_options={"schedule": "latency" | "throughput" | "auto"} (watsor_amd/detection/hip_gpu.py). */
+#define WZ_SCHEDULE_THROUGHPUT 0
+#define WZ_SCHEDULE_LATENCY 1
+int wz_set_schedule(int schedule);
+int wz_get_schedule(void);
 
 /* ---- lifecycle: TensorRTObjectDetector.__init__/__exit__ (tensorrt_gpu.py:20-53,62-63)
  * engine_path: file written by `python -m watsor_amd.engine` (the analogue of gpu.trt).

@@ -42,14 +42,43 @@ def synth_weights():
     return synthetic_weights(SEED)
 
 
+class ModelDir(str):
+    """A model directory path that remembers which `-p 16` program its mi355x.bin holds (`.program`: "default" | "robust")."""
+    program = "default"
+
+
+def _packed(tmp_path_factory, name, image, program="default"):
+    from watsor_amd import engine
+    d = tmp_path_factory.mktemp(name)
+    engine.save_engine(image, str(d / "mi355x.bin"))
+    out = ModelDir(str(d))
+    out.program = program
+    return out
+
+
 @pytest.fixture(scope="session")
-def model_dir(synth_weights, tmp_path_factory):
+def model_dir_default(synth_weights, tmp_path_factory):
     """A model directory holding mi355x.bin built from the seeded synthetic weights: the default `-p 16` program
     (fused blocks, stem folded in, blocks 0 .. 12 with split matrix operands)."""
     from watsor_amd import engine
-    d = tmp_path_factory.mktemp("model")
-    engine.save_engine(engine.build_engine(synth_weights), str(d / "mi355x.bin"))
-    return str(d)
+    return _packed(tmp_path_factory, "model", engine.build_engine(synth_weights))
+
+
+@pytest.fixture(scope="session")
+def model_dir_robust(synth_weights, tmp_path_factory):
+    """The ROBUST `-p 16` program on the same weights (`build_engine(robust=True)`: all 17 blocks on the split-operand kernel, the
+    16-bit float-form chunk buffer on blocks 0 .. 9, Conv_1 with split weights) -- what `--robust auto` packs for a trained checkpoint
+    and what bench.py's headline is timed on."""
+    from watsor_amd import engine
+    return _packed(tmp_path_factory, "model_robust", engine.build_engine(synth_weights, robust=True), "robust")
+
+
+@pytest.fixture(scope="session", params=["default", "robust"])
+def model_dir(request):
+    """BOTH `-p 16` programs: every test that asks for `model_dir` -- directly or through an engine fixture built
+    on it -- runs once on the default program and once on the robust one, the program the benchmark's headline and a trained
+    checkpoint get.  Tests that are about one program's own launch shapes ask for `model_dir_default` / `model_dir_robust`."""
+    return request.getfixturevalue("model_dir_" + request.param)
 
 
 @pytest.fixture(scope="session")

@@ -50,3 +50,35 @@ def test_gpus_flag_starts_the_ranks_itself():
         os.environ.update(saved)
     assert out["n_gpus"] == 2 and out["camera_seeds"] == [1234, 2234] and out["rounds"] >= 3
     assert 3000 < out["value"] < 16200                # two replicas of the single-process figure
+
+
+def test_eight_ranks_dry_run():
+    """The shape the driver's scaling run has on an 8-GPU node: `--gpus 8` without a launcher -> eight rank processes, one line,
+    every rank with its own camera, the host-side legs gathered from all eight.  (Timing is not asserted: eight stub ranks share
+    this container's cores.)"""
+    env_keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")
+    saved = {k: os.environ.pop(k) for k in env_keys if k in os.environ}
+    try:
+        out = run([sys.executable, "bench.py", "--gpus", "8", "--steps", "10", "--warmup", "2", "--dry-run"])
+    finally:
+        os.environ.update(saved)
+    assert out["n_gpus"] == 8 and out["camera_seeds"] == [1234 + 1000 * r for r in range(8)]
+    leg = out["legs_all_ranks_concurrently"]["host_frames_pinned_b8"]
+    assert leg["per_rank"] == [1000.0 + r for r in range(8)] and leg["sum"] == sum(1000.0 + r for r in range(8))
+    assert out["value"] > 0 and out["scaling"] == "weak"
+
+
+def test_a_rank_that_dies_stops_the_run_at_once():
+    """`spawn_ranks` watches its children: a rank that exits non-zero before the rendezvous (no such device, engine creation failed)
+    must end the run with an error within seconds -- not leave the other ranks in gloo's rendezvous / barrier until ITS timeout."""
+    import time
+    env_keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")
+    env = {k: v for k, v in os.environ.items() if k not in env_keys}
+    env.update(WZ_BENCH_VERBOSE="0", MASTER_ADDR="127.0.0.1")
+    t0 = time.time()
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "3", "--steps", "10", "--warmup", "2", "--dry-run", "--fail-rank", "2"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=100)
+    assert p.returncode == 3, (p.returncode, p.stderr[-500:])
+    assert "rank 2 exited with code 3" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]      # no line is better than a line from a broken job
+    assert time.time() - t0 < 60

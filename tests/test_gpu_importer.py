@@ -17,12 +17,12 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("precision", [16, 32])
-def test_engine_from_a_frozen_graph_detects_identically(model_dir, model_dir_fp32, synth_weights, tmp_path, precision):
+def test_engine_from_a_frozen_graph_detects_identically(model_dir_default, model_dir_fp32, synth_weights, tmp_path, precision):
     pb = tmp_path / "frozen_inference_graph.pb"
     write_frozen_graph(str(pb), synth_weights)
     out = tmp_path / "model" / "mi355x.bin"
     assert engine.main(["-i", str(pb), "-o", str(out), "-p", str(precision)]) == 0     # the CLI, like watsor/engine.py:61-107
-    ref_dir = model_dir if precision == 16 else model_dir_fp32
+    ref_dir = model_dir_default if precision == 16 else model_dir_fp32
     assert open(out, "rb").read() == open(os.path.join(ref_dir, "mi355x.bin"), "rb").read()
     frames = [synthetic_frame(640, 480, 50 + i) for i in range(3)] + [synthetic_frame(1280, 720, 60)]
     a, b = make_engine(str(tmp_path / "model"), max_batch=4), make_engine(ref_dir, max_batch=4)

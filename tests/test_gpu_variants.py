@@ -74,10 +74,10 @@ def outside_heavy_head_outputs(seed, n_objects=40, per_object=6):
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
-def test_clip_after_nms_matches_its_oracle_twin(dir_clip_after, model_dir, seed):
+def test_clip_after_nms_matches_its_oracle_twin(dir_clip_after, model_dir_default, seed):
     be, lg = outside_heavy_head_outputs(seed)
     after = conftest.make_engine(dir_clip_after, max_batch=2, dev=True)
-    before = conftest.make_engine(model_dir, max_batch=2, dev=True)
+    before = conftest.make_engine(model_dir_default, max_batch=2, dev=True)
     try:
         for eng, kw in ((after, dict(clip_after_nms=True)), (before, {})):
             B, S, C, N = eng.stage_postprocess(be, lg)
@@ -172,7 +172,10 @@ def test_latency_schedule_detects_the_same_objects(model_dir, tmp_path):
         assert p.returncode == 0, p.stderr[-1500:]
         out[sched] = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     a, b = out["throughput"], out["latency"]
-    assert b["nodes"] > a["nodes"]                                   # the latency schedule keeps the reduce launches of blocks 13 .. 16
+    if model_dir.program == "default":
+        assert b["nodes"] > a["nodes"]                               # the latency schedule keeps the reduce launches of blocks 13 .. 16
+    else:
+        assert b["nodes"] >= a["nodes"]                              # (robust: those blocks reduce inside their launch under both schedules)
     for f in range(8):
         ref = dict(label=np.array(a["label"][f], np.int32), confidence=np.array(a["conf"][f]), box=np.array(a["box"][f], np.int32))
         got = np.zeros(100, ROW_DTYPE)
@@ -190,7 +193,8 @@ def test_latency_schedule_detects_the_same_objects(model_dir, tmp_path):
     dict(WZ_HP_CS19_LEAN4="0", WZ_HP_CS_OCC4="0", WZ_HP_CS6_LEAN4="0"),             # the 256-register builds of the chunk-split blocks
     dict(WZ_HP_CS19_LEAN4="0", WZ_HP_CS19_NW="8", WZ_MB_CS_MIN_W="11"),             # round 2's shapes
 ])
-def test_earlier_launch_shapes_detect_the_same_objects(model_dir, knobs):
+def test_earlier_launch_shapes_detect_the_same_objects(model_dir_default, knobs):
+    model_dir = model_dir_default
     """The launch shapes of the split blocks and of blocks 13 .. 16 changed several times this round (DESIGN.md section 5): every one of
     them is the same network summed in another order.  A child process on the development library with the earlier shapes selected
     reports more graph nodes where a reduce launch comes back, and rows that agree with the default's to rounding."""

@@ -28,6 +28,7 @@ def fill(frame, img):
 def run_child(ctx, *args, **kw):
     import gpu_worker_child
     rq = ctx.Queue()
+    args = tuple(str(a) if isinstance(a, str) else a for a in args)      # (conftest.ModelDir does not unpickle in the spawned child)
     p = ctx.Process(target=gpu_worker_child.run_worker, args=args + (rq,), kwargs=kw)
     p.start()
     status, a, b, c = rq.get(timeout=240)
@@ -161,7 +162,7 @@ def test_two_workers_share_one_queue_and_one_gpu(model_dir):
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import worker_bench
-    r = worker_bench.run(model_dir, n_cams=8, seconds=1.5, workers=2, gpus=1, costly=False, check=True, max_batch=4, warm_frames=20)
+    r = worker_bench.run(str(model_dir), n_cams=8, seconds=1.5, workers=2, gpus=1, costly=False, check=True, max_batch=4, warm_frames=20)
     print("\ntwo workers, one queue, one GPU: %s" % r)
     c = r["check"]
     assert c["latch_steps"] == c["fps_calls"] == c["worker_frames"] > 1000

@@ -211,17 +211,40 @@ def test_rejected_batch_is_retried_frame_by_frame_and_every_payload_is_released(
     assert fps.count.value == 2
 
 
-def test_options_follow_the_frame_buffers():
+def test_options_follow_the_frame_buffers(monkeypatch):
+    monkeypatch.delenv("WATSOR_HIP_MAX_BATCH", raising=False)
+    monkeypatch.delenv("WZ_SCHEDULE", raising=False)
     _, cams = setup(wide=2)
-    assert hip_detector_options(cams, {}) == {"max_width": 96, "max_height": 48}
+    assert hip_detector_options(cams, {}) == {"max_width": 96, "max_height": 48, "schedule": "latency"}
     assert hip_detector_options(cams, {"hip_options": {"max_width": 4096, "max_batch": 16}}) == \
-        {"max_width": 4096, "max_height": 48, "max_batch": 16}
-    assert hip_detector_options({}, {}) == {}
+        {"max_width": 4096, "max_height": 48, "max_batch": 16, "schedule": "latency"}
+    assert hip_detector_options({}, {}) == {"schedule": "throughput"}
     # more than 8 cameras: batches of up to 16 unless the installation says otherwise
     many = {"cam%d" % i: cams["cam0"] for i in range(9)}
     assert hip_detector_options(many, {})["max_batch"] == 16
     assert hip_detector_options(many, {"hip_options": {"max_batch": 4}})["max_batch"] == 4
     assert "max_batch" not in hip_detector_options({"cam%d" % i: cams["cam0"] for i in range(8)}, {})
+    # ... and that includes the environment setting the plugin reads: the factory's 16 must not shadow it
+    monkeypatch.setenv("WATSOR_HIP_MAX_BATCH", "12")
+    assert "max_batch" not in hip_detector_options(many, {})
+    assert hip_detector_options(many, {"hip_options": {"max_batch": 4}})["max_batch"] == 4
+
+
+def test_schedule_is_chosen_by_the_number_of_cameras(monkeypatch):
+    """`hip_options["schedule"]` = latency | throughput | auto.  auto (default): one queued frame per camera (`sync.py:156-166`) means
+    up to four cameras never fill the lanes -- the launch shapes that finish a lone batch soonest; more cameras: throughput.
+    An explicit option or WZ_SCHEDULE in the environment wins."""
+    monkeypatch.delenv("WZ_SCHEDULE", raising=False)
+    _, cams = setup()
+    few = {"cam%d" % i: cams["cam0"] for i in range(4)}
+    more = {"cam%d" % i: cams["cam0"] for i in range(5)}
+    assert hip_detector_options(few, {})["schedule"] == "latency"
+    assert hip_detector_options(more, {})["schedule"] == "throughput"
+    assert hip_detector_options(few, {"hip_options": {"schedule": "auto"}})["schedule"] == "latency"
+    assert hip_detector_options(few, {"hip_options": {"schedule": "throughput"}})["schedule"] == "throughput"
+    assert hip_detector_options(more, {"hip_options": {"schedule": "latency"}})["schedule"] == "latency"
+    monkeypatch.setenv("WZ_SCHEDULE", "throughput")
+    assert "schedule" not in hip_detector_options(few, {})                    # the operator's environment setting decides in the library
 
 
 def test_plain_plugin_without_batch_or_async_api():
@@ -279,3 +302,15 @@ def test_rows_incomplete_counts_the_batch_any_other_collect_failure_does_not(mon
     w._next_frames([shm.Payload("cam%d" % c, 1) for c in range(3)], None, cams, fps, it, det)
     assert [e for e in det.log if e[0] == "sync"] == [("sync", 3)]         # one batched call, no frame-by-frame retry
     assert fps.count.value == 3 and all(cams["cam%d" % c].frames[1].latch.steps.value == 1 for c in range(3))
+    assert it.count.value == 3 and it.total.value >= 0                     # ... and the gauge is fed although the call raised
+
+    class OneOverflowing(ScriptedDetector):
+        def detect(self, shape, image, detections):
+            super().detect(shape, image, detections)
+            raise RowsIncomplete("rows may be incomplete")
+
+    _, cams = setup()
+    det, w = OneOverflowing(), Worker()
+    fps, it = shm.Gauge(ctx), shm.Gauge(ctx)
+    w._next_frames([shm.Payload("cam0", 2)], None, cams, fps, it, det)     # one payload: the frame-by-frame path
+    assert fps.count.value == 1 and it.count.value == 1 and cams["cam0"].frames[2].latch.steps.value == 1

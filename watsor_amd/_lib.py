@@ -22,6 +22,7 @@ WZ_SLOTS = 8
 WZ_FMT_RGB24, WZ_FMT_NV12, WZ_FMT_I420 = 0, 1, 2
 WZ_NUM_LABELS = 91
 WZ_MAX_CAMS = 256
+WZ_SCHEDULE_THROUGHPUT, WZ_SCHEDULE_LATENCY = 0, 1
 
 c_u8p = C.POINTER(C.c_uint8)
 c_i32p = C.POINTER(C.c_int32)
@@ -34,6 +35,9 @@ DetP = C.POINTER(Detection)
 SIGNATURES = {
     "wz_device_count": (C.c_int, []),
     "wz_device_name_of": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
+    "wz_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
+    "wz_set_schedule": (C.c_int, [C.c_int]),
+    "wz_get_schedule": (C.c_int, []),
     "wz_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "wz_destroy": (None, [C.c_void_p]),
     "wz_device_name": (C.c_char_p, [C.c_void_p]),

@@ -157,14 +157,13 @@ static inline const char* wz_dev_getenv(const char* name) {
 #endif
 }
 
-// WZ_SCHEDULE=latency (operator setting, read once per process): the launch shapes that make ONE batch finish soonest on an otherwise
-// idle GPU -- eight waves per 19x19 tile, the 10x10 blocks on 256 workgroups + a reduce launch, the SSD heads' K slices cut for the
-// whole chip.  Default ("throughput"): the shapes that leave room for the other lanes' launches -- 9 % more frames/s with four lanes
-// in flight, 3 % more latency of a lone batch (profiles/r03_wave_counts_and_cu_footprints.txt).
-static inline bool wz_latency_schedule() {
-    static const bool lat = [] { const char* e = getenv("WZ_SCHEDULE"); return e && (e[0] == 'l' || e[0] == 'L'); }();
-    return lat;
-}
+// The SCHEDULE of a process (wz_set_schedule() before its first engine, else WZ_SCHEDULE in the environment, else throughput; fixed the
+// first time anything asks): "latency" = the launch shapes that make ONE batch finish soonest on an otherwise idle GPU -- eight waves
+// per 19x19 tile, the 10x10 blocks on 256 workgroups (+ a reduce launch in the default program), the SSD heads' K slices cut for the
+// whole chip, page-locked host frames read in place.  "throughput" (default): the shapes that leave room for the other lanes'
+// launches -- 9 % more frames/s with four lanes in flight, 3 % more latency of a lone batch (DESIGN.md section 5,
+// profiles/r03_wave_counts_and_cu_footprints.txt).  Defined in wz_engine.hip.
+bool wz_latency_schedule();
 
 #define WZ_LAUNCH(...) do { for (int _wz_r = 0; _wz_r < wz_launch_repeat; ++_wz_r) hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 // hp: the input tensor is a hi + lo pair (8 halves per pixel: r g b 0 | r g b 0)

@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <map>
 #include <string>
@@ -690,6 +691,38 @@ extern "C" int wz_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+// ---- the process's schedule (wz_common.h: wz_latency_schedule; include/watsor_hip.h: wz_set_schedule) --------------------------
+static std::atomic<int> g_schedule{-1};   // -1: not fixed yet; WZ_SCHEDULE_THROUGHPUT / WZ_SCHEDULE_LATENCY once anything asked
+bool wz_latency_schedule() {
+    int s = g_schedule.load();
+    if (s < 0) {
+        const char* env = getenv("WZ_SCHEDULE");
+        int want = (env && (env[0] == 'l' || env[0] == 'L')) ? WZ_SCHEDULE_LATENCY : WZ_SCHEDULE_THROUGHPUT;
+        int expect = -1;
+        g_schedule.compare_exchange_strong(expect, want);
+        s = g_schedule.load();
+    }
+    return s == WZ_SCHEDULE_LATENCY;
+}
+extern "C" int wz_set_schedule(int schedule) {
+    if (schedule != WZ_SCHEDULE_THROUGHPUT && schedule != WZ_SCHEDULE_LATENCY) return wz_fail(WZ_EINVAL, "wz_set_schedule: unknown schedule %d", schedule);
+    int expect = -1;
+    if (g_schedule.compare_exchange_strong(expect, schedule) || expect == schedule) return WZ_OK;
+    return wz_fail(WZ_EINVAL, "wz_set_schedule: the launch shapes of this process were already fixed for the %s schedule (set it before the first wz_create)",
+                   expect == WZ_SCHEDULE_LATENCY ? "latency" : "throughput");
+}
+extern "C" int wz_get_schedule(void) { return wz_latency_schedule() ? WZ_SCHEDULE_LATENCY : WZ_SCHEDULE_THROUGHPUT; }
+
+// "0000:c1:00.0" of a device: what /sys/bus/pci/devices/<id>/{numa_node,local_cpulist} are keyed by (watsor_amd/numa.py)
+extern "C" int wz_device_pci_bus_id(int device, char* buf, int buflen) {
+    if (!buf || buflen < 16) return wz_fail(WZ_EINVAL, "wz_device_pci_bus_id: buffer of at least 16 bytes expected");
+    if (hipDeviceGetPCIBusId(buf, buflen, device) != hipSuccess) {
+        (void)hipGetLastError();
+        return wz_fail(WZ_ENODEV, "no HIP device %d", device);
+    }
+    return WZ_OK;
 }
 
 extern "C" int wz_device_name_of(int device, char* buf, int buflen) {

@@ -36,6 +36,7 @@ installed Watsor, see INTEGRATION.md.  Everything below `detect_batch()` does no
 """
 from __future__ import annotations
 
+import os
 from collections import deque
 from os import path
 from queue import Empty
@@ -156,6 +157,7 @@ class BatchedWorkerMixin:
                         images.append(image_np)
                         rows.append(frame.header.detections)
                     cams = self._camera_ids(st, [p for p, _ in frames])
+                    t0 = perf_counter()
                     if cams is not None:
                         time_of_inference = object_detector.detect_batch(shapes, images, rows, cameras=cams)
                     else:
@@ -166,7 +168,9 @@ class BatchedWorkerMixin:
                     done = True
                 except RowsIncomplete as e:       # rows written (and complete for every frame but the one named): no retry
                     self._warn("batch of %d frames: %s" % (len(frames), e))
-                    for _ in frames:
+                    share = (perf_counter() - t0) * 1000.0 / len(frames)   # (the call raised instead of returning its time: the
+                    for _ in frames:                                        # gauge must not go stale under a persistent overflow)
+                        inference_time(value=share)
                         fps(value=True)
                     done = True
                 except ValueError as e:           # a frame the engine cannot take (size): the others still get detected
@@ -184,6 +188,7 @@ class BatchedWorkerMixin:
     def _detect_one(self, st, payload, frame, fps, inference_time, object_detector):
         image_shape, image_np = frame.get_numpy_image(uint8)
         cams = self._camera_ids(st, [payload])
+        t0 = perf_counter()
         try:
             if cams is not None and hasattr(object_detector, "detect_batch"):
                 t = object_detector.detect_batch([image_shape], [image_np], [frame.header.detections], cameras=cams)
@@ -191,6 +196,7 @@ class BatchedWorkerMixin:
                 t = object_detector.detect(image_shape, image_np, frame.header.detections)
         except RowsIncomplete as e:               # the rows were written (possibly fewer than the frame deserves): it counts
             self._warn("frame of %s: %s" % (payload.sender, e))
+            inference_time(value=(perf_counter() - t0) * 1000.0)
             fps(value=True)
             return
         inference_time(value=t)
@@ -340,9 +346,19 @@ def hip_detector_options(frame_buffers, kwargs):
     # More than 8 cameras: batches of up to 16.  The worker never WAITS for a batch to fill (it takes what is queued), so the limit
     # only matters once that many frames are waiting -- and then one batch of 16 is both faster and sooner done than two of 8
     # (16 cameras, one MI355X: 40.1 k frames/s at 0.24 ms enqueue-to-latch against 34.1 k at 1.31 ms).
-    if len(frame_buffers) > 8:
-        opts.setdefault("max_batch", 16)
+    # An operator's own setting -- `hip_options["max_batch"]` or WATSOR_HIP_MAX_BATCH -- is left alone.
+    if len(frame_buffers) > 8 and "max_batch" not in opts and not os.environ.get("WATSOR_HIP_MAX_BATCH"):
+        opts["max_batch"] = 16
+    # The schedule: "auto" (or nothing) -> by the number of cameras this detector serves.  `BalancedQueue` holds one queued frame per
+    # camera (`watsor/stream/sync.py:156-166`), so with up to 4 cameras a batch is 1 - 4 frames and at most one or two are in flight:
+    # the launch shapes that finish a lone batch soonest are the right ones (one frame: 0.35 -> 0.30 ms per detect()); with more
+    # cameras the lanes fill and the throughput shapes give 5 - 9 % more frames per second.
+    if str(opts.get("schedule") or "auto").lower() == "auto" and not os.environ.get("WZ_SCHEDULE"):
+        opts["schedule"] = "latency" if 0 < len(frame_buffers) <= LATENCY_SCHEDULE_MAX_CAMERAS else "throughput"
     return opts
+
+
+LATENCY_SCHEDULE_MAX_CAMERAS = 4
 
 
 def create_object_detectors(delegate_class, stop_event, log_queue, frame_queue, frame_buffers, model_path,
@@ -355,8 +371,10 @@ def create_object_detectors(delegate_class, stop_event, log_queue, frame_queue, 
       hip_cameras  {camera name: normalised camera config}  -> the camera's Confidence / Area / Mask filters run on the GPU
       hip_drop     True: rows failing those filters come back as all-zero rows (for `hip_detection_sieve()`)
       hip_options  dict(max_batch=, max_width=, max_height=) overriding what is derived from the frame buffers (the largest
-                   frame; max_batch 16 for more than 8 cameras, else the plugin's 8);
-                   pixel_format= "rgb24" | "nv12" | "yuv420p" (or {camera name: ...}): what the decoders write (hip_gpu.py)
+                   frame; max_batch 16 for more than 8 cameras unless WATSOR_HIP_MAX_BATCH says otherwise, else the plugin's 8);
+                   pixel_format= "rgb24" | "nv12" | "yuv420p" (or {camera name: ...}): what the decoders write (hip_gpu.py);
+                   schedule= "latency" | "throughput" | "auto" (default: latency for up to 4 cameras per detector, WZ_SCHEDULE wins);
+                   numa= True | False | "auto" (default: pin each detector process to its GPU's NUMA node on multi-GPU hosts)
       hip_lanes    batches kept in flight per GPU by the worker (default: the engine's lanes, 4)
       hip_metric_interval  seconds of batches folded into one `inference_time` observation (default 0.005; 0: one per batch)
       hip_frame_table      False: describe the frames of every batch to the engine instead of binding them once"""
@@ -373,7 +391,35 @@ def create_object_detectors(delegate_class, stop_event, log_queue, frame_queue, 
                 delegate_class, "detector{}".format(len(detectors) + 1), stop_event, log_queue, frame_queue,
                 frame_buffers, kwargs={**kwargs, 'detector_class': clazz, 'detector_args': (model_path, device, options)}))
 
-    if _ref._ALWAYS_USE_CPU or len(detectors) == 0:
-        detectors += _ref.create_object_detectors(delegate_class, stop_event, log_queue, frame_queue,
-                                                  frame_buffers, model_path, kwargs)
-    return detectors
+    # The reference's own gates run as they always do (`detector.py:40-50`): Coral for edgetpu.tflite, CUDA for gpu.trt, CPU when
+    # `_ALWAYS_USE_CPU` is set or NOTHING was found so far -- and the detectors they add continue the count ("detector3" after two AMD
+    # GPUs: worker names stay unique, every family the model path provides for coexists on the one queue).
+    others = _reference_detectors(_ref, delegate_class, stop_event, log_queue, frame_queue, frame_buffers, model_path, kwargs,
+                                  first_index=len(detectors) + 1, found_so_far=len(detectors))
+    return detectors + others
+
+
+def _reference_detectors(ref, delegate_class, stop_event, log_queue, frame_queue, frame_buffers, model_path, kwargs, first_index,
+                         found_so_far):
+    """What `watsor.detection.detector.create_object_detectors` would append after `found_so_far` detectors already exist: its file
+    gates and its CPU rule (`_ALWAYS_USE_CPU or len(detectors) == 0`, detector.py:48), named from `first_index` on.  The reference
+    function itself cannot be told either (its `gen_name()` restarts at detector1 and its CPU rule counts only its own list)."""
+    from watsor.detection.devices import cpus, cuda_gpus, edge_tpus
+    out = []
+
+    def append_detector(clazz, *args):
+        out.append(ref.ObjectDetector(delegate_class, "detector{}".format(first_index + len(out)), stop_event, log_queue, frame_queue,
+                                      frame_buffers, kwargs={**kwargs, 'detector_class': clazz, 'detector_args': (model_path, *args,)}))
+
+    if path.isfile(path.join(model_path, 'edgetpu.tflite')):
+        for device, clazz in edge_tpus():
+            append_detector(clazz, device)
+    if path.isfile(path.join(model_path, 'gpu.trt')):
+        for device, clazz in cuda_gpus():
+            append_detector(clazz, device)
+    if ref._ALWAYS_USE_CPU or found_so_far + len(out) == 0:
+        for clazz in cpus():
+            append_detector(clazz)
+    assert found_so_far + len(out) > 0, "Failed to create an object detector." \
+                                        "Make sure TensorFlow is installed and model files are provided."
+    return out

@@ -62,11 +62,27 @@ class HipObjectDetector:
         the keyword forms and the WATSOR_HIP_MAX_* environment variables are the fallbacks.
         `options["pixel_format"]`: "rgb24" (default) | "nv12" | "yuv420p", or {camera name: one of these} -- what the cameras'
         decoders write into their frame buffers.  An NV12 / yuv420p frame is handed over as the (H*3/2, W) uint8 array of its
-        bytes (that is its `image_shape`)."""
+        bytes (that is its `image_shape`).
+        `options["schedule"]`: "latency" | "throughput" | "auto" (default) -- the launch shapes of this detector PROCESS
+        (include/watsor_hip.h: wz_set_schedule).  "latency" makes a lone batch finish soonest -- the reference's normal load is one
+        frame at a time (`_next_frame`, detector.py:102-112); "throughput" gets the most frames per second out of four batches in
+        flight.  "auto" leaves what is in force (WZ_SCHEDULE, else throughput) -- the factory resolves it by the number of cameras
+        (`hip_detector_options`: latency for up to 4).
+        `options["numa"]`: True | False | "auto" (default) -- pin this process to the CPUs local to the GPU before the engine
+        allocates its page-locked blocks (watsor_amd/numa.py); "auto": only on hosts with more than one GPU."""
         engine_path = os.path.join(model_path, ENGINE_FILE)
         if not os.path.isfile(engine_path):
             raise FileNotFoundError(engine_path)
         options = options or {}
+        schedule = options.get("schedule") or "auto"
+        if str(schedule).lower() not in ("auto", "latency", "throughput"):
+            raise ValueError("schedule %r: expected latency, throughput or auto" % (schedule,))
+        schedule = None if str(schedule).lower() == "auto" else str(schedule).lower()
+        self.numa = None
+        numa = options.get("numa", "auto")
+        if numa is True or (numa == "auto" and self._several_gpus()):
+            from ..numa import pin_to_gpu_node
+            self.numa = pin_to_gpu_node(device)
         max_batch = max_batch or options.get("max_batch") or int(os.environ.get("WATSOR_HIP_MAX_BATCH", "8"))
         max_width = max_width or options.get("max_width") or int(os.environ.get("WATSOR_HIP_MAX_WIDTH", "1920"))
         max_height = max_height or options.get("max_height") or int(os.environ.get("WATSOR_HIP_MAX_HEIGHT", "1080"))
@@ -74,10 +90,22 @@ class HipObjectDetector:
         self.__fmt_by_name = {str(k): pixel_format_code(v) for k, v in pf.items()} if isinstance(pf, dict) else {}
         self.__fmt_default = FMT_RGB24 if isinstance(pf, dict) else pixel_format_code(pf)
         self.__fmt_by_cam = {}
-        self.__engine = HipEngine(engine_path, device, max_batch, max_width, max_height)
+        self.__engine = HipEngine(engine_path, device, max_batch, max_width, max_height, schedule=schedule)
         self.__device = device
         self.__filters = []
         self.__pinned = []
+
+    @staticmethod
+    def _several_gpus() -> bool:
+        from ..runtime import device_count
+        try:
+            return device_count() > 1
+        except (OSError, RuntimeError):
+            return False
+
+    @property
+    def schedule(self) -> str:
+        return self.__engine.schedule
 
     def _formats(self, frames: Sequence[np.ndarray], cameras: Optional[Sequence[int]]):
         return frame_formats(frames, cameras, self.__fmt_default, self.__fmt_by_cam)

@@ -24,6 +24,26 @@ def device_count() -> int:
     return int(_lib.load().wz_device_count())
 
 
+SCHEDULES = {"throughput": _lib.WZ_SCHEDULE_THROUGHPUT, "latency": _lib.WZ_SCHEDULE_LATENCY}
+
+
+def set_schedule(name: str, dev: bool = False) -> None:
+    """The process's schedule (include/watsor_hip.h: wz_set_schedule): "latency" | "throughput".  Before its first engine; afterwards
+    only the schedule already in force is accepted (ValueError otherwise)."""
+    try:
+        code = SCHEDULES[str(name).lower()]
+    except KeyError:
+        raise ValueError("schedule %r: expected one of %s" % (name, ", ".join(sorted(SCHEDULES)))) from None
+    lib = _lib.load(dev=dev)
+    _lib.check(lib.wz_set_schedule(code), "wz_set_schedule", lib)
+
+
+def get_schedule(dev: bool = False) -> str:
+    """The schedule in force ("latency" | "throughput"); asking fixes it (WZ_SCHEDULE in the environment, else throughput)."""
+    code = _lib.load(dev=dev).wz_get_schedule()
+    return next(k for k, v in SCHEDULES.items() if v == code)
+
+
 def device_name(device: int) -> str:
     buf = C.create_string_buffer(256)
     _lib.check(_lib.load().wz_device_name_of(device, buf, 256))
@@ -32,14 +52,18 @@ def device_name(device: int) -> str:
 
 class HipEngine:
     def __init__(self, engine_path: str, device: int = 0, max_batch: int = 8, max_width: int = 1920,
-                 max_height: int = 1080, dev: Optional[bool] = None):
+                 max_height: int = 1080, dev: Optional[bool] = None, schedule: Optional[str] = None):
         """dev=True: on the DEVELOPMENT library (libwatsor_hip_dev.so: stage-level entry points, per-kernel profiling, the WZ_*
         tuning knobs) -- parity tests, bench.py's roofline table and tools/; the product path never asks for it.  Default: the
-        product library, unless WATSOR_HIP_DEV=1 is set (how tools/ switch every engine they create)."""
+        product library, unless WATSOR_HIP_DEV=1 is set (how tools/ switch every engine they create).
+        schedule: "latency" | "throughput" -- the PROCESS's launch shapes (`set_schedule`), asked for before the engine exists; None:
+        whatever is in force (WZ_SCHEDULE, else throughput)."""
         if dev is None:
             dev = os.environ.get("WATSOR_HIP_DEV", "0") not in ("", "0")
         self.dev = bool(dev)
         self._lib = _lib.load(dev=self.dev)
+        if schedule is not None:
+            set_schedule(schedule, dev=self.dev)
         self._h = C.c_void_p()
         self.max_batch = max_batch
         rc = self._lib.wz_create(os.fsencode(engine_path), device, max_batch, max_width, max_height, C.byref(self._h))
@@ -50,6 +74,7 @@ class HipEngine:
         self.num_classes = self._lib.wz_num_classes(self._h)
         self.num_slots = self._lib.wz_num_slots(self._h)
         self.hp_blocks = self._lib.wz_hp_blocks(self._h)   # leading blocks with split (hi + lo) matrix operands
+        self.schedule = get_schedule(dev=self.dev)
         self._dev_allocs: List[int] = []
         self._bound_arrays = {}                            # (submit_bound before any bind_frames: the engine's EINVAL, not an AttributeError)
 
