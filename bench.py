@@ -304,13 +304,19 @@ def schedule_child():
     d = "/tmp/wz_sched_child_%d" % os.getpid()
     os.makedirs(d, exist_ok=True)
     path = os.path.join(d, "mi355x.bin")
-    builder.save_engine(builder.build_engine(synthetic_weights(1234), **HEADLINE_PROGRAM), path)
+    weights = synthetic_weights(1234)
+    builder.save_engine(builder.build_engine(weights, **HEADLINE_PROGRAM), path)
     eng = HipEngine(path, int(os.environ.get("LOCAL_RANK", "0")), BATCH, WIDTH, HEIGHT)
     try:
-        dfr = [eng.upload(synthetic_frame(WIDTH, HEIGHT, 1234 + i)) for i in range(RING * BATCH)]
+        hfr = [synthetic_frame(WIDTH, HEIGHT, 1234 + i) for i in range(RING * BATCH)]
+        dfr = [eng.upload(f) for f in hfr]
         r = throughput(eng, lambda lane, s: eng.submit_device(lane, dfr[(s % RING) * BATCH:(s % RING + 1) * BATCH], [WIDTH] * BATCH, [HEIGHT] * BATCH),
                        BATCH, steps=400, warm=40)
         r["graph_nodes_per_batch"] = eng.graph_nodes(0)
+        r["schedule"] = eng.schedule
+        # the rows THIS schedule's launch shapes produce, against the oracle (three of the batch's frames: ~2 s of oracle each)
+        pr = parity_leg(eng, hfr, dfr, weights, check=(0, 3, 7))
+        r["parity"] = {k: pr[k] for k in ("max_dscore", "max_dbox_px", "frames", "rows_compared", "rows_unexplained", "within_tolerance")}
         print(json.dumps(r), flush=True)
     finally:
         eng.close()
@@ -323,7 +329,7 @@ def latency_schedule_leg():
     """WZ_SCHEDULE=latency: the launch shapes that finish a lone batch soonest (include/watsor_hip.h), measured in a child process on
     the headline workload -- what the default (throughput) schedule trades away."""
     env = dict(os.environ, WZ_SCHEDULE="latency", WZ_BENCH_VERBOSE="0")
-    p = subprocess.run([sys.executable, os.path.abspath(__file__), "--schedule-child"], env=env, capture_output=True, text=True, timeout=180)
+    p = subprocess.run([sys.executable, os.path.abspath(__file__), "--schedule-child"], env=env, capture_output=True, text=True, timeout=240)
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     if p.returncode != 0 or not lines:
         return dict(error=(p.stderr or p.stdout)[-300:])
@@ -404,7 +410,7 @@ def sample_detect_config(nz):
             {"truck": {"area": 10, "confidence": 50, "zones": []}}]
 
 
-def config_legs(engine_path, device, rank):
+def config_legs(engine_path, device, rank, weights=None):
     """Per-GPU shares of BASELINE.json configs[2..4] (frames resident in HBM, filters on where the config has them)
     plus the north star's 300x300 sweep point."""
     from watsor_amd.filter.hip_filter import HipCameraFilter
@@ -430,21 +436,24 @@ def config_legs(engine_path, device, rank):
         for c in range(4):
             nz = zones_from_alpha(masks[c])[0].shape[0]
             filters.append(HipCameraFilter(eng, c, {"width": 1920, "height": 1080, "detect": sample_detect_config(nz)}, alpha=masks[c]))
-        f1080 = [eng.upload(synthetic_frame(1920, 1080, 700 + c)) for c in range(8)]
+        h1080 = [synthetic_frame(1920, 1080, 700 + c) for c in range(8)]
+        f1080 = [eng.upload(f) for f in h1080]
         r = throughput(eng, lambda lane, s: eng.submit_device(lane, f1080[:4], [1920] * 4, [1080] * 4, cams=[0, 1, 2, 3]), 4)
         r["workload"] = "configs[3] share: 4 cameras 1920x1080, each with its alpha zone mask + sample-config thresholds (filters on), batch 4, frames in HBM"
         legs["config4_4x1080p_masks_b4"] = r
         # configs[4]: 128 mixed cameras (640x480 / 1920x1080) with masks + confidence / area filters: 16 per GPU, saturation
         small_masks = [synthetic_zone_mask(640, 480, 300 + c, 2 + c % 5) for c in range(8)]
-        fsmall = [eng.upload(synthetic_frame(640, 480, 800 + c)) for c in range(8)]
+        hsmall = [synthetic_frame(640, 480, 800 + c) for c in range(8)]
+        fsmall = [eng.upload(f) for f in hsmall]
         for c in range(4, 8):
             nz = zones_from_alpha(masks[c])[0].shape[0]
             filters.append(HipCameraFilter(eng, c, {"width": 1920, "height": 1080, "detect": sample_detect_config(nz)}, alpha=masks[c]))
         for c in range(8):
             nz = zones_from_alpha(small_masks[c])[0].shape[0]
             filters.append(HipCameraFilter(eng, 8 + c, {"width": 640, "height": 480, "detect": sample_detect_config(nz)}, alpha=small_masks[c]))
-        mix_frames, mix_w, mix_h, mix_c = [], [], [], []
+        mix_frames, mix_w, mix_h, mix_c, mix_host = [], [], [], [], []
         for c in range(8):                         # alternating resolutions, as the config says
+            mix_host += [hsmall[c], h1080[c]]
             mix_frames += [fsmall[c], f1080[c]]
             mix_w += [640, 1920]
             mix_h += [480, 1080]
@@ -453,11 +462,45 @@ def config_legs(engine_path, device, rank):
         r["workload"] = ("configs[4] share: 16 cameras alternating 640x480 / 1920x1080, masks + confidence / area thresholds "
                          "(config.yaml:69-79), batch 16 = one frame of each camera, frames in HBM, saturation")
         legs["config5_16_mixed_filters_b16"] = r
+        if weights is not None:
+            # parity of THIS leg's configuration: batch 16 (the grid shapes `hip_detector_options` selects for more than 8 cameras), mixed
+            # resolutions, camera filters on -- four of the sixteen frames' rows (label, score, box) against the oracle, and every
+            # frame's zones[] / pass bytes against the oracle's literal polygon filters on those rows (bit-exact or not at all)
+            try:
+                eng.submit_device(0, mix_frames, mix_w, mix_h, cams=mix_c)
+                eng.wait(0)
+                got = eng.slot_rows(0, 16).copy()
+                pr = rows_parity(got, mix_host, weights, check=(0, 1, 10, 15))
+                r["parity"] = {k: pr[k] for k in ("max_dscore", "max_dbox_px", "frames", "rows_compared", "rows_unexplained", "within_tolerance")}
+                r["parity"]["zones_bit_exact"] = zones_bit_exact(got, mix_c, {8 + c: (640, 480, small_masks[c]) for c in range(8)} |
+                                                                 {c: (1920, 1080, masks[c]) for c in range(8)})
+            except Exception as e:                     # a leg must not take the headline down with it
+                r["parity"] = dict(error=repr(e))
         for f in filters:
             f.close()
     finally:
         eng.close()
     return legs
+
+
+def zones_bit_exact(rows, cams, cam_masks):
+    """The rows' zones[] as the GPU wrote them == the oracle's literal MaskFilter (polygon test, oracle/filters.py) on the same rows,
+    for every frame of the batch (north star: "zone-mask hit/miss is bit-exact")."""
+    from oracle import filters as of
+    from oracle import zones as oz
+    from watsor_amd.share import BoundingBox, Detection
+    for i, cam in enumerate(cams):
+        w, h, alpha = cam_masks[cam]
+        nz = len(oz.zone_polygons(alpha))
+        cfg = {"width": w, "height": h, "detect": sample_detect_config(nz)}
+        chain = [of.ConfidenceFilter(cfg), of.AreaFilter(cfg), of.MaskFilter(cfg, alpha=alpha)]
+        for r in rows[i]:
+            d = Detection(label=int(r["label"]), confidence=float(r["confidence"]),
+                          bounding_box=BoundingBox(int(r["x_min"]), int(r["y_min"]), int(r["x_max"]), int(r["y_max"])))
+            _ = d.label > 0 and all(f(d) for f in chain)       # `label > 0 and Confidence and Area and Mask`, short-circuit (track.py:26)
+            if list(d.zones) != [int(z) for z in r["zones"]]:
+                return False
+    return True
 
 
 def host_legs(engine_path, model_dir, device, host_frames):
@@ -696,37 +739,46 @@ def busy_scene_leg(frames, rank):
         os.rmdir(d)
 
 
-def parity_leg(eng, host_frames, d_frames, weights):
-    """North star criterion (1), live, on the engine that was just timed: scores of its detection rows vs the oracle's
-    on 8 of the benchmark's own frames."""
+def rows_parity(got, frames, weights, check=None, tol=SCORE_TOLERANCE):
+    """Detection rows `got[i]` of `frames[i]` (host arrays) against the oracle's, for the frames in `check` (default: all): the north
+    star's criterion as oracle/compare.py states it -- scores, boxes, and an explanation for every row without a partner."""
     from oracle.compare import box_tolerance_px, compare_rows
     from oracle.detect import OracleObjectDetector, rows_as_array
-    n = BATCH
-    eng.submit_device(0, d_frames[:n], [WIDTH] * n, [HEIGHT] * n)
-    eng.wait(0)
-    got = eng.slot_rows(0, n).copy()
     det = OracleObjectDetector(weights=weights)
-    worst, worst_px, matched, total, odd, unexplained, reasons = 0.0, 0, 0, 0, 0, 0, {}
-    for i in range(n):
-        b, c, s, _, _ = det.raw(host_frames[i])
-        ref = rows_as_array(host_frames[i].shape, b, c, s)
-        r = compare_rows(got[i], ref, host_frames[i].shape, tol=SCORE_TOLERANCE)
+    check = list(range(len(frames))) if check is None else list(check)
+    worst, worst_px, matched, total, odd, unexplained, reasons, px_ok = 0.0, 0, 0, 0, 0, 0, {}, True
+    for i in check:
+        b, c, s, _, _ = det.raw(frames[i])
+        ref = rows_as_array(frames[i].shape, b, c, s)
+        r = compare_rows(got[i], ref, frames[i].shape, tol=tol)
         matched += len(r["pairs"])
         total += r["rows_reference"]
         worst = max(worst, r["max_dscore"])
         worst_px = max(worst_px, r["max_dbox_px"])
+        px_ok = px_ok and r["max_dbox_px"] <= box_tolerance_px(frames[i].shape[1], frames[i].shape[0])
         unexplained += r["unexplained"]
         for _, why in r["missing"] + r["extra"]:
             odd += 1
             key = (why or "UNEXPLAINED").split(":")[0].split("(")[0].strip()
             reasons[key] = reasons.get(key, 0) + 1
-    tol_px = box_tolerance_px(WIDTH, HEIGHT)
-    return dict(max_dscore=round(worst, 6), max_dbox_px=int(worst_px), frames=n, rows_compared=matched, rows_reference=total,
-                tolerance=SCORE_TOLERANCE, box_tolerance_px=tol_px, rows_without_partner=odd, rows_without_partner_reasons=reasons,
-                rows_unexplained=unexplained,
-                within_tolerance=bool(worst <= SCORE_TOLERANCE and worst_px <= tol_px and unexplained == 0 and matched >= 0.9 * total),
-                against="oracle (CPU restatement of the reference's TF detector, fp32), same frames, rows matched by label and IoU >= 0.9; "
-                        "a row without a partner must sit at the top-100 cut or at an NMS tie within 2 x tolerance (oracle/compare.py)")
+    return dict(max_dscore=round(worst, 6), max_dbox_px=int(worst_px), frames=len(check), rows_compared=matched, rows_reference=total,
+                tolerance=tol, rows_without_partner=odd, rows_without_partner_reasons=reasons, rows_unexplained=unexplained,
+                within_tolerance=bool(worst <= tol and px_ok and unexplained == 0 and matched >= 0.9 * total))
+
+
+def parity_leg(eng, host_frames, d_frames, weights, check=None):
+    """North star criterion (1), live, on the engine that was just timed: scores of its detection rows vs the oracle's
+    on 8 of the benchmark's own frames."""
+    from oracle.compare import box_tolerance_px
+    n = BATCH
+    eng.submit_device(0, d_frames[:n], [WIDTH] * n, [HEIGHT] * n)
+    eng.wait(0)
+    got = eng.slot_rows(0, n).copy()
+    out = rows_parity(got, host_frames[:n], weights, check)
+    out["box_tolerance_px"] = box_tolerance_px(WIDTH, HEIGHT)
+    out["against"] = ("oracle (CPU restatement of the reference's TF detector, fp32), same frames, rows matched by label and IoU >= 0.9; "
+                      "a row without a partner must sit at the top-100 cut or at an NMS tie within 2 x tolerance (oracle/compare.py)")
+    return out
 
 
 def fp32_engine_leg(weights, frames, rank):
@@ -1193,7 +1245,7 @@ def main():
             legs = {}
             legs.update(host_legs(engine_path, model_dir, local_rank, host_frames))
             note("host-frame legs done")
-            legs.update(config_legs(engine_path, local_rank, rank))
+            legs.update(config_legs(engine_path, local_rank, rank, weights))
             note("config legs done")
             legs.update(host_config_legs(engine_path, local_rank))
             note("host-memory config legs done")

@@ -252,6 +252,15 @@ int wz_debug_nms(wz_engine_t* e, int n, uint64_t* out);
  * workgroup of every fused inverted-residual block, out[n_ops][16]; groups[n_ops] = channel groups launched. */
 int wz_debug_mbconv(wz_engine_t* e, uint64_t* out, int32_t* groups);
 
+/* Lane stamps -- only in a library built with -DWZ_LANE_STAMPS=1 (`make stamps` -> libwatsor_hip_stamps.so; elsewhere both return
+ * WZ_EINVAL): every kernel of a batch records when its first workgroup entered and its last one left (100 MHz ticks of the
+ * device's constant clock).  After wz_wait(slot): out[2k], out[2k+1] = entry / exit of launch k of that batch (launch 0 = the resize
+ * kernel, the last one = the NMS kernel); returns the number of launches.  wz_debug_lane_launch: kernel name and
+ * dims[5] = {workgroups, threads per workgroup, LDS bytes, workgroups one CU holds, registers} of launch idx; returns the number of
+ * launches.  What tools/lane_overlap.py turns into kernels-in-flight and CU-slot-time per step without a profiler in the way. */
+int wz_debug_lane_stamps(wz_engine_t* e, int slot, uint64_t* out, int cap);
+int wz_debug_lane_launch(wz_engine_t* e, int slot, int idx, char* name, int namelen, int* dims);
+
 /* ---- stage-level entry points for the parity tests (host in, host out, synchronous) */
 /* resize + normalise of one frame -> half[size*size*4] (x,y,z,0 per pixel); when the input tensor is a pair
  * (wz_tensor_flags) half[size*size*8]: (x,y,z,0) hi then (x,y,z,0) lo per pixel */

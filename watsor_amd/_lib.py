@@ -101,6 +101,8 @@ DEV_SIGNATURES = {
     "wz_profile_stages": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), c_i32p, c_i32p, C.c_int, C.c_int, c_f32p]),
     "wz_debug_nms": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "wz_debug_mbconv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "wz_debug_lane_stamps": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "wz_debug_lane_launch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int, c_i32p]),
     "wz_stage_preprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "wz_stage_preprocess_fmt": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "wz_stage_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

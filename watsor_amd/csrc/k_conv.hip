@@ -419,6 +419,7 @@ __device__ __forceinline__ void wz_conv_body(const WzConvArgs& a, int bx, int by
 
 template <int KS, int MT, int NT, int U>
 __global__ __launch_bounds__(256) void wz_k_conv(const WzConvArgs a) {
+    WZ_LANE_STAMP(a.dbg);
     wz_conv_body<KS, MT, NT, U>(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
@@ -430,6 +431,7 @@ __global__ __launch_bounds__(256) void wz_k_conv(const WzConvArgs a) {
 // WGS_PER_CU = 2 holds the kernel to 128 registers (U = 2: 109) so that two workgroups share a CU (U = 4: 173 registers, a CU per workgroup).
 template <int KS, int WM = 1, int WN = 1, int U = 2, int WGS_PER_CU = 2>
 __global__ __launch_bounds__(512, WGS_PER_CU) void wz_k_conv_ws(const WzConvArgs a) {
+    WZ_LANE_STAMP(a.dbg);
     constexpr int MT = 2, NT = 2, WAVES = 8, KSPL = WAVES / (WM * WN);
     static_assert(KSPL * WM * WN == WAVES, "eight waves: sub-tiles x K slices");
     __shared__ float4_t red[WAVES][MT * NT][64];   // 32 KiB
@@ -503,6 +505,7 @@ __global__ __launch_bounds__(512, WGS_PER_CU) void wz_k_conv_ws(const WzConvArgs
 // Several small 3x3 convolutions that do not depend on each other (the SSD heads on the 3x3 ... 1x1 maps) in one launch:
 // a workgroup finds its entry from the prefix table and runs wz_k_conv's body on it.
 __global__ __launch_bounds__(256) void wz_k_conv_group(const WzConvGroup g) {
+    WZ_LANE_STAMP(g.stamp);
     int e = 0;
     while (e + 1 < g.n && (int)blockIdx.x >= g.first[e + 1]) ++e;   // wave-uniform
     const int L = (int)blockIdx.x - g.first[e];
@@ -511,6 +514,7 @@ __global__ __launch_bounds__(256) void wz_k_conv_group(const WzConvGroup g) {
 }
 
 __global__ __launch_bounds__(256) void wz_k_splitk_reduce(const WzConvArgs a, const float* __restrict__ ws) {
+    WZ_LANE_STAMP(a.dbg);
     const int tid = blockIdx.x * 256 + threadIdx.x;
     const int n4s = a.n_pad >> 2;
     if (tid >= a.M * n4s) return;
@@ -527,6 +531,7 @@ __global__ __launch_bounds__(256) void wz_k_splitk_reduce(const WzConvArgs a, co
 // The reductions of several convolutions in one launch: a workgroup finds its entry from the prefix table, then does
 // exactly what wz_k_splitk_reduce does (same order over the splits: bit-identical results).
 __global__ __launch_bounds__(256) void wz_k_splitk_reduce_group(const WzReduceGroup g) {
+    WZ_LANE_STAMP(g.stamp);
     if (g.decode && !g.list) {   // first kernel of the histogram-based post chain: clear its per-frame scratch
         const int i = blockIdx.x * 256 + threadIdx.x;
         if (i < g.n_frames * WZ_HIST_BINS) g.hist[i] = 0u;
@@ -614,8 +619,9 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void wz_k_conv_lds(const WzConvAr
     const int wm = wave >> 1, wn = wave & 1;
     // diagnostics (a.dbg != nullptr only in engines created with WZ_MB_DEBUG=1): phase timestamps (100 MHz) of the
     // first workgroup (slots 0..7) and of the last one (8..15)
-    const bool stamp = a.dbg && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1);
+    const bool stamp = !WZ_LANE_STAMPS && a.dbg && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1);
     unsigned long long* const dbg = a.dbg + (blockIdx.x == 0 ? 0 : 8);
+    WZ_LANE_STAMP(a.dbg);
 #define CL_STAMP(i) do { if (stamp) dbg[i] = wall_clock64(); } while (0)
     CL_STAMP(0);
     // XCD-aware tile order: workgroup L runs on XCD L % 8 (each XCD has its own L2).  Renumber so that
@@ -791,6 +797,7 @@ struct WzEpiF16 {
 template <int KS, int NW, bool SPEC>
 __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void wz_k_conv_rs(const WzConvArgs a) {   // <= 256 registers: two waves per SIMD
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 16384];
+    WZ_LANE_STAMP(a.dbg);
     wz_conv_rs_body<KS, NW, SPEC, false, WzEpiF16>(a, smem, blockIdx.x);
 }
 
@@ -799,6 +806,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256, 2) void wz_k_conv_rs(const WzConv
 // workgroups share a CU and cover each other's stalls, and the kernel boundaries between them go away
 // (measured for the two big heads: 32 us together against 23 + 26 us apart).
 __global__ __launch_bounds__(256, 2) void wz_k_conv_rs_group(const WzConvGroup g) {
+    WZ_LANE_STAMP(g.stamp);
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 16384];
     int e = 0;
     while (e + 1 < g.n && (int)blockIdx.x >= g.first[e + 1]) ++e;   // wave-uniform

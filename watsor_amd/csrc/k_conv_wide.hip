@@ -359,6 +359,7 @@ __device__ __forceinline__ void wz_conv_wide_body(const WzConvArgs& a, unsigned 
 }
 
 __global__ __launch_bounds__(256, 1) void wz_k_conv_wide_group(const WzConvGroup g) {
+    WZ_LANE_STAMP(g.stamp);
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 16384 + WZ_WIDE_TM * 8];   // two activation tiles + the pixel table
     int e = 0;
     while (e + 1 < g.n && (int)blockIdx.x >= g.first[e + 1]) ++e;   // wave-uniform

@@ -41,7 +41,8 @@ __global__ __launch_bounds__(256) void wz_k_mbconv(const WzMbArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
     // diagnostics (a.dbg != nullptr only under wz_debug_mbconv): phase timestamps of the first and the last workgroup
-    const bool stamp = a.dbg && threadIdx.x == 0 && blockIdx.y == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1);
+    const bool stamp = !WZ_LANE_STAMPS && a.dbg && threadIdx.x == 0 && blockIdx.y == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1);
+    WZ_LANE_STAMP(a.dbg);
     unsigned long long* const dbg = a.dbg + (blockIdx.x == 0 ? 0 : 8);
 #define MB_STAMP(i) do { if (stamp) dbg[i] = wall_clock64(); } while (0)
     MB_STAMP(0);

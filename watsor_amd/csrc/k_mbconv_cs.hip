@@ -21,6 +21,7 @@
 template <bool EXPAND, int MPW, int MQW, int KCI, int NTO, int CS_WAVES = 8>
 __global__ __launch_bounds__(CS_WAVES * 64) void wz_k_mbconv_cs(const WzMbArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wz_cs_smem[];
+    WZ_LANE_STAMP(a.dbg);
     constexpr int CE = 32, ES = CE + 8;
     constexpr int EBYTES = EXPAND ? MPW * 16 * ES * 2 : 0;
     constexpr int NTC = NTO > 10 ? 10 : NTO;                        // output tiles reduced per round

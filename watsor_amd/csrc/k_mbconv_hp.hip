@@ -175,6 +175,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
     static_assert(!LEAN || (CS && SH && !ONEPASS && !STEM && MQW == 1), "lean: chunk-split, shared halo, 4 x 4 tiles");
     static_assert(!CG || (LEAN && OCC == 2), "channel groups over workgroups: the lean builds of the 10x10 maps");
     extern __shared__ __attribute__((aligned(16))) unsigned char wz_hp_smem[];
+    WZ_LANE_STAMP(a.dbg);
     const long long t_entry = WZ_HP_STAMPS ? __builtin_readcyclecounter() : 0;
     constexpr bool LDSW = CS || OCC > 2;                 // depthwise weights staged in LDS (else: registers, from L2)
     constexpr bool PRE = OCC <= 2;                       // all taps of an output requested before the first is used

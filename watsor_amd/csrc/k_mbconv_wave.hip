@@ -26,6 +26,7 @@
 template <int MPW, int MQW, int KCI, int NTO, int NKK, bool STEM>
 __global__ __launch_bounds__(256, 4) void wz_k_mbconv_wave(const WzMbArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wz_mbw_smem[];
+    WZ_LANE_STAMP(a.dbg);
     constexpr int CE = 32 * NKK, ES = CE + 8;   // NKK 32-channel K chunks of the project conv per pass
     constexpr int EBYTES = MPW * 16 * ES * 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -914,6 +914,37 @@ __global__ __launch_bounds__(NMS_THREADS) void wz_k_nms(WzPostBuffers b, WzPostC
     const int A = k.num_anchors;
 #define NMS_STAMP(i) do { if (tid == 0) b.dbg[(size_t)f * 16 + (i)] = wall_clock64(); } while (0)
     NMS_STAMP(0);
+#if WZ_LANE_STAMPS
+    // lane stamps (wz_common.h): every kernel in front of this one has finished -- frame 0's workgroup hands their entry / exit pairs
+    // to the page-locked block the host reads and resets them for the lane's next batch; this kernel's own pairs (one per frame)
+    // go straight to that block
+    if (b.stamps_host) {
+        if (tid == 0) b.stamps_host[2 * (b.stamps_n + f)] = wall_clock64();
+        if (f == 0) {   // a wavefront per launch: earliest of the 64 entry words, latest of the 256 exit buckets
+            const int sw = tid >> 6, sl = tid & 63;
+            for (int q = sw; q < b.stamps_n; q += NMS_THREADS / 64) {
+                unsigned long long* src = q == 0 ? b.stamps_pre : b.stamps + (size_t)(q - 1) * WZ_STAMP_WORDS;
+                unsigned long long t0 = src[WZ_STAMP_ENTRY + sl], t1 = 0ull;
+                src[WZ_STAMP_ENTRY + sl] = ~0ull;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned long long v = src[WZ_STAMP_EXIT + sl + 64 * j];
+                    t1 = v > t1 ? v : t1;
+                    src[WZ_STAMP_EXIT + sl + 64 * j] = 0ull;
+                }
+                for (int off = 32; off; off >>= 1) {
+                    const unsigned long long o0 = __shfl_xor(t0, off), o1 = __shfl_xor(t1, off);
+                    t0 = o0 < t0 ? o0 : t0;
+                    t1 = o1 > t1 ? o1 : t1;
+                }
+                if (sl == 0) {
+                    b.stamps_host[2 * q] = t0;
+                    b.stamps_host[2 * q + 1] = t1;
+                }
+            }
+        }
+    }
+#endif
     uint32_t processed = 0;
     int kept = 0;
     if (tid == 0) S->kept = 0;
@@ -1113,6 +1144,9 @@ __global__ __launch_bounds__(NMS_THREADS) void wz_k_nms(WzPostBuffers b, WzPostC
     }
     NMS_STAMP(4);
     if (tid == 0) b.dbg[(size_t)f * 16 + 10] = processed;
+#if WZ_LANE_STAMPS
+    if (b.stamps_host && tid == 0) b.stamps_host[2 * (b.stamps_n + f) + 1] = wall_clock64();
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1272,7 +1306,7 @@ void wz_launch_nms(const WzPostBuffers& b, const WzPostConsts& c, int n, hipStre
     const int ls = (self_scan && listed) ? 1 : 0;
     const bool count = c.max_per_class < c.max_total;   // the per-class cap can bind: one thread per class walks its chain (wz_nms_band)
 #define WZ_NMS_GO(SELF, CLIP, COUNT) \
-    hipLaunchKernelGGL((wz_k_nms<SELF, CLIP, COUNT>), dim3(n), dim3(NMS_THREADS), sizeof(NmsShared), s, b, c, d_frames, d_cams, rows, pass, SELF ? 1 : 0, SELF ? ls : 0, status)
+    WZ_LAUNCH((wz_k_nms<SELF, CLIP, COUNT>), dim3(n), dim3(NMS_THREADS), sizeof(NmsShared), s, b, c, d_frames, d_cams, rows, pass, SELF ? 1 : 0, SELF ? ls : 0, status)
     if (self_scan) {
         if (!c.clip_after) { if (!count) WZ_NMS_GO(true, false, false); else WZ_NMS_GO(true, false, true); }
         else { if (!count) WZ_NMS_GO(true, true, false); else WZ_NMS_GO(true, true, true); }

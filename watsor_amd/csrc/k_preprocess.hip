@@ -98,6 +98,7 @@ __device__ __forceinline__ void wz_fetch_row_pair(const WzFrameDesc& f, int x_lo
 template <bool HP>
 __global__ __launch_bounds__(256) void wz_k_preprocess(const WzFrameDesc* __restrict__ frames, const WzDescPack pack, int size,
                                                        half_t* __restrict__ out, WzFrameDesc* __restrict__ keep, int flags) {
+    WZ_LANE_STAMP(keep ? reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(keep) - WZ_STAMP_PRE_BYTES) : nullptr);
     const int half_pixel = flags & 1;   // (bits 8 ..: the row-staged kernel's LDS budget, unused here; one argument list for both kernels)
     const WzFrameDesc f = frames ? frames[blockIdx.y] : pack.d[blockIdx.y];
     if (keep && blockIdx.x == 0 && threadIdx.x == 0) keep[blockIdx.y] = f;
@@ -196,6 +197,7 @@ template <bool HP>
 __global__ __launch_bounds__(WZ_PRE_ROWS_THREADS) void wz_k_preprocess_rows(const WzFrameDesc* __restrict__ frames, const WzDescPack pack,
                                                                             int size, half_t* __restrict__ out,
                                                                             WzFrameDesc* __restrict__ keep, int flags) {
+    WZ_LANE_STAMP(keep ? reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(keep) - WZ_STAMP_PRE_BYTES) : nullptr);
     extern __shared__ __attribute__((aligned(16))) uint8_t wz_pre_lds[];
     typedef unsigned int wz_u32x4 __attribute__((ext_vector_type(4)));   // (an array of HIP's uint4 structs is kept in scratch memory)
     const int half_pixel = flags & 1;

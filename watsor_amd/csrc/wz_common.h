@@ -165,7 +165,52 @@ static inline const char* wz_dev_getenv(const char* name) {
 // profiles/r03_wave_counts_and_cu_footprints.txt).  Defined in wz_engine.hip.
 bool wz_latency_schedule();
 
+// ---- lane stamps (`make stamps`: -DWZ_DEV_BUILD -DWZ_LANE_STAMPS=1 -> libwatsor_hip_stamps.so; tools/lane_overlap.py) -----------------
+// What rocprofv3 cannot show on this stack: which kernels of DIFFERENT lanes are on the chip at the same time (under its kernel trace the
+// four lanes serialise, concurrency 1.18; unprofiled the headline needs > 2).  In this build every kernel of a batch stamps the constant
+// 100 MHz clock (s_memrealtime: one clock for all XCDs) into its launch's block of the lane -- PLAIN stores, no atomics (a first version
+// with one device-scope atomic min / max per workgroup on one address cost 21 % of the throughput: 2 816 of them per resize launch
+// queue up at the memory side): the first 64 workgroups each store their entry time into a word of their own ([16 + id]); every
+// workgroup stores its exit time into bucket [80 + id % 256] -- workgroups are dealt round-robin over the 8 XCDs, so all writers of a
+// bucket share one L2 and the last one to leave is the value that stays.  The chain's last kernel (wz_k_nms) reduces a launch's words to
+// (earliest entry, latest exit), hands the pairs to the lane's page-locked stamp block and resets the words; the host reads that
+// block after wz_wait().  Nothing of this exists in the product or the development library.
+#ifndef WZ_LANE_STAMPS
+#define WZ_LANE_STAMPS 0
+#endif
+#define WZ_STAMP_SLOTS 128            // launches of a batch that can be stamped (the robust program has 30, the per-layer one ~75)
+#define WZ_STAMP_WORDS 384            // 64-bit words per launch block: [0 .. 15] the older per-kernel phase stamps, [16 .. 79] entry times of
+                                      // workgroups 0 .. 63, [80 .. 335] exit-time buckets (workgroup id mod 256)
+#define WZ_STAMP_ENTRY 16
+#define WZ_STAMP_EXIT 80
+#define WZ_STAMP_PRE_BYTES (WZ_STAMP_WORDS * 8)   // the resize kernel's block lies this far in front of the descriptors it leaves behind (`keep`)
+struct WzLaunchNote { const void* func; unsigned grid[3], block[3]; unsigned lds; };
+#if WZ_LANE_STAMPS
+void wz_note_launch(const void* func, dim3 grid, dim3 block, size_t lds);
+#define WZ_LAUNCH(kern, grid, block, lds, s, ...) do { wz_note_launch(reinterpret_cast<const void*>(kern), grid, block, lds); \
+        for (int _wz_r = 0; _wz_r < wz_launch_repeat; ++_wz_r) hipLaunchKernelGGL(kern, grid, block, lds, s, __VA_ARGS__); } while (0)
+#ifdef __HIPCC__
+struct WzLaneStamp {
+    unsigned long long* p;
+    __device__ __forceinline__ explicit WzLaneStamp(unsigned long long* q) : p(q) {
+        if (p && threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0) {
+            const unsigned id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+            if (id < 64u) p[WZ_STAMP_ENTRY + id] = (unsigned long long)wall_clock64();   // (the first workgroups dispatched hold the earliest entry)
+        }
+    }
+    __device__ __forceinline__ ~WzLaneStamp() {
+        if (p && threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0) {
+            const unsigned id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+            p[WZ_STAMP_EXIT + (id & 255u)] = (unsigned long long)wall_clock64();
+        }
+    }
+};
+#define WZ_LANE_STAMP(ptr) WzLaneStamp _wz_lane_stamp(const_cast<unsigned long long*>(ptr))
+#endif
+#else
 #define WZ_LAUNCH(...) do { for (int _wz_r = 0; _wz_r < wz_launch_repeat; ++_wz_r) hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+#define WZ_LANE_STAMP(ptr) do { } while (0)
+#endif
 // hp: the input tensor is a hi + lo pair (8 halves per pixel: r g b 0 | r g b 0)
 #define WZ_DESC_PACK 16
 struct WzDescPack { WzFrameDesc d[WZ_DESC_PACK]; };   // frame descriptors as kernel arguments (512 bytes)
@@ -196,6 +241,7 @@ struct WzReduceGroup {
     // list != 0: class logits at or above the frame's hint_logit get their bit set in cbits[f] -- the first band of
     // wz_k_nms then needs no scan of the logits at all
     int32_t list, cbits_words;
+    unsigned long long* stamp;   // WZ_LANE_STAMPS builds: this launch's block of the lane's stamps, else nullptr
     const float* hint_logit;
     uint32_t* cbits;
     WzPostConsts pc;
@@ -214,6 +260,7 @@ struct WzConvGroup {
     WzConvArgs a[WZ_CONV_GROUP_MAX];
     int32_t* tickets;           // host side only: the lane's counter block and how much of it the entries added so far use
     int32_t ticket_off;
+    unsigned long long* stamp;  // WZ_LANE_STAMPS builds: this launch's block of the lane's stamps, else nullptr
 };
 // split-K across the waves of a workgroup (no partials in HBM, no reduce launch): the extras chain
 bool wz_conv_ws_applies(const WzConvArgs& a);
@@ -283,6 +330,13 @@ struct WzPostBuffers {
     int32_t* det_classes;     // [n][100] 1-based
     int32_t* det_num;         // [n]
     unsigned long long* dbg;  // [n][16] phase timestamps of wz_k_nms (wall_clock64, 100 MHz), diagnostics only
+    // WZ_LANE_STAMPS builds (else all null / 0): the lane's launch blocks, the resize kernel's block, the page-locked copy the host reads
+    // (pairs: [2k] entry, [2k + 1] exit of launch k; launch 0 = the resize kernel; wz_k_nms's own pairs follow, one per frame) and
+    // how many launches of this batch were stamped
+    unsigned long long* stamps;
+    unsigned long long* stamps_pre;
+    unsigned long long* stamps_host;
+    int32_t stamps_n, _stamps_pad;
 };
 void wz_launch_decode(const WzPostBuffers& b, const WzPostConsts& c, int n, hipStream_t s);
 void wz_launch_hist(const WzPostBuffers& b, const WzPostConsts& c, int n, hipStream_t s);

@@ -155,6 +155,15 @@ struct wz_engine {
         std::map<int, hipGraph_t> graph_src;     // the captured graph itself, kept where one of its node handles is
         std::map<int, hipGraphNode_t> pre_nodes; // ... and the resize kernel's node in that graph (its arguments carry the frame
                                                  // descriptors and are rewritten before every replay), if it takes them by value
+        // WZ_LANE_STAMPS builds (wz_common.h): the lane's launch blocks [WZ_STAMP_SLOTS][WZ_STAMP_WORDS], the resize kernel's block and the
+        // descriptors behind it in ONE allocation; the page-locked pairs the host reads; launches stamped so far in the batch being enqueued
+        unsigned char* d_stamp_raw = nullptr;
+        unsigned long long* d_stamps = nullptr;
+        unsigned long long* d_stamps_pre = nullptr;
+        unsigned long long* h_stamps = nullptr;
+        unsigned long long* m_stamps = nullptr;
+        int stamp_next = 1;
+        std::map<int, std::vector<WzLaunchNote>> launch_notes;   // graph key -> what was launched, in order (grid, block, LDS, kernel)
         WzDescPack pack;                         // storage behind that node's kernelParams
         const WzFrameDesc* pre_frames = nullptr;
         int pre_size = 0, pre_half_pixel = 0;
@@ -186,6 +195,23 @@ struct wz_engine {
 };
 
 static int input_tensor_index(wz_engine* e) { return e->ops[0].src; }
+
+// lane stamps: the block of the next launch of the batch being enqueued (nullptr in every build but `make stamps`)
+#if WZ_LANE_STAMPS
+static thread_local std::vector<WzLaunchNote>* g_launch_sink = nullptr;
+void wz_note_launch(const void* func, dim3 grid, dim3 block, size_t lds) {
+    if (g_launch_sink) g_launch_sink->push_back({func, {grid.x, grid.y, grid.z}, {block.x, block.y, block.z}, (unsigned)lds});
+}
+static unsigned long long* next_stamp(wz_engine::Lane& L) {
+    if (!L.d_stamps || L.stamp_next > WZ_STAMP_SLOTS) return nullptr;
+    return L.d_stamps + (size_t)(L.stamp_next++ - 1) * WZ_STAMP_WORDS;
+}
+#define WZ_STAMP_ARG(a) ((a).dbg = next_stamp(L))
+#define WZ_STAMP_GROUP(g) ((g).stamp = next_stamp(L))
+#else
+#define WZ_STAMP_ARG(a) ((void)0)
+#define WZ_STAMP_GROUP(g) ((void)0)
+#endif
 static bool tensor_is_pair(wz_engine* e, int idx) { return (e->tensors[idx].flags & WZ_TENSOR_HP) != 0; }
 static bool input_is_pair(wz_engine* e) { return tensor_is_pair(e, input_tensor_index(e)); }
 // bytes of one frame of tensor idx (pair tensors hold two halves per value; the input tensor is fp16 in both engines)
@@ -312,6 +338,7 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
             a.ws_bytes = ws_top;
             a.tickets = e->use_splitk ? L.d_tickets : nullptr;   // (channel groups over workgroups of the 10x10 split blocks: k_mbconv_hp.hip)
             a.dbg = e->d_mbdbg ? e->d_mbdbg + (size_t)i * 16 : nullptr;
+            WZ_STAMP_ARG(a);
             int groups = a.hp ? wz_launch_mbconv_hp(a, n, s, false)   // split-operand blocks (the `-p 16` program's first 13)
                               : wz_launch_mbconv_wave(a, n, s, false);   // large maps: one wavefront per pixel tile
             if (a.hp && groups < 0) L.launch_failed = (int)i + 1;   // nothing was enqueued for a split-operand block: run_batch reports it
@@ -326,6 +353,7 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
                 r.bias = a.bp; r.res = a.res; r.out = a.out;
                 r.M = a.M; r.hout = op.hout; r.wout = op.wout; r.cout = op.cout; r.n_pad = op.n_pad;
                 r.act = WZ_ACT_NONE; r.out_mode = WZ_OUT_ACT; r.splitk = groups;
+                WZ_STAMP_ARG(r);
                 wz_launch_splitk_reduce(r, L.d_ws, s);
             }
         } else {
@@ -478,6 +506,7 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
                     for (int k = 0; k < added; ++k) big_head[big.n - 1 - k] = heads.n;   // the heads on the tile kernel: one launch, too
                     ++heads_in_groups;
                 } else {
+                    WZ_STAMP_ARG(a);
                     wz_launch_conv(a, s);
                 }
                 if (t) { t->mark(); t->mark(); }   // its own reduce slot stays empty
@@ -491,6 +520,7 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
                 // (on the 2x2 and 1x1 maps also where one wave per tile would walk all of K alone)
                 a.splitk = 1;
                 a.out = final_out;
+                WZ_STAMP_ARG(a);
                 wz_launch_conv_ws(a, s);
                 if (t) { t->mark(); t->mark(); }
                 continue;
@@ -499,12 +529,15 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
             a.splitk = sk;
             if (sk > 1) {
                 a.out = L.d_ws;
+                WZ_STAMP_ARG(a);
                 wz_launch_conv(a, s);
                 if (t) t->mark();
                 a.out = final_out;
+                WZ_STAMP_ARG(a);
                 wz_launch_splitk_reduce(a, L.d_ws, s);
             } else {
                 a.out = final_out;
+                WZ_STAMP_ARG(a);
                 wz_launch_conv(a, s);
                 if (t) t->mark();
             }
@@ -530,10 +563,11 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
             a.fin = L.d_fin;
         }
     }
-    if (wide.n > 0) wz_launch_conv_wide_group(wide, s);
-    if (big.n > 0) wz_launch_conv_rs_group(big, s);
+    wide.stamp = big.stamp = small.stamp = heads.stamp = nullptr;   // (set per launch in the stamps build only)
+    if (wide.n > 0) { WZ_STAMP_GROUP(wide); wz_launch_conv_wide_group(wide, s); }
+    if (big.n > 0) { WZ_STAMP_GROUP(big); wz_launch_conv_rs_group(big, s); }
     if (t) t->mark();
-    if (small.n > 0) wz_launch_conv_group(small, s);
+    if (small.n > 0) { WZ_STAMP_GROUP(small); wz_launch_conv_group(small, s); }
     if (t) t->mark();
     if (L.decode_fused) {
         heads.decode = 1;
@@ -552,7 +586,7 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
         heads.cbits = L.post.cbits;
         heads.cbits_words = (e->pc.num_anchors * e->pc.num_classes + 31) >> 5;
     }
-    if (heads.n > 0 && !inline_heads) wz_launch_splitk_reduce_group(heads, s);
+    if (heads.n > 0 && !inline_heads) { WZ_STAMP_GROUP(heads); wz_launch_splitk_reduce_group(heads, s); }
     if (t) t->mark();
 }
 
@@ -568,6 +602,10 @@ static void enqueue_post(wz_engine* e, Lane& L, bool rows, int n, StageTimer* t,
     if (t) t->mark();
     // with `rows` the NMS kernel also fills the Detection rows (straight into the lane's pinned, device-mapped host
     // block: no D2H copy node, no separate row kernel); the "post/rows" stage slot stays empty
+#if WZ_LANE_STAMPS
+    L.post.stamps_n = rows && L.m_stamps ? L.stamp_next : 0;   // launches stamped in front of the NMS kernel (launch 0 = the resize kernel)
+    L.post.stamps_host = rows && L.post.stamps_n ? L.m_stamps : nullptr;
+#endif
     if (rows)
         wz_launch_nms(L.post, e->pc, n, s, L.d_desc, e->d_cams, L.m_rows, L.m_pass, e->post_self, listed, L.m_status);
     else
@@ -590,6 +628,7 @@ static void enqueue_batch(wz_engine* e, Lane& L, int n, StageTimer* t, int inner
     if (!by_value && !zero_copy) (void)hipMemcpyAsync(L.d_desc, L.h_desc, sizeof(WzFrameDesc) * n, hipMemcpyHostToDevice, s);
     if (t) t->mark();
     wz_launch_repeat = inner;
+    L.stamp_next = 1;   // (lane stamps: launch 0 is the resize kernel, whose block lies in front of the descriptors it leaves behind)
     wz_launch_preprocess(zero_copy ? L.h_desc_dev : L.d_desc, n, (int)e->hdr.input_size, L.tptr[input_tensor_index(e)], s,
                          input_is_pair(e), (zero_copy || by_value) ? L.d_desc : nullptr, e->hdr.resize_mode == 1,
                          by_value ? L.h_desc : nullptr, L.rows ? e->pre_rows_lds : 0);
@@ -613,7 +652,14 @@ static int run_batch(wz_engine* e, int slot, int n) {
         if (it == L.graphs.end()) {
             hipGraph_t g = nullptr;
             HIPCHK(hipStreamBeginCapture(L.stream, hipStreamCaptureModeThreadLocal));
+#if WZ_LANE_STAMPS
+            L.launch_notes[key].clear();
+            g_launch_sink = &L.launch_notes[key];
+#endif
             enqueue_batch(e, L, n, nullptr);
+#if WZ_LANE_STAMPS
+            g_launch_sink = nullptr;
+#endif
             HIPCHK(hipStreamEndCapture(L.stream, &g));
             if (L.launch_failed) {
                 (void)hipGraphDestroy(g);
@@ -1034,7 +1080,30 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
             (void)hipGetLastError();
             L.h_desc_dev = nullptr;
         }
+#if WZ_LANE_STAMPS
+        {   // [launch blocks][the resize kernel's block][descriptors]: every pair starts as (entry = max, exit = 0)
+            const size_t blocks = (size_t)WZ_STAMP_SLOTS * WZ_STAMP_WORDS * 8;
+            CK(hipMalloc((void**)&L.d_stamp_raw, blocks + WZ_STAMP_PRE_BYTES + sizeof(WzFrameDesc) * max_batch));
+            L.d_stamps = reinterpret_cast<unsigned long long*>(L.d_stamp_raw);
+            L.d_stamps_pre = reinterpret_cast<unsigned long long*>(L.d_stamp_raw + blocks);
+            L.d_desc = reinterpret_cast<WzFrameDesc*>(L.d_stamp_raw + blocks + WZ_STAMP_PRE_BYTES);
+            std::vector<unsigned long long> init((blocks + WZ_STAMP_PRE_BYTES) / 8, 0ull);
+            for (size_t k = 0; k < init.size(); k += WZ_STAMP_WORDS)
+                for (int j = 0; j < 64; ++j) init[k + WZ_STAMP_ENTRY + j] = ~0ull;
+            CK(hipMemcpy(L.d_stamp_raw, init.data(), init.size() * 8, hipMemcpyHostToDevice));
+            const size_t host_pairs = (size_t)(WZ_STAMP_SLOTS + 1 + max_batch) * 2 * 8;
+            CK(hipHostMalloc((void**)&L.h_stamps, host_pairs, hipHostMallocMapped));
+            memset(L.h_stamps, 0, host_pairs);
+            CK(hipHostGetDevicePointer((void**)&L.m_stamps, L.h_stamps, 0));
+        }
+#else
         CK(hipMalloc((void**)&L.d_desc, sizeof(WzFrameDesc) * max_batch));
+#endif
+        pb.stamps = L.d_stamps;
+        pb.stamps_pre = L.d_stamps_pre;
+        pb.stamps_host = nullptr;
+        pb.stamps_n = 0;
+        pb._stamps_pad = 0;
         CK(hipMalloc((void**)&L.d_rows, sizeof(wz_detection_t) * WZ_MAX_DETECTIONS * max_batch));
         CK(hipMalloc((void**)&L.d_pass, (size_t)WZ_MAX_DETECTIONS * max_batch));
         CK(hipHostMalloc((void**)&L.h_rows, sizeof(wz_detection_t) * WZ_MAX_DETECTIONS * max_batch, hipHostMallocMapped));
@@ -1099,14 +1168,15 @@ extern "C" void wz_destroy(wz_engine_t* e) {
         for (auto& kv : L.graph_src) (void)hipGraphDestroy(kv.second);
         for (void* p : L.bufs) (void)hipFree(p);
         void* lp[] = {L.d_frames, L.d_box_enc, L.d_logits, L.d_ws, L.d_tickets, L.d_fin, L.post.boxes, L.post.valid, L.d_post_scratch, L.post.cand,
-                      L.post.det_boxes, L.post.det_scores, L.post.det_classes, L.post.det_num, L.post.dbg, L.d_desc, L.d_rows,
-                      L.d_pass};
+                      L.post.det_boxes, L.post.det_scores, L.post.det_classes, L.post.det_num, L.post.dbg,
+                      L.d_stamp_raw ? (void*)L.d_stamp_raw : (void*)L.d_desc, L.d_rows, L.d_pass};
         for (void* p : lp)
             if (p) (void)hipFree(p);
         if (L.h_desc) (void)hipHostFree(L.h_desc);
         if (L.h_rows) (void)hipHostFree(L.h_rows);
         if (L.h_pass) (void)hipHostFree(L.h_pass);
         if (L.h_status) (void)hipHostFree(L.h_status);
+        if (L.h_stamps) (void)hipHostFree(L.h_stamps);
         if (L.done) (void)hipEventDestroy(L.done);
         if (L.stream && L.owns_stream) (void)hipStreamDestroy(L.stream);
     }
@@ -1566,6 +1636,56 @@ extern "C" int wz_debug_mbconv(wz_engine_t* e, uint64_t* out, int32_t* groups) {
     HIPCHK(hipMemcpy(out, e->d_mbdbg, (size_t)e->hdr.n_ops * 16 * 8, hipMemcpyDeviceToHost));
     if (groups) memcpy(groups, e->mb_groups.data(), sizeof(int) * e->hdr.n_ops);
     return WZ_OK;
+}
+
+// ---- lane stamps (`make stamps`; tools/lane_overlap.py): entry / exit of every launch of the batch last run on `slot`, 100 MHz ticks
+extern "C" int wz_debug_lane_stamps(wz_engine_t* e, int slot, uint64_t* out, int cap) {
+#if WZ_LANE_STAMPS
+    if (!e || !out || slot < 0 || slot >= e->n_lanes) return wz_fail(WZ_EINVAL, "wz_debug_lane_stamps: bad argument");
+    const Lane& L = e->lanes[slot];
+    const int k = L.post.stamps_n;          // launches in front of the NMS kernel; its own pairs (one per frame) follow and are folded here
+    if (!L.h_stamps || k <= 0 || cap < k + 1) return wz_fail(WZ_EINVAL, "wz_debug_lane_stamps: no stamped batch on lane %d (or cap %d < %d)", slot, cap, k + 1);
+    for (int i = 0; i < 2 * k; ++i) out[i] = L.h_stamps[i];
+    uint64_t t0 = ~0ull, t1 = 0;
+    for (int f = 0; f < L.n; ++f) {
+        t0 = std::min<uint64_t>(t0, L.h_stamps[2 * (k + f)]);
+        t1 = std::max<uint64_t>(t1, L.h_stamps[2 * (k + f) + 1]);
+    }
+    out[2 * k] = t0;
+    out[2 * k + 1] = t1;
+    return k + 1;
+#else
+    (void)e; (void)slot; (void)out; (void)cap;
+    return wz_fail(WZ_EINVAL, "wz_debug_lane_stamps: this library was not built with -DWZ_LANE_STAMPS=1 (`make stamps`)");
+#endif
+}
+// launch `idx` of that batch: kernel name, dims = {workgroups, threads per workgroup, LDS bytes (static + dynamic), workgroups a CU holds}
+extern "C" int wz_debug_lane_launch(wz_engine_t* e, int slot, int idx, char* name, int namelen, int* dims) {
+#if WZ_LANE_STAMPS
+    if (!e || slot < 0 || slot >= e->n_lanes || !dims) return wz_fail(WZ_EINVAL, "wz_debug_lane_launch: bad argument");
+    Lane& L = e->lanes[slot];
+    auto it = L.launch_notes.find(L.key);
+    if (it == L.launch_notes.end() || idx < 0 || idx >= (int)it->second.size()) return wz_fail(WZ_EINVAL, "wz_debug_lane_launch: no launch %d", idx);
+    const WzLaunchNote& ln = it->second[idx];
+    HIPCHK(hipSetDevice(e->device));
+    const char* nm = hipKernelNameRefByPtr(ln.func, L.stream);
+    if (name && namelen > 0) snprintf(name, namelen, "%s", nm ? nm : "?");
+    hipFuncAttributes fa;
+    memset(&fa, 0, sizeof(fa));
+    (void)hipFuncGetAttributes(&fa, ln.func);
+    const int threads = (int)(ln.block[0] * ln.block[1] * ln.block[2]);
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ln.func, threads, ln.lds) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
+    dims[0] = (int)(ln.grid[0] * ln.grid[1] * ln.grid[2]);
+    dims[1] = threads;
+    dims[2] = (int)fa.sharedSizeBytes + (int)ln.lds;
+    dims[3] = per_cu;
+    dims[4] = fa.numRegs;
+    return (int)it->second.size();
+#else
+    (void)e; (void)slot; (void)idx; (void)name; (void)namelen; (void)dims;
+    return wz_fail(WZ_EINVAL, "wz_debug_lane_launch: this library was not built with -DWZ_LANE_STAMPS=1 (`make stamps`)");
+#endif
 }
 
 extern "C" int wz_num_stages(wz_engine_t* e) { return e ? (int)e->stage_names.size() : 0; }
