@@ -172,8 +172,9 @@ __device__ __forceinline__ void wz_hp_fma8(wz_f32x2_t d[4], const wz_f32x2_t x[4
 template <int NW, bool CS, bool STEM, int MPW, int MQW, int KCI, int NTO, int OCC = 2, bool ONEPASS = false, bool SH = false,
           bool QE = false, bool LEAN = false, bool CG = false>
 __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a) {
-    static_assert(!LEAN || (CS && SH && !ONEPASS && !STEM && MQW == 1), "lean: chunk-split, shared halo, 4 x 4 tiles");
-    static_assert(!CG || (LEAN && OCC == 2), "channel groups over workgroups: the lean builds of the 10x10 maps");
+    static_assert(!LEAN || (CS && SH && !ONEPASS && !STEM), "lean: chunk-split, shared halo");
+    static_assert(!LEAN || MQW == 1 || (OCC <= 2 && MPW == 4), "lean 4 x 8 tiles: the stride-1 10x10 blocks at one or two waves per SIMD");
+    static_assert(!CG || (LEAN && OCC <= 2), "channel groups over workgroups: the lean builds of the 10x10 maps");
     extern __shared__ __attribute__((aligned(16))) unsigned char wz_hp_smem[];
     WZ_LANE_STAMP(a.dbg);
     const long long t_entry = WZ_HP_STAMPS ? __builtin_readcyclecounter() : 0;
@@ -181,8 +182,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
     constexpr bool PRE = OCC <= 2;                       // all taps of an output requested before the first is used
     constexpr int ES = 40;                               // unorm16 per row of the chunk buffer: 32 channels + 8 of padding
     constexpr int EBYTES = MPW * 16 * ES * 2;
-    constexpr int RROUNDS = (LEAN && OCC >= 4 && NTO % 2 == 0 && NTO >= 6) ? 2 : 1;   // rounds of the accumulators' trip through LDS
-    constexpr int RED_BYTES = CS ? NW * MQW * (NTO / RROUNDS) * 1024 : 0;
+    // rounds of the accumulators' trip through LDS (the lean 4 x 8 builds hold 2 x 10 fragments per wave: four rounds of five)
+    constexpr int RROUNDS = (LEAN && MQW == 2) ? (NW >= 8 ? 4 : 5) : (LEAN && OCC >= 4 && NTO % 2 == 0 && NTO >= 6) ? 2 : 1;
+    constexpr int RED_BYTES = CS ? NW * (MQW * NTO / RROUNDS) * 1024 : 0;
     constexpr int REGION = (NW * EBYTES > RED_BYTES) ? NW * EBYTES : RED_BYTES;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, g = lane >> 4;
@@ -346,12 +348,12 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
             }
         }
     };
-    constexpr bool WA_AHEAD = !((LEAN || !CS) && OCC >= 4);   // the next pass's expand fragments requested a stage ahead (4 waves per SIMD: at the
+    constexpr bool WA_AHEAD = !((LEAN || !CS) && OCC >= 4) && !(LEAN && MQW == 2 && OCC == 2);   // the next pass's expand fragments requested a stage ahead (4 waves per SIMD: at the
                                                      // top of the pass instead -- the other waves cover the wait, the registers are not there)
     if (!SH && WA_AHEAD && ps0 < c_hi) load_wa(ps0);
     {   // biases (and, LDSW, depthwise weights) into LDS: every load of a thread in flight before its first store
         constexpr int NT = NW * 64;
-        constexpr int WD_IT = LEAN ? 5 : NW >= 8 ? 3 : 8;   // 9 * cmid_pad / 4 float4s over NT threads: at most this many each (checked by the launcher)
+        constexpr int WD_IT = LEAN ? (NW >= 8 ? 5 : 9) : NW >= 8 ? 3 : 8;   // 9 * cmid_pad / 4 float4s over NT threads: at most this many each (checked by the launcher)
         const int nb4 = a.cmid_pad >> 2;
         float4_t sw[WD_IT], sb, se;
         if constexpr (LDSW) {
@@ -407,7 +409,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
                 wpl[nt] = *reinterpret_cast<const half8_t*>(a.wp_lo + off);
             }
         };
-        constexpr bool WP_LATE = (OCC > 2 && CS) || LEAN || OCC >= 4;   // 3 waves per SIMD: the project fragments are requested behind the expand stage
+        constexpr bool WP_LATE = (OCC > 2 && CS) || (LEAN && OCC >= 2) || OCC >= 4;   // 3 waves per SIMD: the project fragments are requested behind the expand stage
         if constexpr (!WP_LATE) load_wp();        // (they have the depthwise stage to land) instead of holding 8 x NTO registers through it
         if constexpr (!WA_AHEAD) load_wa(ps);
         float4_t wt0[9], wt1[9];   // (LDSW: unused, the weights are read from LDS where they are needed)
@@ -550,7 +552,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
             // rows hp0 .. hp0 + 3 of the halo serve both outputs: row rr is tap row rr of output 0 and rr - 1 of output 1.
             // All 12 taps are requested before the first one is used: one LDS latency instead of twelve.
             const unsigned short* ep = E + hp0[0] * ES + g * 8;
-            constexpr int RR = PRE ? 4 : WZ_HP_RR3;         // halo rows requested per group (3 waves per SIMD: WZ_HP_RR3)
+            constexpr int RR = (LEAN && OCC >= 2) ? 2 : PRE ? 4 : WZ_HP_RR3;   // halo rows requested per group (3 waves per SIMD: WZ_HP_RR3; the lean 4 x 8 builds hold
+                                                                  // 2 x 10 accumulators and the project fragments in flight: two rows at a time)
 #pragma unroll
             for (int r0 = 0; r0 < 4; r0 += RR) {
                 wz_u32x4_t tq[RR * 3];
@@ -673,6 +676,95 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
                 finish(acc[j][nt], sd[j][nt], opix[j], n4);
             }
         }
+    } else if constexpr (RROUNDS > 1 && MQW > 1) {
+        // lean 4 x 8 builds (the stride-1 10x10 blocks): MQW x NTO = 20 accumulator fragments per wave cross LDS in RROUNDS rounds of NH;
+        // fragment q = j * NTO + nt of a round is summed by wave q - r * NH in the order wave 0 .. NW - 1, as everywhere.  With channel
+        // groups over workgroups (CG) the sums then go through the workspace like the 4 x 4 builds' (below): slabs, ticket, last arriver.
+        constexpr int TF = MQW * NTO, NH = TF / RROUNDS;
+        static_assert(TF % RROUNDS == 0 && NH <= NW, "rounds of the lean 4 x 8 reduction");
+        Side sd[RROUNDS];
+        int sop[RROUNDS], sn4[RROUNDS];
+        const bool fin_wave = wave < NH;
+#pragma unroll
+        for (int r = 0; r < RROUNDS; ++r) {
+            const int q = r * NH + (fin_wave ? wave : 0);
+            const int j = q / NTO, nt = q - j * NTO;
+            int op = -1;
+#pragma unroll
+            for (int jj = 0; jj < MQW; ++jj)
+                if (jj == j) op = opix[jj];
+            const int n4 = (nt0 + nt) * 16 + g * 4;
+            const bool on = fin_wave && op >= 0 && n4 < a.cout;
+            sop[r] = on ? op : -1;
+            sn4[r] = n4;
+            sd[r] = side(on ? op : 0, on ? n4 : 0);
+        }
+        float* const red = reinterpret_cast<float*>(wz_hp_smem);
+        float4_t vs[RROUNDS];
+#pragma unroll
+        for (int r = 0; r < RROUNDS; ++r) {
+            __syncthreads();   // every wave is done with its chunk buffer / with the previous round's partials
+#pragma unroll
+            for (int t = 0; t < NH; ++t)
+                *reinterpret_cast<float4_t*>(red + ((size_t)(wave * NH + t) * 64 + lane) * 4) = acc[(r * NH + t) / NTO][(r * NH + t) % NTO];
+            __syncthreads();
+            vs[r] = (float4_t){0.f, 0.f, 0.f, 0.f};
+            if (fin_wave) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    const float4_t pz = *reinterpret_cast<const float4_t*>(red + ((size_t)(w * NH + wave) * 64 + lane) * 4);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) vs[r][q] += pz[q];
+                }
+            }
+        }
+        if constexpr (CG) {
+            if (cgn > 1) {
+                float* const slab0 = a.ws + (size_t)bidx * cgn * TF * 256;
+                if (fin_wave) {
+#pragma unroll
+                    for (int r = 0; r < RROUNDS; ++r) {
+                        float* const dst = slab0 + ((size_t)cg * TF + r * NH + wave) * 256 + lane * 4;
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(vs[r]) : "memory");
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();                       // every wave's stores have landed
+                int* const flag = reinterpret_cast<int*>(bd_l);   // (the staged biases are dead behind the chunk loop)
+                if (threadIdx.x == 0) {
+                    int32_t* const tk = a.tickets + bidx;
+                    const int tt = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    if (tt == cgn - 1) {
+                        __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                        // this CU reads the slabs fresh
+                    }
+                    *flag = tt;
+                }
+                __syncthreads();
+                if (*flag != cgn - 1) return;
+                if (fin_wave) {
+#pragma unroll
+                    for (int r = 0; r < RROUNDS; ++r) {
+                        float4_t pz[4];
+#pragma unroll
+                        for (int z = 0; z < 4; ++z)
+                            pz[z] = z < cgn ? *reinterpret_cast<const float4_t*>(slab0 + ((size_t)z * TF + r * NH + wave) * 256 + lane * 4)
+                                            : (float4_t){0.f, 0.f, 0.f, 0.f};
+                        float4_t v = pz[0];
+#pragma unroll
+                        for (int z = 1; z < 4; ++z)
+                            if (z < cgn) {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) v[q] += pz[z][q];
+                            }
+                        vs[r] = v;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RROUNDS; ++r)
+            if (fin_wave && sop[r] >= 0) finish(vs[r], sd[r], sop[r], sn4[r]);
     } else if constexpr (RROUNDS > 1) {
         // lean builds at 4 waves per SIMD: the accumulators cross LDS in RROUNDS rounds of NTO / RROUNDS n-tiles, so that the area they
         // need (NW KiB per n-tile) stays under the chunk buffers and two workgroups fit the LDS of a CU; n-tile t of a round is
@@ -767,7 +859,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
                 int* const flag = reinterpret_cast<int*>(bd_l);   // (the staged biases are dead behind the chunk loop)
                 if (threadIdx.x == 0) {
                     int32_t* const tk = a.tickets + bidx;
-                    const int tt = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // (RELEASE: the slabs -- write-through stores that the barrier above saw land -- are ordered in front of the ticket by the
+                    //  memory model as well, not only by `sc1` + vmcnt(0))
+                    const int tt = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                     if (tt == cgn - 1) {
                         __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                        // this CU reads the slabs fresh
@@ -839,10 +933,10 @@ static int wz_hp_launch(WzMbArgs a, int n, hipStream_t s, bool prepare) {
     if (!LEAN && a.n_pad / 16 != NTO) return -1;
     if (LEAN && a.nsplit * NTO != a.n_pad / 16) return -1;
     constexpr int EB = MPW * 16 * 40 * 2;
-    constexpr int RED = CS ? NW * MQW * (NTO / ((LEAN && OCC >= 4 && NTO % 2 == 0 && NTO >= 6) ? 2 : 1)) * 1024 : 0;
+    constexpr int RED = CS ? NW * (MQW * NTO / ((LEAN && MQW == 2) ? (NW >= 8 ? 4 : 5) : (LEAN && OCC >= 4 && NTO % 2 == 0 && NTO >= 6) ? 2 : 1)) * 1024 : 0;
     const size_t region = (size_t)(NW * EB > RED ? NW * EB : RED);
     const size_t lds = region + (size_t)a.cmid_pad * ((CS || OCC > 2) ? 8 + 36 : 8) + (SH ? (size_t)MPW * KCI * 2 * 1024 : 0);
-    if ((a.cmid_pad >> 2) > NW * 64 || 9 * (a.cmid_pad >> 2) > (LEAN ? 5 : NW >= 8 ? 3 : 8) * NW * 64) return -1;   // the staging code's fixed trip counts
+    if ((a.cmid_pad >> 2) > NW * 64 || 9 * (a.cmid_pad >> 2) > (LEAN ? (NW >= 8 ? 5 : 9) : NW >= 8 ? 3 : 8) * NW * 64) return -1;   // the staging code's fixed trip counts
     auto k = wz_k_mbconv_hp<NW, CS, STEM, MPW, MQW, KCI, NTO, OCC, ONEPASS, SH, QE, LEAN, CG>;
     if (prepare) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -941,10 +1035,16 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
         // batch 8 runs as before.  profiles/r04_channel_groups.txt.  WZ_HP_CGROUPS=1: never; 2 .. 4: at most that many.
         static const int cg_env = wz_hp_env("WZ_HP_CGROUPS", 0);
         static const int cg_cap = wz_hp_env("WZ_HP_CG_CAP", wz_latency_schedule() ? 256 : 128);   // workgroups such a launch may have
-        const int units = ((a.hout + 3) / 4) * ((a.wout + 3) / 4) * n * (nto / 10);   // (tile, n-group) pairs = ticket counters
+        // 4 x 8 tiles for the stride-1 blocks (round 5, the lean MQW = 2 builds): a workgroup streams ALL of the block's split weights
+        // (1.2 - 1.8 MB) through its CU's vector memory path whatever it computes, and that stream -- not the arithmetic -- is what
+        // these launches take (9 - 10 of their 16 us).  A 10x10 map is 9 tiles of 4 x 4 but 6 of 4 x 8: a third fewer workgroups and
+        // weight streams for the same matrix work (6 x (4 + 2) against 9 x (3 + 1) pixel tiles through expand + project).
+        static const int t48_env = wz_hp_env("WZ_HP_T48", 0);   // 1: eight waves at two per SIMD, 2: FOUR waves, one per SIMD (512 registers each)
+        const bool t48 = t48_env && a.stride == 1 && a.kc0 == 5 && (nto == 10 || nto == 20);
+        const int units = ((a.hout + 3) / 4) * ((a.wout + (t48 ? 7 : 3)) / (t48 ? 8 : 4)) * n * (nto / 10);   // (tile, n-group) pairs = ticket counters
         int G = 1;
         if (!prepare && a.ws && a.tickets && cg_env != 1 && units <= WZ_HP_TICKETS &&
-            (size_t)units * 4 * 10 * 1024 <= (size_t)(a.ws_bytes >> 1)) {
+            (size_t)units * 4 * (t48 ? 20 : 10) * 1024 <= (size_t)(a.ws_bytes >> 1)) {
             int best = (nk32 + 7) / 8;                                       // chunks a wave walks with one group
             for (int g = 2; g <= 4; ++g) {
                 if (units * g > cg_cap || (cg_env > 1 && g > cg_env)) break;
@@ -960,6 +1060,18 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
                          : wz_hp_launch<8, true, false, 6, 1, 3, 10, 2, false, true, false, true>(a, n, s, prepare);
         }
         if (a.kc0 == 5 && (nto == 10 || nto == 20)) {
+            if (prepare) {
+                (void)wz_hp_launch<8, true, false, 4, 2, 5, 10, 2, false, true, false, true, true>(a, n, s, true);
+                (void)wz_hp_launch<8, true, false, 4, 2, 5, 10, 2, false, true, false, true>(a, n, s, true);
+                (void)wz_hp_launch<4, true, false, 4, 2, 5, 10, 1, false, true, false, true, true>(a, n, s, true);
+                (void)wz_hp_launch<4, true, false, 4, 2, 5, 10, 1, false, true, false, true>(a, n, s, true);
+            } else if (t48 && t48_env == 2) {
+                return G > 1 ? wz_hp_launch<4, true, false, 4, 2, 5, 10, 1, false, true, false, true, true>(a, n, s, false)
+                             : wz_hp_launch<4, true, false, 4, 2, 5, 10, 1, false, true, false, true>(a, n, s, false);
+            } else if (t48) {
+                return G > 1 ? wz_hp_launch<8, true, false, 4, 2, 5, 10, 2, false, true, false, true, true>(a, n, s, false)
+                             : wz_hp_launch<8, true, false, 4, 2, 5, 10, 2, false, true, false, true>(a, n, s, false);
+            }
             if (prepare) (void)wz_hp_launch<8, true, false, 3, 1, 5, 10, 2, false, true, false, true, true>(a, n, s, true);
             return G > 1 ? wz_hp_launch<8, true, false, 3, 1, 5, 10, 2, false, true, false, true, true>(a, n, s, false)
                          : wz_hp_launch<8, true, false, 3, 1, 5, 10, 2, false, true, false, true>(a, n, s, prepare);
