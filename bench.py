@@ -317,9 +317,28 @@ def schedule_child():
         # the rows THIS schedule's launch shapes produce, against the oracle (three of the batch's frames: ~2 s of oracle each)
         pr = parity_leg(eng, hfr, dfr, weights, check=(0, 3, 7))
         r["parity"] = {k: pr[k] for k in ("max_dscore", "max_dbox_px", "frames", "rows_compared", "rows_unexplained", "within_tolerance")}
+        # ... and the load this schedule is FOR (what the factory's `schedule: auto` selects for up to 4 cameras per detector): one camera's
+        # frame at a time -- configs[2]'s share of a GPU with its frames in HBM, and the plugin call on one pageable host frame
+        eng.close()
+        eng = HipEngine(path, int(os.environ.get("LOCAL_RANK", "0")), 4, 1280, 720)
+        f720 = [eng.upload(synthetic_frame(1280, 720, 600 + i)) for i in range(5)]
+        one = throughput(eng, lambda lane, s: eng.submit_device(lane, [f720[s % 5]], [1280], [720]), 1, steps=300, warm=20)
+        r["config3_1x720p_b1"] = dict(value=one["value"], unit="frames/s", p50_ms=one["p50_ms"])
+        from watsor_amd.detection.hip_gpu import HipObjectDetector
+        from watsor_amd.runtime import ROW_DTYPE
+        eng.close()
+        with HipObjectDetector(d, int(os.environ.get("LOCAL_RANK", "0")), max_batch=1, max_width=WIDTH, max_height=HEIGHT) as det:
+            rows = np.zeros(100, ROW_DTYPE)
+            for _ in range(20):
+                det.detect(hfr[0].shape, hfr[0], rows)
+            ms = [det.detect(hfr[i % len(hfr)].shape, hfr[i % len(hfr)], rows) for i in range(300)]
+            r["plugin_detect_b1"] = dict(p50_ms=round(float(np.median(ms)), 4), p99_ms=round(float(np.percentile(ms, 99)), 4))
         print(json.dumps(r), flush=True)
     finally:
-        eng.close()
+        try:
+            eng.close()
+        except Exception:
+            pass
         os.remove(path)
         os.rmdir(d)
     return 0
@@ -334,7 +353,8 @@ def latency_schedule_leg():
     if p.returncode != 0 or not lines:
         return dict(error=(p.stderr or p.stdout)[-300:])
     r = json.loads(lines[-1])
-    r["workload"] = "the headline workload with WZ_SCHEDULE=latency in the environment (child process)"
+    r["workload"] = ("the headline workload with the LATENCY schedule (child process; `hip_options={'schedule': 'latency'}`, what `auto` picks for up "
+                     "to 4 cameras per detector) + the single-frame operating points it is for: configs[2]'s share with frames in HBM, detect() of one host frame")
     return r
 
 
@@ -368,6 +388,39 @@ def skeleton_ratio(kernel, launches):
                     real_over_skeleton=round(prog["avg_us_real"] / prog["avg_us_skeleton"], 3), source=t["source"])
     except (OSError, ValueError, KeyError, TypeError):
         return None
+
+
+def lane_overlap(timeout_s=120):
+    """Kernels in flight and CU-slot-time per step of the headline workload, from in-kernel entry / exit stamps of an UNPROFILED four-lane
+    run (tools/lane_overlap.py on libwatsor_hip_stamps.so -- `make -C watsor_amd/csrc stamps`; rocprofv3's kernel trace serialises the
+    lanes: concurrency 1.18 under it).  Live when the stamps library is there, else the committed profiles/lane_overlap.json."""
+    keep = ("kernels_in_flight_mean_while_busy", "time_share_by_kernels_in_flight", "chip_idle_share", "cu_slot_time_us_per_step",
+            "cu_slot_time_uncapped_us_per_step", "kernel_time_sum_us_per_step", "us_per_step_device_clock", "slot_time_over_step_time",
+            "frames_per_s_stamped_run", "frames_per_s_product_library", "launches_per_step", "lanes", "program")
+    res, source = None, None
+    tool = os.path.join(ROOT, "tools", "lane_overlap.py")
+    if os.path.isfile(os.path.join(ROOT, "watsor_amd", "libwatsor_hip_stamps.so")):
+        tmp = "/tmp/wz_lane_overlap_%d.json" % os.getpid()
+        try:
+            p = subprocess.run([sys.executable, tool, "--steps", "400", "--json", tmp], capture_output=True, text=True, timeout=timeout_s)
+            if p.returncode == 0 and os.path.isfile(tmp):
+                res, source = json.load(open(tmp)), "live: tools/lane_overlap.py in this run (in-kernel stamps, no profiler)"
+        except (subprocess.TimeoutExpired, OSError, ValueError):
+            res = None
+        finally:
+            if os.path.isfile(tmp):
+                os.remove(tmp)
+    if res is None:
+        try:
+            res, source = json.load(open(os.path.join(ROOT, "profiles", "lane_overlap.json"))), "committed profiles/lane_overlap.json"
+        except (OSError, ValueError):
+            return None
+    out = {k: res[k] for k in keep if k in res}
+    out["largest_holders"] = [dict(launch=p_["launch"], kernel=p_["kernel"][:48], workgroups=p_["workgroups"], wg_per_cu=p_["wg_per_cu"],
+                                   mean_us=p_["mean_us"], slot_time_us=p_["slot_time_us"])
+                              for p_ in sorted(res.get("per_launch", []), key=lambda q: -q["slot_time_us"])[:6]]
+    out["source"] = source
+    return out
 
 
 def rocprof_avg_us(kernel):
@@ -1241,6 +1294,14 @@ def main():
                 roof["frac_counter_traffic"] = round(roof["traffic"]["bytes"] / (roof["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
                 roof["traffic_over_fused_min"] = round(roof["traffic"]["bytes"] / max(roof["fused_min_bytes_per_launch"], 1), 3)
                 out["roofline"] = roof
+        if world == 1 and not args.no_live_pmc:
+            lo = lane_overlap()
+            note("lane overlap %s" % ("measured" if lo and lo["source"].startswith("live") else "from the committed file" if lo else "unavailable"))
+            if lo:
+                # what the four-lane headline rests on: how many kernels are on the chip at once, and what they book of it
+                out["roofline"]["concurrency_mean"] = lo["kernels_in_flight_mean_while_busy"]
+                out["roofline"]["cu_slot_time_us_per_step"] = lo["cu_slot_time_us_per_step"]
+                out["roofline"]["lane_overlap"] = lo
         if world == 1 and not args.no_legs:
             legs = {}
             legs.update(host_legs(engine_path, model_dir, local_rank, host_frames))
@@ -1289,6 +1350,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:
+        if world > 1:
+            out["only_at_n_gpus_1"] = "cpu_baseline, live counter traffic, lane overlap, the other-engine legs and the single-process legs run at N = 1 only"
         print(json.dumps(out), flush=True)
     try:
         os.remove(engine_path)

@@ -147,8 +147,10 @@ def test_end_to_end_with_each_option(request, synth_weights, which):
 
 
 def test_latency_schedule_detects_the_same_objects(model_dir, tmp_path):
-    """WZ_SCHEDULE=latency (include/watsor_hip.h) picks other launch shapes -- other summation orders -- for the same network: the rows
-    of a child process running it agree with this process's (throughput schedule) to rounding, on the product library."""
+    """The LATENCY schedule (include/watsor_hip.h: wz_set_schedule; plugin option `schedule`, what the factory picks for up to 4 cameras)
+    selects other launch shapes -- other summation orders -- for the same network: the rows of a child process that asks for it through
+    the OPTION (not the environment) agree with those of one on the throughput schedule to rounding, on the product library; and a
+    process whose shapes are fixed refuses the other schedule."""
     import json
     import os
     import subprocess
@@ -158,17 +160,23 @@ def test_latency_schedule_detects_the_same_objects(model_dir, tmp_path):
         "sys.path.insert(0, %r)\n"
         "from watsor_amd.runtime import HipEngine, ROW_DTYPE\n"
         "from watsor_amd.synth import synthetic_frame\n"
-        "e = HipEngine(%r, 0, 8, 640, 480)\n"
+        "e = HipEngine(%r, 0, 8, 640, 480, schedule=sys.argv[1])\n"
+        "assert e.schedule == sys.argv[1]\n"
+        "try:\n"
+        "    HipEngine(%r, 0, 1, 640, 480, schedule='latency' if sys.argv[1] == 'throughput' else 'throughput')\n"
+        "    raise SystemExit('the other schedule was accepted')\n"
+        "except ValueError:\n"
+        "    pass\n"
         "frames = [synthetic_frame(640, 480, 8800 + i) for i in range(8)]\n"
         "rows = [np.zeros(100, ROW_DTYPE) for _ in frames]\n"
         "e.detect_batch(frames, rows)\n"
         "print(json.dumps(dict(nodes=e.graph_nodes(0), label=[r['label'].tolist() for r in rows], conf=[r['confidence'].tolist() for r in rows],"
         " box=[np.stack([r['x_min'], r['y_min'], r['x_max'], r['y_max']], 1).tolist() for r in rows])))\n"
-        "e.close()\n" % (conftest.ROOT, os.path.join(model_dir, "mi355x.bin")))
+        "e.close()\n" % (conftest.ROOT, os.path.join(model_dir, "mi355x.bin"), os.path.join(model_dir, "mi355x.bin")))
     out = {}
+    env = {k: v for k, v in os.environ.items() if k != "WZ_SCHEDULE"}
     for sched in ("throughput", "latency"):
-        env = dict(os.environ, WZ_SCHEDULE=sched)
-        p = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=240)
+        p = subprocess.run([sys.executable, "-c", script, sched], env=env, capture_output=True, text=True, timeout=240)
         assert p.returncode == 0, p.stderr[-1500:]
         out[sched] = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     a, b = out["throughput"], out["latency"]

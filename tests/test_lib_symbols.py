@@ -71,3 +71,34 @@ def test_no_gpu_calls_fail_cleanly():
             assert False
         except FileNotFoundError:
             pass
+
+
+def test_schedule_is_a_process_wide_setting_fixed_on_first_use():
+    """include/watsor_hip.h: wz_set_schedule / wz_get_schedule (no GPU needed).  Fresh processes: the option wins over nothing, the
+    environment decides when nothing was set, and once fixed only the value in force is accepted."""
+    import sys
+    root = os.path.join(os.path.dirname(__file__), "..")
+    script = ("import sys; sys.path.insert(0, %r)\n"
+              "from watsor_amd import runtime as r\n"
+              "import os\n"
+              "mode = sys.argv[1]\n"
+              "if mode == 'option':\n"
+              "    r.set_schedule('latency'); assert r.get_schedule() == 'latency'\n"
+              "    r.set_schedule('latency')\n"
+              "    try:\n"
+              "        r.set_schedule('throughput'); print('NO ERROR')\n"
+              "    except ValueError as e:\n"
+              "        print('refused:', e)\n"
+              "elif mode == 'env':\n"
+              "    print(r.get_schedule())\n"
+              "    try:\n"
+              "        r.set_schedule('bogus')\n"
+              "    except ValueError as e:\n"
+              "        print('bad name:', e)\n" % os.path.abspath(root))
+    env = {k: v for k, v in os.environ.items() if k != "WZ_SCHEDULE"}
+    p = subprocess.run([sys.executable, "-c", script, "option"], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "refused:" in p.stdout and "already fixed for the latency schedule" in p.stdout, p.stdout + p.stderr
+    p = subprocess.run([sys.executable, "-c", script, "env"], env=dict(env, WZ_SCHEDULE="latency"), capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and p.stdout.splitlines()[0] == "latency" and "bad name:" in p.stdout, p.stdout + p.stderr
+    p = subprocess.run([sys.executable, "-c", script, "env"], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and p.stdout.splitlines()[0] == "throughput", p.stdout + p.stderr
