@@ -448,3 +448,13 @@ def test_builder_picks_the_robust_program_by_channel_spread(tmp_path, synth_weig
     assert hp_blocks() == 17 and "WARNING" in cap.err and "-p 32" in cap.err
     with pytest.raises(ValueError):
         engine.main(["-i", "synthetic", "-o", out, "--robust", "on", "--plain-fp16"])
+
+
+def test_float_form_beyond_the_blocks_that_have_it_is_refused(synth_weights):
+    """blocks 13 .. 16 exist with the linear chunk buffer only -- an engine that asked for the float form there would be built
+    happily and then refused by the runtime ("no split-operand kernel took op").  The builder says so instead."""
+    import pytest
+    from watsor_amd import engine
+    with pytest.raises(ValueError, match="float-form chunk buffer exists for blocks 0 .. 12"):
+        engine.build_engine(synth_weights, robust=True, float_form_upto=13)
+    assert engine.FLOAT_FORM_LAST_BLOCK == 12

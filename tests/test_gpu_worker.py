@@ -55,7 +55,9 @@ def test_plugin_in_a_spawned_worker_writes_the_same_rows(model_dir, asynchronous
     fps, inference_time = shm.Gauge(ctx), shm.Gauge(ctx)
     name, opts, pinned = run_child(ctx, model_dir, cams, batches, fps, inference_time, None, False, asynchronous=asynchronous)
     assert "gfx950" in name or "MI3" in name
-    assert opts == {"max_width": 1280, "max_height": 720}          # derived from the frame buffers, not from env defaults
+    # derived from the frame buffers, not from env defaults; five cameras: the throughput schedule (up to four: latency -- the two-camera
+    # tests below run their child on it and still compare bit for bit with this process's engine)
+    assert opts == {"max_width": 1280, "max_height": 720, "schedule": "throughput"}
     assert pinned == 15                                             # every Frame.image of every camera was page-locked
     # the parent reads the rows out of shared memory and compares with an in-process engine
     e = make_engine(model_dir, max_batch=8, max_width=1280, max_height=720)

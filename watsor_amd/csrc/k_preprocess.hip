@@ -228,6 +228,10 @@ __global__ __launch_bounds__(WZ_PRE_ROWS_THREADS) void wz_k_preprocess_rows(cons
     const int cy0 = y0 >> 1, cy1 = y1 >> 1;
 
     // the byte runs: luma / RGB span, chroma span(s); each lands at the 16-byte boundary below its first byte
+    // (Over-read: a run is fetched as the whole aligned 16-byte chunks that COVER it -- up to 15 bytes in front of its first and behind its
+    //  last byte.  Every chunk holds at least one byte of the run and an aligned 16-byte chunk never straddles a page, so the extra bytes
+    //  lie in a page the run itself lies in: inside what wz_host_register() page-locked (pinning is page-granular) or inside the lane's
+    //  staging allocation, whatever the alignment of the registered range or of frame_stride.  They are never used.  ADVICE r4.)
     const uint8_t* const chroma = f.rgb + (size_t)f.w * f.h;
     const uint8_t* const src0 = f.rgb + (size_t)y0 * rowb;
     const uint8_t* const src1 = chroma + (size_t)cy0 * crowb;

@@ -138,6 +138,7 @@ def split_halves(w: np.ndarray):
 UNORM16_PER_6 = 65535.0 / 6.0    # the split-operand blocks keep relu6 outputs in LDS as unorm16 of x / 6
 FLOAT_FORM_C = 2.0 ** -7         # ... the robust program as a 16-bit float of t = C + (x / 6) K (3 exponent + 13 mantissa bits; k_mbconv_hp.hip)
 FLOAT_FORM_K = (2.0 - 2.0 ** -13) - FLOAT_FORM_C
+FLOAT_FORM_LAST_BLOCK = 12       # the last block whose kernel has a float-form build (csrc/k_mbconv_hp.hip: wz_launch_mbconv_hp_q; the 10x10 maps do not)
 
 
 def stem_k_rows(w: np.ndarray) -> np.ndarray:
@@ -262,6 +263,10 @@ def build_engine(weights: Dict[str, np.ndarray], precision: int = 16, model_widt
         raise ValueError("resize mode %r: expected one of %s" % (opt["resize"], ", ".join(RESIZE_MODES)))
     if robust and not (precision == 16 and fuse and fuse_stem and hp_upto is None):
         raise ValueError("the robust program is the `-p 16` program with fused blocks")
+    if robust and not (-1 <= float_form_upto <= FLOAT_FORM_LAST_BLOCK):
+        # (blocks 13 .. 16 -- the 10x10 maps -- exist with the linear chunk buffer only: an engine asking for the float form there would be
+        #  refused by the runtime with "no split-operand kernel took op")
+        raise ValueError("float_form_upto %r: the float-form chunk buffer exists for blocks 0 .. %d (-1: nowhere)" % (float_form_upto, FLOAT_FORM_LAST_BLOCK))
     if hp_upto is None:
         hp_upto = (arch.HP_ALL_BLOCKS if robust else arch.HP_LAST_BLOCK) if (precision == 16 and fuse and fuse_stem) else -1
     prog = arch.build(model_width, fuse=fuse, fuse_stem=fuse_stem, hp_upto=hp_upto, input_pair=precision == 32, tap_in_block=tap_in_block,
