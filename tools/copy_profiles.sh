@@ -11,3 +11,6 @@ for L in 1 4; do
   cp gpurun_out/$1_lanes$L/rocprof_kernel_avg.json $P/${T}_rocprof_kernel_avg_lanes$L.json
 done
 cp gpurun_out/$1_lanes1/rocprof_kernel_avg.json $P/rocprof_kernel_avg.json; cp gpurun_out/$1_lanes1/pmc_traffic.json $P/pmc_traffic.json
+# round 5
+cp $S/lane_overlap_robust.txt $P/${T}_lane_overlap_robust.txt; cp $S/lane_overlap_default.txt $P/${T}_lane_overlap_default.txt; cp $S/lane_overlap_robust_one_lane.txt $P/${T}_lane_overlap_robust_one_lane.txt
+cp $S/lane_overlap_robust.json $P/lane_overlap.json; cp $S/cu_stream.txt $P/${T}_cu_stream.txt; cp $S/soak.txt $P/${T}_soak.txt

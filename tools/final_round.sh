@@ -15,3 +15,9 @@ timeout 200 python tools/stage_table.py --robust --throughput > $OUT/stage_table
 timeout 200 python tools/stage_table.py --throughput > $OUT/stage_table_default.txt 2>&1; tail -2 $OUT/stage_table_default.txt
 timeout 200 python tools/nms_probe.py > $OUT/nms_probe.txt 2>&1; tail -2 $OUT/nms_probe.txt
 timeout 300 python tools/parity_report.py --robust --frames 4 > $OUT/parity_report_robust.txt 2>&1; tail -4 $OUT/parity_report_robust.txt
+# round 5: kernels in flight / CU-slot-time from in-kernel stamps (no profiler), both programs; the per-CU weight stream; the soak
+timeout 200 python tools/lane_overlap.py --out $OUT/lane_overlap_robust.txt --json $OUT/lane_overlap_robust.json > /dev/null 2> $OUT/lane_overlap.err; grep -E "KERNELS|CU-SLOT|^run" $OUT/lane_overlap_robust.txt
+timeout 200 python tools/lane_overlap.py --default-program --out $OUT/lane_overlap_default.txt --json $OUT/lane_overlap_default.json > /dev/null 2>> $OUT/lane_overlap.err; grep -E "KERNELS|CU-SLOT|^run" $OUT/lane_overlap_default.txt
+WZ_LANES=1 timeout 200 python tools/lane_overlap.py --no-product --out $OUT/lane_overlap_robust_one_lane.txt > /dev/null 2>> $OUT/lane_overlap.err; grep -E "KERNELS|CU-SLOT|^run" $OUT/lane_overlap_robust_one_lane.txt
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w tools/micro/cu_stream.hip -o /tmp/cu_stream && timeout 60 /tmp/cu_stream > $OUT/cu_stream.txt 2>&1
+timeout 200 python tools/soak.py 40 --robust > $OUT/soak.txt 2>&1; timeout 100 python tools/soak.py 20 --robust --small >> $OUT/soak.txt 2>&1; tail -4 $OUT/soak.txt
