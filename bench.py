@@ -327,6 +327,9 @@ def schedule_child():
         from watsor_amd.detection.hip_gpu import HipObjectDetector
         from watsor_amd.runtime import ROW_DTYPE
         eng.close()
+        eng = HipEngine(path, int(os.environ.get("LOCAL_RANK", "0")), 4, WIDTH, HEIGHT)
+        r["host_frames_pinned_lone_batch_b4"] = lone_host_batch(eng, hfr)
+        eng.close()
         with HipObjectDetector(d, int(os.environ.get("LOCAL_RANK", "0")), max_batch=1, max_width=WIDTH, max_height=HEIGHT) as det:
             rows = np.zeros(100, ROW_DTYPE)
             for _ in range(20):
@@ -454,6 +457,28 @@ def throughput(eng, submit, n_frames_per_step, steps=400, warm=40):
         lat.append((time.perf_counter() - t1) * 1e3)
     return dict(value=round(steps * n_frames_per_step / dt, 1), unit="frames/s", ms_per_step=round(dt / steps * 1e3, 4),
                 p50_ms=round(float(np.median(lat)), 4), frames_per_step=n_frames_per_step, steps=steps)
+
+
+def lone_host_batch(eng, host_frames, n=4, reps=200):
+    """A LONE batch of n page-locked 640x480 host frames, submit + collect, nothing else in flight -- what a detector with up to four
+    cameras does all day (one queued frame per camera, `watsor/stream/sync.py:156-166`): p50 / p99 in ms."""
+    from watsor_amd.runtime import ROW_DTYPE
+    arena = np.ascontiguousarray(np.stack(host_frames[:2 * n]))
+    eng.host_register(arena)
+    try:
+        rows = [np.zeros(100, ROW_DTYPE) for _ in range(n)]
+        lat = []
+        for i in range(reps + 20):
+            views = [arena[(i % 2) * n + k] for k in range(n)]
+            t1 = time.perf_counter()
+            eng.submit_host(0, views)
+            eng.collect(0, rows)
+            if i >= 20:
+                lat.append((time.perf_counter() - t1) * 1e3)
+        return dict(p50_ms=round(float(np.median(lat)), 4), p99_ms=round(float(np.percentile(lat, 99)), 4), frames=n)
+    finally:
+        eng.sync()
+        eng.host_unregister(arena)
 
 
 def sample_detect_config(nz):
@@ -598,6 +623,13 @@ def host_legs(engine_path, model_dir, device, host_frames):
             finally:
                 eng.sync()
                 eng.host_unregister(arena)
+    finally:
+        eng.close()
+    eng = HipEngine(engine_path, device, 4, WIDTH, HEIGHT)
+    try:
+        legs["host_frames_pinned_lone_batch_b4"] = dict(lone_host_batch(eng, host_frames), schedule=eng.schedule,
+                                                        workload="a lone batch of four 640x480 frames in page-locked host memory, submit + collect, nothing else in "
+                                                                 "flight (a detector with four cameras); the latency schedule's twin: legs.latency_schedule_b8.host_frames_pinned_lone_batch_b4")
     finally:
         eng.close()
     # the plugin call the reference worker makes: one frame from (pageable) host memory, synchronous -- the time
