@@ -10,6 +10,9 @@
 //   * here a wave owns 128 pixels x 80 channels (five 16-channel tiles; accumulators: 160 registers, the kernel runs one
 //     wave per SIMD with the unified 512-register file): 80 MFMAs (1 280 cycles) per 16 KiB of LDS reads -- LDS 512,
 //     vector memory <= 900 (16 KiB activations + <= 40 KiB weights), MFMA 1 280 cycles per workgroup step;
+//     -- since round 5 the DEFAULT is the same body with THREE tiles per wave (wz_k_conv_wide_group3: 96 accumulator registers, 248 in all, two
+//     workgroups per CU and two waves per SIMD that cover each other's barrier waits): 48 MFMAs per 16 KiB of LDS reads, 1.5 - 2 x the activation
+//     tiles through LDS, and a launch that is 27 % shorter (38.0 -> 27.9 us at batch 8) -- see wz_conv_wide_ntw() below;
 //   * and the step is software-pipelined in two halves (the two 32-channel MFMA K chunks of the step): while the MFMAs
 //     of one half run, the LDS fragment reads of the next half, the LDS write of the next step's activations and the
 //     global loads of the step after are in flight.  One `s_barrier` per step, preceded by `lgkmcnt(0)` only: the weight
@@ -366,6 +369,27 @@ __global__ __launch_bounds__(256, 1) void wz_k_conv_wide_group(const WzConvGroup
     wz_conv_wide_body<3, 5>(g.a[e], smem, (int)blockIdx.x - g.first[e]);
 }
 
+// The same body with THREE channel tiles per wave (128 pixels x up to 192 channels per workgroup) at <= 256 registers: two workgroups share a
+// CU, two waves a SIMD (round 5; WZ_WIDE_NTW=3).  Alone the five-tile form does more matrix work per LDS byte (80 against 48 MFMAs per 16 KiB of fragment
+// reads); what this form is for is the four-lane case: a 344-register workgroup needs a WHOLE free CU and, with three other lanes' workgroups scattered over
+// the chip, waits for one (the launch takes 55 us under load against 26.5 us alone: profiles/r05zz_lane_overlap_robust.txt), a 256-register one moves in
+// beside whatever holds the other half.
+__global__ __launch_bounds__(256, 2) void wz_k_conv_wide_group3(const WzConvGroup g) {
+    WZ_LANE_STAMP(g.stamp);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 16384 + WZ_WIDE_TM * 8];
+    int e = 0;
+    while (e + 1 < g.n && (int)blockIdx.x >= g.first[e + 1]) ++e;   // wave-uniform
+    wz_conv_wide_body<3, 3>(g.a[e], smem, (int)blockIdx.x - g.first[e]);
+}
+
+// channel tiles per wave of the build in use (5: one workgroup per CU; 3: two) -- the workgroup's tile is four times that
+int wz_conv_wide_ntw() {
+    // default 3 since round 5: the heads' launch 38.0 -> 27.9 us alone, a lone batch of eight 0.391 -> 0.379 ms, frames/s with four lanes unchanged
+    // (47.7 - 47.8 k both ways; under load the launch takes ~55 us either way: profiles/r05_heads_three_tiles_per_wave.txt).  WZ_WIDE_NTW=5: the round-2 .. 4 build.
+    static const int ntw = [] { const char* e = wz_dev_getenv("WZ_WIDE_NTW"); const int v = (e && e[0]) ? atoi(e) : 3; return v == 5 ? 5 : 3; }();
+    return ntw;
+}
+
 // 3x3 heads with a K loop worth tiling (the conditions of the LDS-tiled kernels); the engine's WZ_CONV_WIDE=0 gives them back to
 // wz_k_conv_rs
 bool wz_conv_wide_applies(const WzConvArgs& a) {
@@ -378,7 +402,8 @@ bool wz_conv_wide_applies(const WzConvArgs& a) {
 
 void wz_conv_wide_shape(const WzConvArgs& a, int* tiles, int* steps) {
     const int live = (a.cout + 15) >> 4;
-    const int groups = (live + 19) / 20;
+    const int per = 4 * wz_conv_wide_ntw();
+    const int groups = (live + per - 1) / per;
     *tiles = ((a.M + WZ_WIDE_TM - 1) / WZ_WIDE_TM) * groups;
     *steps = a.kchunks >> 1;
 }
@@ -417,7 +442,7 @@ int wz_conv_wide_group_add(WzConvGroup& g, const WzConvArgs& a0) {
     WzConvArgs& a = g.a[i];
     a = a0;
     a.nt_live = (a.cout + 15) >> 4;
-    a.grid_n = (a.nt_live + 19) / 20;
+    a.grid_n = (a.nt_live + 4 * wz_conv_wide_ntw() - 1) / (4 * wz_conv_wide_ntw());
     a.nt_group = (a.nt_live + a.grid_n - 1) / a.grid_n;
     a.grid_m = (a.M + WZ_WIDE_TM - 1) / WZ_WIDE_TM;
     g.gx[i] = g.gy[i] = 0;
@@ -426,5 +451,8 @@ int wz_conv_wide_group_add(WzConvGroup& g, const WzConvArgs& a0) {
 }
 
 void wz_launch_conv_wide_group(const WzConvGroup& g, hipStream_t s) {
-    WZ_LAUNCH(wz_k_conv_wide_group, dim3(g.first[g.n]), dim3(256), 0, s, g);
+    if (wz_conv_wide_ntw() == 3)
+        WZ_LAUNCH(wz_k_conv_wide_group3, dim3(g.first[g.n]), dim3(256), 0, s, g);
+    else
+        WZ_LAUNCH(wz_k_conv_wide_group, dim3(g.first[g.n]), dim3(256), 0, s, g);
 }

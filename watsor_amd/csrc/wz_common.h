@@ -274,6 +274,7 @@ int wz_conv_rs_group_add(WzConvGroup& g, const WzConvArgs& a);   // entries adde
 void wz_launch_conv_rs_group(const WzConvGroup& g, hipStream_t s);
 // ... and the wide tile kernel (k_conv_wide.hip: 128 pixels x up to 320 channels per workgroup), which serves the big heads by default
 bool wz_conv_wide_applies(const WzConvArgs& a);
+int wz_conv_wide_ntw();                                                 // channel tiles per wave of the build in use (5, or 3: two workgroups per CU)
 void wz_conv_wide_shape(const WzConvArgs& a, int* tiles, int* steps);   // workgroup tiles and K steps (of 64 channels x one tap)
 int wz_choose_wide_T(const int* tiles, const int* steps, const long long* tile_bytes, int n, int cus);   // steps per K slice
 int wz_conv_wide_group_add(WzConvGroup& g, const WzConvArgs& a);         // a.splitk set by the caller; 0 = the group is full

@@ -306,12 +306,13 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
             a.zeros = e->d_zeros;
             if (!wz_conv_wide_applies(a) || a.M < e->wide_min_m) continue;
             wz_conv_wide_shape(a, &tiles[cnt], &steps[cnt]);
-            tile_bytes[cnt] = 128ll * 4 * (((a.cout + 15) & ~15) / (((a.cout + 15) / 16 + 19) / 20));
+            tile_bytes[cnt] = 128ll * 4 * (((a.cout + 15) & ~15) / (((a.cout + 15) / 16 + 4 * wz_conv_wide_ntw() - 1) / (4 * wz_conv_wide_ntw())));
             ++cnt;
         }
         // (K slices sized for HALF the chip when other lanes are there to use the rest: at batch 8 T = 27 -> 41 steps per slice, 179 -> ~120
         // workgroups of this one-wave-per-SIMD kernel, a third fewer fp32 partial tiles: 49.8 k -> 50.5 k frames/s, p50 +8 us)
-        if (cnt > 0) wide_T = e->wide_T > 0 ? e->wide_T : wz_choose_wide_T(tiles, steps, tile_bytes, cnt, e->n_lanes > 1 ? e->wide_cus : e->num_cus);
+        // (the three-tile build puts two workgroups on a CU: twice the slots in the same part of the chip)
+        if (cnt > 0) wide_T = e->wide_T > 0 ? e->wide_T : wz_choose_wide_T(tiles, steps, tile_bytes, cnt, (e->n_lanes > 1 ? e->wide_cus : e->num_cus) * (wz_conv_wide_ntw() == 3 ? 2 : 1));
     }
     int big_head[WZ_CONV_GROUP_MAX] = {0}, small_head[WZ_CONV_GROUP_MAX] = {0};   // ... and which entry
     for (uint32_t i = 0; i < e->hdr.n_ops; ++i) {
