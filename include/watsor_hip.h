@@ -215,7 +215,7 @@ int wz_dev_download(wz_engine_t* e, void* h_dst, const void* d_src, uint64_t byt
 /* ======================================================================================================================
  * Development library only (`make dev` -> libwatsor_hip_dev.so, compiled with -DWZ_DEV_BUILD): stage-level entry points of the
  * parity tests, per-kernel profiling for bench.py's roofline, diagnostics, and -- inside the library -- the WZ_* tuning knobs and
- * the kernel variants that lost their A/B.  libwatsor_hip.so exports nothing below this line and reads
+ * the kernel variants that lost their A/B (HISTORY.md part B).  libwatsor_hip.so exports nothing below this line and reads
  * only WZ_LANES, WZ_STREAMS, WZ_GRAPH and WZ_SCHEDULE from the environment.
  * ====================================================================================================================== */
 #ifdef WZ_DEV_BUILD

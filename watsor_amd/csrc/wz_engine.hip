@@ -173,7 +173,7 @@ struct wz_engine {
     };
     Lane lanes[WZ_SLOTS];
     int n_lanes = 4;   // default; WZ_LANES overrides (1..WZ_SLOTS)
-    int n_streams = 4; // HIP streams the lanes are spread over (WZ_STREAMS); more than 4 run slower on this stack
+    int n_streams = 4; // HIP streams the lanes are spread over (WZ_STREAMS); more than 4 run slower on this stack (HISTORY.md part B)
 
     // the worker's frame table (wz_bind_frames): one entry per Frame of every FrameBuffer, described once instead of once per batch
     struct BoundFrame {
@@ -360,7 +360,7 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
         } else {
             // The extras behind the 5x5 map: a chain of plain convolutions on maps of <= 32 pixels, each reading what the one before it
             // wrote -- WZ_TAIL_FUSE=1 runs them as ONE launch, a workgroup per frame (k_tail.hip).  Built, bit-compatible within fp32
-            // summation order, and slower than the six launches it replaces (34 us against 23.5 us: DESIGN.md section 10): off by default.
+            // summation order, and slower than the six launches it replaces (34 us against 23.5 us: HISTORY.md part B): off by default.
 #ifdef WZ_DEV_BUILD
             if (!f32 && e->tail_fuse && op.out_mode == WZ_OUT_ACT) {
                 WzTailArgs T;
@@ -1328,7 +1328,7 @@ extern "C" int wz_detect_batch_fmt(wz_engine_t* e, int n, const uint8_t* const* 
 // the frames through their device-mapped addresses -- one graph node per batch instead of one call per frame -- reaches
 // 55 GB/s on its own, tools/micro/h2d_streams.hip, but only 23 GB/s beside the other lanes' kernels against the copies'
 // 29 GB/s; a fifth stream for the copies alone, so that whole batches arrive back to back: 24.8 k against 31.5 k frames/s at
-// 640x480 -- this stack runs four streams side by side, section 10 of DESIGN.md: profiles/r03_host_path_*.)
+// 640x480 -- this stack runs four streams side by side, HISTORY.md part B: profiles/r03_host_path_*.)
 // Where the device sees a page-locked host frame, or nullptr: inside a range wz_host_register locked (WzFrameDesc::rgb may then point
 // at the frame itself and the resize kernel reads its tap rows over PCIe, no staging copy -- `host_read`).
 static const uint8_t* device_view(wz_engine* e, const uint8_t* host, uint64_t bytes) {
