@@ -109,6 +109,39 @@ def test_self_test_of_the_oracle_comparison(self_made):
         check_oracle_stage_by_stage(g, self_made[1])
 
 
+def test_nms_order_witness_tells_the_two_exporter_generations_apart():
+    """`make_tf_golden.nms_order_witness`: which clip / NMS order a graph has, read off its own raw head outputs and final detections
+    (the first TensorFlow run settles `--clip-after-nms` by data).  Stand-in "graphs": the oracle in either order
+    on head outputs whose boxes straddle the image border (the two orders keep different rows there)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_tf_golden as gen
+    from oracle import postprocess as post
+    rng = np.random.default_rng(5)
+    anchors = post.generate_anchors()
+    acs = post.anchors_center_size(anchors)
+    be = np.zeros((1917, 4), np.float32)
+    be[:, 2:] = -3.0
+    lg = (rng.standard_normal((1917, 91)) - 7.0).astype(np.float32)
+    for _ in range(40):                                            # objects near / across the border, a few jittered anchors each
+        cy, cx = rng.uniform(-0.15, 1.15, 2)
+        h, w = rng.uniform(0.15, 0.6, 2)
+        cls = int(rng.integers(1, 91))
+        near = np.argsort((acs[:, 0] - cy) ** 2 + (acs[:, 1] - cx) ** 2)[:18]
+        for a in rng.choice(near, 6, replace=False):
+            jy, jx = rng.normal(0, 0.02, 2)
+            ay, ax, ah, aw = acs[a]
+            be[a] = [((cy + jy) - ay) / ah * 10, ((cx + jx) - ax) / aw * 10, np.log(h / ah) * 5, np.log(w / aw) * 5]
+            lg[a, cls] = rng.uniform(0.5, 4.0)
+    for clip_after, want in ((False, "clip_before_nms"), (True, "clip_after_nms")):
+        b, s_, c, n = post.postprocess(be, lg, acs, clip_after_nms=clip_after, **({} if clip_after else {"fast": True}))
+        g = {"frames": np.array([[640, 480, 1]], np.int32), "f0_box_encodings": be[None], "f0_class_logits": lg[None], "f0_anchors": anchors,
+             "f0_detection_boxes": b[None], "f0_detection_scores": s_[None], "f0_num_detections": np.array([float(n)], np.float32)}
+        w_ = gen.nms_order_witness(g)
+        assert w_["order"] == want and w_["frames_telling_them_apart"] == 1, w_
+    assert gen.nms_order_witness({"frames": np.array([[1, 1, 1]], np.int32)})["order"] == "no raw head outputs in the file"
+
+
 def check_engine_rows(golden, tf_weights, tmp_path):
     from oracle.compare import assert_rows_match
     from oracle.detect import rows_as_array
