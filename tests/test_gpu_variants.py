@@ -239,3 +239,51 @@ def test_earlier_launch_shapes_detect_the_same_objects(model_dir_default, knobs)
         n_ref = int((ref["confidence"] > 0.1).sum())
         assert n_ref > 50 and len(missing) <= max(1, n_ref // 20)
         assert max(abs(p[3]) for p in pairs) <= 5e-4
+
+
+def test_stamps_build_writes_the_same_rows_and_sees_the_lanes_overlap(model_dir_robust, tmp_path):
+    """`libwatsor_hip_stamps.so` (make stamps: every kernel records its entry / exit, tools/lane_overlap.py) is a MEASUREMENT build -- what it
+    measures must be the product's behaviour: in a child process it writes bit for bit the rows the product library writes for the same
+    batch, reports one (entry < exit) pair per launch of the batch, and with the four lanes busy finds more than two kernels in flight."""
+    import json
+    import os
+    import subprocess
+    import sys
+    stamps = os.path.join(conftest.ROOT, "watsor_amd", "libwatsor_hip_stamps.so")
+    if not os.path.isfile(stamps):
+        pytest.skip("no stamps build here (make -C watsor_amd/csrc stamps)")
+    script = (
+        "import sys, json, ctypes as C, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from watsor_amd.runtime import HipEngine, ROW_DTYPE\n"
+        "from watsor_amd.synth import synthetic_frame\n"
+        "import lane_overlap as lo\n"
+        "path = %r\n"
+        "frames = [synthetic_frame(640, 480, 9100 + i) for i in range(8)]\n"
+        "out = {}\n"
+        "for name, dev in (('product', False), ('stamps', True)):\n"
+        "    e = HipEngine(path, 0, 8, 640, 480, dev=dev)\n"
+        "    rows = [np.zeros(100, ROW_DTYPE) for _ in frames]\n"
+        "    e.detect_batch(frames, rows)\n"
+        "    out[name] = np.stack(rows).tobytes().hex()\n"
+        "    if dev:\n"
+        "        buf = (C.c_uint64 * 320)()\n"
+        "        k = e._lib.wz_debug_lane_stamps(e._h, 0, buf, 160)\n"
+        "        out['launches'] = k\n"
+        "        out['ordered'] = all(0 < buf[2 * i] < buf[2 * i + 1] for i in range(k))\n"
+        "        out['chain'] = all(buf[2 * i + 1] <= buf[2 * i + 3] for i in range(k - 1))\n"
+        "        out['nodes'] = e.graph_nodes(0)\n"
+        "    e.close()\n"
+        "iv, launches, fps, ms, lanes = lo.collect(path, 120, 20, 8)\n"
+        "res = lo.analyse(iv, launches, fps, ms, lanes, 120, 8, None)\n"
+        "out['in_flight'] = res['kernels_in_flight_mean_while_busy']; out['dropped'] = res['intervals_dropped']; out['per_step'] = res['launches_per_step']\n"
+        "out['named'] = sum(1 for p in res['per_launch'] if p['workgroups'] > 0 and p['wg_per_cu'] > 0)\n"
+        "print(json.dumps(out))\n" % (conftest.ROOT, os.path.join(conftest.ROOT, "tools"), os.path.join(model_dir_robust, "mi355x.bin")))
+    env = dict(os.environ, WATSOR_HIP_DEV_LIBRARY=stamps)
+    p = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["product"] == out["stamps"]                              # the measurement build computes what the product computes
+    assert out["launches"] == out["nodes"] == out["per_step"] == out["named"] and out["launches"] >= 25
+    assert out["ordered"] and out["chain"]                              # every launch entered before it left, and left before its successor did
+    assert out["dropped"] == 0 and out["in_flight"] > 2.0, out["in_flight"]
