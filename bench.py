@@ -217,6 +217,21 @@ def roofline_object(table, overhead, single_table, inner):
     if rp:           # ... and at the duration the committed rocprofv3 kernel trace of this command reports
         roof["avg_launch_us_rocprof"] = rp
         roof["frac_at_rocprof_duration"] = round(roof["frac"] * dom["avg_us"] / rp, 5)
+    # What bounds the fraction on THIS workload, each term with the measurement behind it (round 5): at batch 8 a layer's
+    # roofline time is shorter than the dependency wait between two kernels of one stream, and the launches of the 10x10 maps cannot be
+    # shorter than the weight stream of one of their workgroups.
+    step_bytes = sum(r["bytes_per_launch"] * r["launches"] for r in table if r.get("bytes_per_launch"))
+    roof["limits"] = dict(
+        whole_step_algorithmic_bytes=round(step_bytes),
+        whole_step_us_at_hbm_peak=round(step_bytes / (HBM_PEAK_GBS * 1e9) * 1e6, 1),
+        in_stream_boundary_us=3.0, boundaries_per_step=30,
+        boundary_source="profiles/r05_submit_probe.txt: a lone batch takes ~370 us where its launches' HIP-event times sum to 279 us; (370 - 279) / 30",
+        frac_ceiling_of_one_lane_with_free_kernels=round(step_bytes / (HBM_PEAK_GBS * 1e9) * 1e6 / (step_bytes / (HBM_PEAK_GBS * 1e9) * 1e6 + 90.0), 3),
+        cu_stream_gbs=130.0, late_block_weight_bytes_per_workgroup=1228800, late_block_stream_floor_us=9.6,
+        cu_stream_source="profiles/r05_cu_stream_microbench.txt (tools/micro/cu_stream.hip): one CU pulls L2-resident bytes at 110 - 143 GB/s; a workgroup of "
+                         "robust blocks 14 / 15 streams 1.23 MB of split weights = 9.6 us of its 16.5 us launch",
+        packing_bound_us_per_step=143.0,
+        packing_source="profiles/r05zz_lane_overlap_robust_one_lane.txt: duration x booked share of the chip's workgroup slots, summed over a batch's launches, alone")
     return roof
 
 
