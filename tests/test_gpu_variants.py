@@ -287,3 +287,34 @@ def test_stamps_build_writes_the_same_rows_and_sees_the_lanes_overlap(model_dir_
     assert out["launches"] == out["nodes"] == out["per_step"] == out["named"] and out["launches"] >= 25
     assert out["ordered"] and out["chain"]                              # every launch entered before it left, and left before its successor did
     assert out["dropped"] == 0 and out["in_flight"] > 2.0, out["in_flight"]
+
+
+def test_kernel_by_kernel_launches_write_the_same_rows_as_the_captured_graph(model_dir, tmp_path):
+    """`WZ_GRAPH=0` (one of the four operator settings of the product library, include/watsor_hip.h): the batch is enqueued kernel by kernel
+    instead of replaying the captured hipGraph -- the same launches with the same arguments, so the rows are bit-identical, batch after batch
+    (the frame descriptors travel as kernel arguments either way; with the graph they are rewritten in the captured node)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    script = (
+        "import sys, json, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from watsor_amd.runtime import HipEngine, ROW_DTYPE\n"
+        "from watsor_amd.synth import synthetic_frame\n"
+        "e = HipEngine(%r, 0, 8, 1280, 720)\n"
+        "out = []\n"
+        "for k, n in enumerate((8, 3, 8, 1)):\n"
+        "    frames = [synthetic_frame(*((640, 480) if (i + k) %% 2 else (1280, 720)), 9300 + 10 * k + i) for i in range(n)]\n"
+        "    rows = [np.zeros(100, ROW_DTYPE) for _ in frames]\n"
+        "    e.detect_batch(frames, rows)\n"
+        "    out.append(np.stack(rows).tobytes().hex())\n"
+        "print(json.dumps(dict(nodes=e.graph_nodes(0), rows=out)))\n"
+        "e.close()\n" % (conftest.ROOT, os.path.join(model_dir, "mi355x.bin")))
+    res = {}
+    for g in ("1", "0"):
+        p = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, WZ_GRAPH=g), capture_output=True, text=True, timeout=240)
+        assert p.returncode == 0, p.stderr[-1500:]
+        res[g] = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["1"]["nodes"] >= 25 and res["0"]["nodes"] == 0          # a captured graph / none
+    assert res["1"]["rows"] == res["0"]["rows"]
