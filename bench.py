@@ -1088,7 +1088,6 @@ def spawn_ranks(n, argv, poll_s=RANK_POLL_S):
     until gloo's timeout, i.e. for the driver's whole budget."""
     import signal
     import tempfile
-    import threading
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]

@@ -7,7 +7,7 @@ headline workload (BASELINE configs[1]: batches of 8 frames 640x480 resident in 
 records when its first workgroup entered and its last one left, on the device's constant 100 MHz clock (one clock for all XCDs).  From
 the (lane, step, launch) intervals of an UNPROFILED run it prints
 
-  * frames/s of this very run (the stamps cost ~1 %: compare with the product library's figure printed beside it),
+  * frames/s of this very run (the stamps cost ~2 %: compare with the product library's figure printed beside it),
   * kernels in flight: mean over the time the chip is busy, and the share of time at 0, 1, 2, 3, 4+,
   * per launch of a batch: kernel, workgroups, threads, registers, LDS, workgroups a CU holds (the runtime's occupancy calculator),
     mean duration under load, and its CU-SLOT-TIME: duration x the share of the chip's workgroup slots the launch books,
@@ -30,9 +30,8 @@ NUM_CUS = 256
 TICK_US = 0.01            # s_memrealtime: 100 MHz
 
 
-def collect(engine_path, steps, warm, batch, lanes_env=None):
+def collect(engine_path, steps, warm, batch):
     """-> (intervals [(lane, step, launch, t0_ticks, t1_ticks)], launches [dict], frames/s, ms per step, lanes)"""
-    import numpy as np
     from watsor_amd.runtime import HipEngine
     from watsor_amd.synth import synthetic_frame
     eng = HipEngine(engine_path, 0, batch, 640, 480, dev=True)
