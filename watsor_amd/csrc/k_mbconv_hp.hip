@@ -174,7 +174,7 @@ template <int NW, bool CS, bool STEM, int MPW, int MQW, int KCI, int NTO, int OC
 __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a) {
     static_assert(!LEAN || (CS && SH && !ONEPASS && !STEM), "lean: chunk-split, shared halo");
     static_assert(!LEAN || MQW == 1 || (OCC <= 2 && MPW == 4), "lean 4 x 8 tiles: the stride-1 10x10 blocks at one or two waves per SIMD");
-    static_assert(!CG || (LEAN && OCC <= 2), "channel groups over workgroups: the lean builds of the 10x10 maps");
+    static_assert(!CG || LEAN, "channel groups over workgroups: the lean builds (10x10 maps; round 5: the 19x19 maps at one or two frames)");
     extern __shared__ __attribute__((aligned(16))) unsigned char wz_hp_smem[];
     WZ_LANE_STAMP(a.dbg);
     const long long t_entry = WZ_HP_STAMPS ? __builtin_readcyclecounter() : 0;
@@ -676,8 +676,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
                 finish(acc[j][nt], sd[j][nt], opix[j], n4);
             }
         }
-    } else if constexpr (RROUNDS > 1 && MQW > 1) {
-        // lean 4 x 8 builds (the stride-1 10x10 blocks): MQW x NTO = 20 accumulator fragments per wave cross LDS in RROUNDS rounds of NH;
+    } else if constexpr (RROUNDS > 1 && (MQW > 1 || CG)) {
+        // lean builds whose accumulators cross LDS in rounds AND may share their block's chunks with other workgroups: the 4 x 8 builds of the
+        // stride-1 10x10 blocks (MQW x NTO = 20 fragments per wave) and, round 5, the 19x19 builds at four waves per SIMD when one or two frames
+        // leave the chip empty (NTO = 4 / 6 fragments in two rounds).  MQW x NTO accumulator fragments per wave cross LDS in RROUNDS rounds of NH;
         // fragment q = j * NTO + nt of a round is summed by wave q - r * NH in the order wave 0 .. NW - 1, as everywhere.  With channel
         // groups over workgroups (CG) the sums then go through the workspace like the 4 x 4 builds' (below): slabs, ticket, last arriver.
         constexpr int TF = MQW * NTO, NH = TF / RROUNDS;
@@ -948,6 +950,28 @@ static int wz_hp_launch(WzMbArgs a, int n, hipStream_t s, bool prepare) {
     return 1;
 }
 
+// Channel groups over workgroups for the 19x19 blocks (round 5; VERDICT r4 #6b): one frame is 25 tiles -- 25 workgroups on 256 CUs, each walking 12 - 18 chunks
+// over its eight waves in two or three passes.  With G workgroups per tile a wave walks one chunk; the groups' sums meet through the workspace like the 10x10
+// blocks' (ticket per tile, the last arriver adds the groups in group order: deterministic).  Only where the launch leaves the chip empty: at most 64 tiles
+// (one or two frames; 128 under the latency schedule), G the smallest number that gets a wave's walk down to one pass.
+// MEASURED AND OFF (WZ_HP_CG19=1 switches it on in the development library): correct (the whole GPU suite passes with it), but these launches are short --
+// 5.5 - 9 us -- and the trip of the groups' sums through the workspace costs more than the second chunk pass it saves: blocks 7 .. 10 5.6 -> 6.5 us at one
+// frame, 5.8 -> 7.4 at two; blocks 11 / 12 (18 chunks) 9.0 / 8.6 -> 8.0 / 7.8 at one frame; frames/s 11.7 -> 11.0 k (one frame), 21.0 -> 17.7 k (two);
+// profiles/r05_channel_groups_19x19.txt.
+static int wz_hp_cs19_groups(const WzMbArgs& a, int n, bool prepare) {
+    static const int on = wz_hp_env("WZ_HP_CG19", 0);
+    static const int cap = wz_hp_env("WZ_HP_CG19_TILES", wz_latency_schedule() ? 128 : 64);
+    const int units = ((a.hout + 3) / 4) * ((a.wout + 3) / 4) * n;
+    const int nto = a.n_pad / 16, nk32 = a.cmid_pad >> 5;
+    if (prepare || !on || !a.ws || !a.tickets || units > cap || units > WZ_HP_TICKETS || (size_t)units * 4 * nto * 1024 > (size_t)(a.ws_bytes >> 1)) return 1;
+    int G = 1, best = (nk32 + 7) / 8;
+    for (int g = 2; g <= 4; ++g) {
+        const int walk = ((nk32 + g - 1) / g + 7) / 8;
+        if (walk < best) { best = walk; G = g; }
+    }
+    return G;
+}
+
 // The ROBUST program (WzMbArgs::qenc, `python -m watsor_amd.engine --robust`): all 17 blocks on this kernel with the float-form chunk
 // buffer, one launch shape per block shape -- the throughput defaults of the dispatcher below, plus the lean builds for blocks 13 .. 16.
 static int wz_launch_mbconv_hp_q(WzMbArgs a, int n, hipStream_t s, bool prepare) {
@@ -968,7 +992,13 @@ static int wz_launch_mbconv_hp_q(WzMbArgs a, int n, hipStream_t s, bool prepare)
     }
     if (a.wout > 10) {
         if (a.stride == 2) return (a.kc0 == 1 && nto == 4) ? wz_hp_launch<6, true, false, 6, 1, 1, 4, 4, false, true, true, true>(a, n, s, prepare) : -1;
-        if (a.kc0 == 2 && nto == 4) return wz_hp_launch<8, true, false, 3, 1, 2, 4, 4, false, true, true, true>(a, n, s, prepare);
+        if (a.kc0 == 2 && nto == 4) {
+            const int G = wz_hp_cs19_groups(a, n, prepare);
+            if (prepare) (void)wz_hp_launch<8, true, false, 3, 1, 2, 4, 4, false, true, true, true, true>(a, n, s, true);
+            a.cgroups = G;
+            return G > 1 ? wz_hp_launch<8, true, false, 3, 1, 2, 4, 4, false, true, true, true, true>(a, n, s, false)
+                         : wz_hp_launch<8, true, false, 3, 1, 2, 4, 4, false, true, true, true>(a, n, s, prepare);
+        }
         if (a.kc0 == 2 && nto == 6) return wz_hp_launch<8, true, false, 3, 1, 2, 6, 4, false, true, true, true>(a, n, s, prepare);
         if (a.kc0 == 3 && nto == 6) return wz_hp_launch<8, true, false, 3, 1, 3, 6, 4, false, true, true, true>(a, n, s, prepare);
         return -1;
@@ -1198,6 +1228,7 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
     if (a.kc0 == K && nto == N) {                                                                             \
         if (prepare) {                                                                                        \
             (void)wz_hp_launch<8, true, false, 3, 1, K, N, 4, false, true, false, true>(a, n, s, true);      \
+            (void)wz_hp_launch<8, true, false, 3, 1, K, N, 4, false, true, false, true, true>(a, n, s, true); \
             (void)wz_hp_launch<3, true, false, 3, 1, K, N, 2, false, true>(a, n, s, true);                   \
             (void)wz_hp_launch<4, true, false, 3, 1, K, N, 2, false, true>(a, n, s, true);                   \
             (void)wz_hp_launch<5, true, false, 3, 1, K, N, 2, false, true>(a, n, s, true);                   \
@@ -1206,7 +1237,13 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
             if (K == 2) (void)wz_hp_launch<12, true, false, 3, 1, 2, N, 3, false, true>(a, n, s, true);      \
             return wz_hp_launch<HP_CS_WAVES, true, false, 3, 1, K, N>(a, n, s, true);                        \
         }                                                                                                     \
-        if (sh && cs19_lean4) { const int r = wz_hp_launch<8, true, false, 3, 1, K, N, 4, false, true, false, true>(a, n, s, false); if (r >= 0) return r; } \
+        if (sh && cs19_lean4) {                                                                               \
+            const int G = wz_hp_cs19_groups(a, n, false);                                                     \
+            a.cgroups = G;                                                                                    \
+            const int r = G > 1 ? wz_hp_launch<8, true, false, 3, 1, K, N, 4, false, true, false, true, true>(a, n, s, false) \
+                                : wz_hp_launch<8, true, false, 3, 1, K, N, 4, false, true, false, true>(a, n, s, false); \
+            if (r >= 0) return r;                                                                             \
+        }                                                                                                     \
         if (sh && cs19_nw == 3) { const int r = wz_hp_launch<3, true, false, 3, 1, K, N, 2, false, true>(a, n, s, false); if (r >= 0) return r; } \
         if (sh && cs19_nw == 5) { const int r = wz_hp_launch<5, true, false, 3, 1, K, N, 2, false, true>(a, n, s, false); if (r >= 0) return r; } \
         if (sh && cs19_nw == 4) { const int r = wz_hp_launch<4, true, false, 3, 1, K, N, 2, false, true>(a, n, s, false); if (r >= 0) return r; } \
