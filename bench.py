@@ -1075,7 +1075,7 @@ def note(msg):
         print("[bench %7.2fs] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
 
 
-RANK_START_TIMEOUT_S = 120     # rendezvous: a rank that is not there by then never will be (gloo's own default is 30 minutes)
+RANK_START_TIMEOUT_S = 300     # rendezvous: a rank that is not there by then never will be (gloo's own default is 30 minutes; the first `import torch` on a fresh box can take two)
 RANK_POLL_S = 0.2
 
 
