@@ -174,11 +174,18 @@ def test_latency_schedule_detects_the_same_objects(model_dir, tmp_path):
         " box=[np.stack([r['x_min'], r['y_min'], r['x_max'], r['y_max']], 1).tolist() for r in rows])))\n"
         "e.close()\n" % (conftest.ROOT, os.path.join(model_dir, "mi355x.bin"), os.path.join(model_dir, "mi355x.bin")))
     out = {}
-    env = {k: v for k, v in os.environ.items() if k != "WZ_SCHEDULE"}
-    for sched in ("throughput", "latency"):
-        p = subprocess.run([sys.executable, "-c", script, sched], env=env, capture_output=True, text=True, timeout=240)
+    env = {k: v for k, v in os.environ.items() if k not in ("WZ_SCHEDULE", "WZ_GRAPH")}
+    for sched in ("throughput", "latency"):     # (WZ_GRAPH=1: both on captured graphs, so that their node counts can be compared)
+        p = subprocess.run([sys.executable, "-c", script, sched], env=dict(env, WZ_GRAPH="1"), capture_output=True, text=True, timeout=240)
         assert p.returncode == 0, p.stderr[-1500:]
         out[sched] = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    # left to itself the latency schedule launches kernel by kernel (no graph: the GPU starts on the first kernel while the host issues the
+    # rest) -- the same launches, the same rows bit for bit
+    p = subprocess.run([sys.executable, "-c", script, "latency"], env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stderr[-1500:]
+    eager = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert eager["nodes"] == 0 and out["latency"]["nodes"] > 0
+    assert eager["label"] == out["latency"]["label"] and eager["conf"] == out["latency"]["conf"] and eager["box"] == out["latency"]["box"]
     a, b = out["throughput"], out["latency"]
     if model_dir.program == "default":
         assert b["nodes"] > a["nodes"]                               # the latency schedule keeps the reduce launches of blocks 13 .. 16

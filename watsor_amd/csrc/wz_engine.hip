@@ -895,7 +895,11 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     e->max_h = max_height;
     const char* env;
     e->no_reuse = (env = wz_dev_getenv("WZ_NO_BUFFER_REUSE")) && atoi(env) != 0;
-    e->use_graph = !((env = getenv("WZ_GRAPH")) && atoi(env) == 0);
+    // WZ_GRAPH=0|1 decides when set.  Unset: captured graphs under the throughput schedule (a batch is handed over in 10.5 us: one thread keeps four lanes
+    // fed), kernel-by-kernel launches under the LATENCY schedule -- the GPU starts on the first kernel while the host still issues the rest, and a lone
+    // batch is done 7 us sooner (0.380 -> 0.372 ms at batch 8, 0.2915 -> 0.2865 at batch 1; 84 us of host time per batch instead of 10, and 2 - 4 % of the
+    // saturated throughput: profiles/r05_submit_probe.txt)
+    e->use_graph = (env = getenv("WZ_GRAPH")) ? atoi(env) != 0 : !wz_latency_schedule();
     e->use_splitk = !((env = wz_dev_getenv("WZ_SPLITK")) && atoi(env) == 0);
     e->wide_frag = !((env = wz_dev_getenv("WZ_WIDE_FRAG")) && atoi(env) == 0);
     e->defer_heads = !((env = wz_dev_getenv("WZ_DEFER_HEADS")) && atoi(env) == 0);
