@@ -18,7 +18,8 @@
  * not retained past the call.
  *
  * Environment (read when the first engine of a process is created): WZ_LANES=1..8 (batches in flight, default 4), WZ_STREAMS (HIP
- * streams they ride, default = lanes, at most 4 pay), WZ_GRAPH=0|1 (launch kernel by kernel / replay a captured graph; unset: graphs under the throughput schedule, kernel by kernel under the latency schedule),
+ * streams they ride, default = lanes, at most 4 pay), WZ_GRAPH=0|1 (launch kernel by kernel / replay a captured graph; unset: under the throughput schedule a captured graph while another lane is busy and
+ * kernel by kernel for a batch that finds the other lanes idle, under the latency schedule always kernel by kernel),
  * WZ_SCHEDULE=latency (launch shapes for the shortest lone batch instead of the most frames per second with every lane busy).
  */
 #ifndef WATSOR_HIP_H

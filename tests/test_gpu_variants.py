@@ -230,8 +230,8 @@ def test_earlier_launch_shapes_detect_the_same_objects(model_dir_default, knobs)
         " box=[np.stack([r['x_min'], r['y_min'], r['x_max'], r['y_max']], 1).tolist() for r in rows])))\n"
         "e.close()\n" % (conftest.ROOT, os.path.join(model_dir, "mi355x.bin")))
     out = {}
-    for name, env in (("default", {}), ("earlier", knobs)):
-        p = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, **env), capture_output=True, text=True, timeout=240)
+    for name, env in (("default", {}), ("earlier", knobs)):     # (WZ_GRAPH=1: a lone batch would otherwise go kernel by kernel and report no graph)
+        p = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, WZ_GRAPH="1", **env), capture_output=True, text=True, timeout=240)
         assert p.returncode == 0, p.stderr[-1500:]
         out[name] = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     a, b = out["default"], out["earlier"]
@@ -286,7 +286,7 @@ def test_stamps_build_writes_the_same_rows_and_sees_the_lanes_overlap(model_dir_
         "out['in_flight'] = res['kernels_in_flight_mean_while_busy']; out['dropped'] = res['intervals_dropped']; out['per_step'] = res['launches_per_step']\n"
         "out['named'] = sum(1 for p in res['per_launch'] if p['workgroups'] > 0 and p['wg_per_cu'] > 0)\n"
         "print(json.dumps(out))\n" % (conftest.ROOT, os.path.join(conftest.ROOT, "tools"), os.path.join(model_dir_robust, "mi355x.bin")))
-    env = dict(os.environ, WATSOR_HIP_DEV_LIBRARY=stamps)
+    env = dict(os.environ, WATSOR_HIP_DEV_LIBRARY=stamps, WZ_GRAPH="1")      # (the launch notes are taken when the graph is captured)
     p = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
@@ -319,9 +319,13 @@ def test_kernel_by_kernel_launches_write_the_same_rows_as_the_captured_graph(mod
         "print(json.dumps(dict(nodes=e.graph_nodes(0), rows=out)))\n"
         "e.close()\n" % (conftest.ROOT, os.path.join(model_dir, "mi355x.bin")))
     res = {}
-    for g in ("1", "0"):
-        p = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, WZ_GRAPH=g), capture_output=True, text=True, timeout=240)
+    base = {k: v for k, v in os.environ.items() if k not in ("WZ_GRAPH", "WZ_SCHEDULE")}
+    for g in ("1", "0", None):
+        env = dict(base, WZ_GRAPH=g) if g is not None else base
+        p = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=240)
         assert p.returncode == 0, p.stderr[-1500:]
         res[g] = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert res["1"]["nodes"] >= 25 and res["0"]["nodes"] == 0          # a captured graph / none
     assert res["1"]["rows"] == res["0"]["rows"]
+    # nothing said (throughput schedule): a batch that finds the other lanes idle -- every batch of this child -- goes kernel by kernel as well
+    assert res[None]["nodes"] == 0 and res[None]["rows"] == res["1"]["rows"]

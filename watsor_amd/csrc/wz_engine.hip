@@ -74,6 +74,7 @@ struct wz_engine {
     const WzOpDesc* ops = nullptr;
     int max_batch = 0, max_w = 0, max_h = 0;
     bool no_reuse = false, use_graph = true, use_splitk = true;
+    bool graph_adaptive = false;   // use_graph && WZ_GRAPH unset: a batch that finds every other lane idle is launched kernel by kernel (wz_create)
     bool wide_frag = true;     // the wide head kernel's partial sums in fragment order (WZ_WIDE_FRAG=0: [slice][pixel][column])
     bool list_cands = true;    // WZ_LIST_CANDS=0: the self-scanning NMS kernel always scans
     bool post_self = true;     // WZ_POST_SELF=0: histogram + compaction kernels in front of the NMS kernel
@@ -648,7 +649,17 @@ static int run_batch(wz_engine* e, int slot, int n) {
     };
     const int key = n | (L.rows ? 1 << 16 : 0);
     L.key = key;
-    if (e->use_graph) {
+    bool graph = e->use_graph;
+    if (graph && e->graph_adaptive) {
+        // a LONE batch -- nothing in flight on any other lane -- is launched kernel by kernel: the GPU starts on the first kernel while the host issues the
+        // other 29 and the batch is done ~7 us sooner; with another lane busy the captured graph is replayed (10 us of host time instead of 84: what
+        // keeps one thread ahead of four lanes).  The same launches either way: the rows do not depend on it (tests/test_gpu_variants.py).
+        graph = false;
+        for (int li = 0; li < e->n_lanes && !graph; ++li)
+            if (li != slot && e->lanes[li].done && hipEventQuery(e->lanes[li].done) == hipErrorNotReady) graph = true;
+        (void)hipGetLastError();
+    }
+    if (graph) {
         auto it = L.graphs.find(key);
         if (it == L.graphs.end()) {
             hipGraph_t g = nullptr;
@@ -895,11 +906,12 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     e->max_h = max_height;
     const char* env;
     e->no_reuse = (env = wz_dev_getenv("WZ_NO_BUFFER_REUSE")) && atoi(env) != 0;
-    // WZ_GRAPH=0|1 decides when set.  Unset: captured graphs under the throughput schedule (a batch is handed over in 10.5 us: one thread keeps four lanes
-    // fed), kernel-by-kernel launches under the LATENCY schedule -- the GPU starts on the first kernel while the host still issues the rest, and a lone
+    // WZ_GRAPH=0|1 decides when set.  Unset: captured graphs under the throughput schedule WHILE ANOTHER LANE IS BUSY (a batch is handed over in 10.5 us: one
+    // thread keeps four lanes fed; a batch that finds the other lanes idle goes kernel by kernel: run_batch), kernel-by-kernel launches under the LATENCY schedule -- the GPU starts on the first kernel while the host still issues the rest, and a lone
     // batch is done 7 us sooner (0.380 -> 0.372 ms at batch 8, 0.2915 -> 0.2865 at batch 1; 84 us of host time per batch instead of 10, and 2 - 4 % of the
     // saturated throughput: profiles/r05_submit_probe.txt)
     e->use_graph = (env = getenv("WZ_GRAPH")) ? atoi(env) != 0 : !wz_latency_schedule();
+    e->graph_adaptive = e->use_graph && !getenv("WZ_GRAPH");   // (throughput schedule, nothing said: graphs while the lanes are busy, kernel by kernel for a lone batch)
     e->use_splitk = !((env = wz_dev_getenv("WZ_SPLITK")) && atoi(env) == 0);
     e->wide_frag = !((env = wz_dev_getenv("WZ_WIDE_FRAG")) && atoi(env) == 0);
     e->defer_heads = !((env = wz_dev_getenv("WZ_DEFER_HEADS")) && atoi(env) == 0);
