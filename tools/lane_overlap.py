@@ -208,6 +208,8 @@ def main():
         print("missing %s: make -C watsor_amd/csrc stamps" % STAMPS_LIB, file=sys.stderr)
         return 2
     os.environ["WATSOR_HIP_DEV_LIBRARY"] = STAMPS_LIB       # read when watsor_amd._lib is imported
+    os.environ.setdefault("WZ_GRAPH", "1")                  # what was launched is noted when the graph is captured: a batch that finds the other lanes idle
+                                                            # (every batch of a one-lane run) would otherwise go kernel by kernel and leave no notes
     from watsor_amd import engine as eb
     from watsor_amd.synth import synthetic_weights
     path = "/tmp/wz_lane_overlap_%d/mi355x.bin" % os.getpid()
