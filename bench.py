@@ -230,7 +230,7 @@ def roofline_object(table, overhead, single_table, inner):
         cu_stream_gbs=130.0, late_block_weight_bytes_per_workgroup=1228800, late_block_stream_floor_us=9.6,
         cu_stream_source="profiles/r05_cu_stream_microbench.txt (tools/micro/cu_stream.hip): one CU pulls L2-resident bytes at 110 - 143 GB/s; a workgroup of "
                          "robust blocks 14 / 15 streams 1.23 MB of split weights = 9.6 us of its 16.5 us launch",
-        packing_bound_us_per_step=143.0,
+        packing_bound_us_per_step=144.0,
         packing_source="profiles/r05zz_lane_overlap_robust_one_lane.txt: duration x booked share of the chip's workgroup slots, summed over a batch's launches, alone")
     return roof
 
