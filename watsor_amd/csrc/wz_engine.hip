@@ -83,7 +83,8 @@ struct wz_engine {
     bool conv_wide = true;     // the big SSD heads on the wide tile kernel (k_conv_wide.hip); WZ_CONV_WIDE=0: on wz_k_conv_rs
     int wide_min_m = 1;        // WZ_WIDE_MIN_M=n: heads with fewer output pixels than this (per batch) stay on wz_k_conv_group
     int wide_T = 0;            // WZ_WIDE_T=n: K steps per slice of that kernel (0: chosen per launch by wz_choose_wide_T)
-    bool tail_fuse = false;       // WZ_TAIL_FUSE=1: the convolutions on the <= 32-pixel maps in one launch (k_tail.hip); measured slower, off
+    int tail_fuse = 0;            // WZ_TAIL_FUSE=1: the convolutions on the <= 32-pixel maps in one launch (k_tail.hip); measured slower, off.
+                                  // 2 (round 5): only the chain behind the 3x3 map -- its last four convolutions, 0.8 MB of weights per frame's workgroup
     bool desc_by_value = true;    // the frame descriptors travel as arguments of the resize kernel (WZ_DESC_ARGS=0: zero-copy / copied)
     bool desc_zero_copy = true;   // the resize kernel reads the frame descriptors from page-locked host memory (WZ_DESC_COPY=1: copied first)
     bool pre_rows = false;        // WZ_PRE_ROWS=1: every batch on the row-staged form of the resize kernel (k_preprocess.hip:
@@ -363,7 +364,7 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
             // wrote -- WZ_TAIL_FUSE=1 runs them as ONE launch, a workgroup per frame (k_tail.hip).  Built, bit-compatible within fp32
             // summation order, and slower than the six launches it replaces (34 us against 23.5 us: HISTORY.md part B): off by default.
 #ifdef WZ_DEV_BUILD
-            if (!f32 && e->tail_fuse && op.out_mode == WZ_OUT_ACT) {
+            if (!f32 && e->tail_fuse && op.out_mode == WZ_OUT_ACT && (e->tail_fuse == 1 || op.hin * op.win <= 9)) {
                 WzTailArgs T;
                 T.n = 0;
                 for (uint32_t j = i; j < e->hdr.n_ops && T.n < WZ_TAIL_MAX; ++j) {
@@ -922,7 +923,7 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     e->conv_wide = !((env = wz_dev_getenv("WZ_CONV_WIDE")) && atoi(env) == 0);
     e->desc_zero_copy = !((env = wz_dev_getenv("WZ_DESC_COPY")) && atoi(env) != 0);
     e->desc_by_value = !((env = wz_dev_getenv("WZ_DESC_ARGS")) && atoi(env) == 0);
-    e->tail_fuse = (env = wz_dev_getenv("WZ_TAIL_FUSE")) && atoi(env) != 0;
+    e->tail_fuse = (env = wz_dev_getenv("WZ_TAIL_FUSE")) ? atoi(env) : 0;
     e->pre_rows = (env = wz_dev_getenv("WZ_PRE_ROWS")) ? atoi(env) != 0 : e->pre_rows;
     // WZ_SCHEDULE=latency: every page-locked frame is read in place -- a lone batch is done sooner without the staging copy in front of it
     // (640x480, batch 8: 0.505 against 0.575 ms) although the waiting workgroups cost frames/s with four lanes in flight (29.7 k against 34 k)
