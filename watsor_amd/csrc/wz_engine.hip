@@ -209,9 +209,11 @@ static unsigned long long* next_stamp(wz_engine::Lane& L) {
     return L.d_stamps + (size_t)(L.stamp_next++ - 1) * WZ_STAMP_WORDS;
 }
 #define WZ_STAMP_ARG(a) ((a).dbg = next_stamp(L))
+#define WZ_STAMP_ARG2(a) ((a).dbg2 = next_stamp(L))
 #define WZ_STAMP_GROUP(g) ((g).stamp = next_stamp(L))
 #else
 #define WZ_STAMP_ARG(a) ((void)0)
+#define WZ_STAMP_ARG2(a) ((void)0)
 #define WZ_STAMP_GROUP(g) ((void)0)
 #endif
 static bool tensor_is_pair(wz_engine* e, int idx) { return (e->tensors[idx].flags & WZ_TENSOR_HP) != 0; }
@@ -342,6 +344,18 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
             a.tickets = e->use_splitk ? L.d_tickets : nullptr;   // (channel groups over workgroups of the 10x10 split blocks: k_mbconv_hp.hip)
             a.dbg = e->d_mbdbg ? e->d_mbdbg + (size_t)i * 16 : nullptr;
             WZ_STAMP_ARG(a);
+            if (a.hp && wz_mbconv_hp2_applies(a, n)) {
+                // the 10x10 split blocks of the robust program from four frames up: two GEMM-shaped launches (k_mbconv_hp2.hip); the stage
+                // timer books the second one on the op's (otherwise empty) reduce slot
+                WZ_STAMP_ARG2(a);
+                int r2 = wz_launch_mbconv_hp2(a, n, s, false, 1);
+                if (t) t->mark();
+                if (r2 >= 0) r2 = wz_launch_mbconv_hp2(a, n, s, false, 2);
+                if (r2 < 0) L.launch_failed = (int)i + 1;
+                if (e->d_mbdbg) e->mb_groups[i] = 1;
+                if (t) t->mark();
+                continue;
+            }
             int groups = a.hp ? wz_launch_mbconv_hp(a, n, s, false)   // split-operand blocks (the `-p 16` program's first 13)
                               : wz_launch_mbconv_wave(a, n, s, false);   // large maps: one wavefront per pixel tile
             if (a.hp && groups < 0) L.launch_failed = (int)i + 1;   // nothing was enqueued for a split-operand block: run_batch reports it
