@@ -190,7 +190,9 @@ def test_latency_schedule_detects_the_same_objects(model_dir, tmp_path):
     if model_dir.program == "default":
         assert b["nodes"] > a["nodes"]                               # the latency schedule keeps the reduce launches of blocks 13 .. 16
     else:
-        assert b["nodes"] >= a["nodes"]                              # (robust: those blocks reduce inside their launch under both schedules)
+        # robust: the throughput schedule runs blocks 13 .. 16 as TWO launches each from four frames up (csrc/k_mbconv_hp2.hip), the latency
+        # schedule keeps the one-launch form with channel groups over workgroups
+        assert a["nodes"] == b["nodes"] + 4
     for f in range(8):
         ref = dict(label=np.array(a["label"][f], np.int32), confidence=np.array(a["conf"][f]), box=np.array(a["box"][f], np.int32))
         got = np.zeros(100, ROW_DTYPE)

@@ -271,7 +271,7 @@ def test_factory_lets_every_family_coexist_with_unique_names(reference_on_path, 
     # the AMD detectors got the factory's options as their third constructor argument
     args = dets[0]._kwargs["detector_args"] if hasattr(dets[0], "_kwargs") else None
     if args is not None:
-        assert args[0] == str(tmp_path) and args[1] == 0 and args[2].get("schedule") in ("latency", "throughput")
+        assert args[0] == str(tmp_path) and args[1] == 0 and args[2].get("schedule") in ("auto:latency", "auto:throughput")
 
 
 def test_worker_class_survives_the_spawn_start_method(reference_on_path):

@@ -64,7 +64,7 @@ class PacedDetector:
         return self.delay * 1000.0
 
 
-def build(reference_on_path, n_cameras, delays, source_sleep):
+def build(reference_on_path, n_cameras, delays, source_sleep, affinity=False):
     from logging import getLogger
     from logging.handlers import QueueHandler
     from multiprocessing import BoundedSemaphore, Event, Queue
@@ -126,9 +126,12 @@ def build(reference_on_path, n_cameras, delays, source_sleep):
         sieve.subscribe(sink_q)
         sources.append(src)
         procs += [src, sieve, sink]
+    from watsor_amd.detection.detector import camera_affinity
+    aff = camera_affinity(buffers, len(delays)) if affinity else None
     workers = [BatchedObjectDetector(Thread, "detector%d" % (i + 1), stop, log_queue,
                                      BalancedQueue(frame_queue, semaphores), buffers,                           # main.py:414-418
-                                     kwargs={'detector_class': PacedDetector, 'detector_args': ("", i, {"delay": d})})
+                                     kwargs=dict({'detector_class': PacedDetector, 'detector_args': ("", i, {"delay": d})},
+                                                 **({'hip_affinity': dict(aff, index=i)} if aff else {})))
                for i, d in enumerate(delays)]
     return stop, seen, sources, workers, procs + workers
 
@@ -189,3 +192,25 @@ def test_fast_workers_leave_the_sources_at_full_rate(reference_on_path):
     for c in range(4):
         assert per_cam[c] >= 0.9 * produced[c] - 2, (dict(per_cam), produced)
         assert produced[c] >= 30, produced                      # ~100 frames/s for 1.5 s, minus scheduling noise on a busy host
+
+
+def test_camera_affinity_on_the_reference_runtime(reference_on_path):
+    """`hip_affinity` under the reference's own queue, sources, frame buffers, latches, sieves and sinks: six cameras dealt to two
+    workers (cam0, 2, 4 -> worker 0; cam1, 3, 5 -> worker 1).  Whoever draws a payload from the ONE `BalancedQueue` (`main.py:414-418`),
+    its camera's OWNER detects it -- disjoint camera sets --, every payload exactly once, the rows the sinks see belong to the frame
+    they sit in (a latch stepped early or twice would break that), no camera deprived."""
+    PacedDetector.log = []
+    stop, seen, sources, workers, procs = build(reference_on_path, 6, delays=(0.004, 0.004), source_sleep=0.0005, affinity=True)
+    go(stop, procs, 2.0)
+    log = list(PacedDetector.log)
+    detected = [fid for _, ids in log for fid in ids]
+    assert len(detected) == len(set(detected)) and len(detected) > 100, len(detected)
+    for tag, ids in log:
+        assert all(cam % 2 == tag for cam, _ in ids), (tag, ids)                 # only the owner ever detects a camera's frames
+    assert len(seen) > 30
+    for cam, number, label, row_number in seen:
+        assert label == 1 + cam and row_number == number, (cam, number, label, row_number)
+    per_cam = Counter(cam for cam, _ in detected)
+    assert len(per_cam) == 6
+    counts = [per_cam[c] for c in range(6)]
+    assert pstdev(counts) <= max(15.0, 0.15 * mean(counts)), counts

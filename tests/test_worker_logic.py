@@ -215,10 +215,10 @@ def test_options_follow_the_frame_buffers(monkeypatch):
     monkeypatch.delenv("WATSOR_HIP_MAX_BATCH", raising=False)
     monkeypatch.delenv("WZ_SCHEDULE", raising=False)
     _, cams = setup(wide=2)
-    assert hip_detector_options(cams, {}) == {"max_width": 96, "max_height": 48, "schedule": "latency"}
+    assert hip_detector_options(cams, {}) == {"max_width": 96, "max_height": 48, "schedule": "auto:latency"}
     assert hip_detector_options(cams, {"hip_options": {"max_width": 4096, "max_batch": 16}}) == \
-        {"max_width": 4096, "max_height": 48, "max_batch": 16, "schedule": "latency"}
-    assert hip_detector_options({}, {}) == {"schedule": "throughput"}
+        {"max_width": 4096, "max_height": 48, "max_batch": 16, "schedule": "auto:latency"}
+    assert hip_detector_options({}, {}) == {"schedule": "auto:throughput"}
     # more than 8 cameras: batches of up to 16 unless the installation says otherwise
     many = {"cam%d" % i: cams["cam0"] for i in range(9)}
     assert hip_detector_options(many, {})["max_batch"] == 16
@@ -232,19 +232,89 @@ def test_options_follow_the_frame_buffers(monkeypatch):
 
 def test_schedule_is_chosen_by_the_number_of_cameras(monkeypatch):
     """`hip_options["schedule"]` = latency | throughput | auto.  auto (default): one queued frame per camera (`sync.py:156-166`) means
-    up to four cameras never fill the lanes -- the launch shapes that finish a lone batch soonest; more cameras: throughput.
-    An explicit option or WZ_SCHEDULE in the environment wins."""
+    two to four cameras never fill the lanes -- the launch shapes that finish a lone batch soonest; more cameras: throughput; ONE
+    camera: throughput as well (a lone frame goes kernel by kernel under either schedule -- same p50 -- and the throughput shapes carry
+    27 % more frames when the camera outruns the detector: bench.py legs).  What auto resolves to is a PREFERENCE
+    ("auto:<name>": a process whose schedule is fixed keeps it); an explicit option or WZ_SCHEDULE in the environment wins."""
     monkeypatch.delenv("WZ_SCHEDULE", raising=False)
     _, cams = setup()
-    few = {"cam%d" % i: cams["cam0"] for i in range(4)}
-    more = {"cam%d" % i: cams["cam0"] for i in range(5)}
-    assert hip_detector_options(few, {})["schedule"] == "latency"
-    assert hip_detector_options(more, {})["schedule"] == "throughput"
-    assert hip_detector_options(few, {"hip_options": {"schedule": "auto"}})["schedule"] == "latency"
-    assert hip_detector_options(few, {"hip_options": {"schedule": "throughput"}})["schedule"] == "throughput"
-    assert hip_detector_options(more, {"hip_options": {"schedule": "latency"}})["schedule"] == "latency"
+    n = lambda k: {"cam%d" % i: cams["cam0"] for i in range(k)}                  # noqa: E731
+    assert hip_detector_options(n(1), {})["schedule"] == "auto:throughput"
+    assert hip_detector_options(n(2), {})["schedule"] == "auto:latency"
+    assert hip_detector_options(n(4), {})["schedule"] == "auto:latency"
+    assert hip_detector_options(n(5), {})["schedule"] == "auto:throughput"
+    assert hip_detector_options(n(4), {"hip_options": {"schedule": "auto"}})["schedule"] == "auto:latency"
+    assert hip_detector_options(n(4), {"hip_options": {"schedule": "throughput"}})["schedule"] == "throughput"
+    assert hip_detector_options(n(5), {"hip_options": {"schedule": "latency"}})["schedule"] == "latency"
     monkeypatch.setenv("WZ_SCHEDULE", "throughput")
-    assert "schedule" not in hip_detector_options(few, {})                    # the operator's environment setting decides in the library
+    assert "schedule" not in hip_detector_options(n(4), {})                    # the operator's environment setting decides in the library
+
+
+def test_options_count_cameras_per_detector(monkeypatch):
+    """all detectors of a host pull from ONE queue (`watsor/main.py:414-418`), so what a detector sees is
+    ceil(cameras / detectors): 16 cameras on 8 GPUs are two per detector (latency shapes, the plugin's batch of 8), 12 cameras on
+    2 GPUs six each (throughput, 8), 20 on 2 ten each (throughput, 16)."""
+    monkeypatch.delenv("WATSOR_HIP_MAX_BATCH", raising=False)
+    monkeypatch.delenv("WZ_SCHEDULE", raising=False)
+    _, cams = setup()
+    n = lambda k: {"cam%d" % i: cams["cam0"] for i in range(k)}                  # noqa: E731
+    o = hip_detector_options(n(16), {}, 8)
+    assert o["schedule"] == "auto:latency" and "max_batch" not in o
+    o = hip_detector_options(n(12), {}, 2)
+    assert o["schedule"] == "auto:throughput" and "max_batch" not in o
+    o = hip_detector_options(n(20), {}, 2)
+    assert o["schedule"] == "auto:throughput" and o["max_batch"] == 16
+    o = hip_detector_options(n(16), {})                                          # one detector: as before
+    assert o["schedule"] == "auto:throughput" and o["max_batch"] == 16
+
+
+class AffinityDetector(ScriptedDetector):
+    """Remembers which cameras it was asked to bind and which frames it was given."""
+
+    def __init__(self):
+        super().__init__()
+        self.bound, self.seen = None, []
+
+    def bind_cameras(self, frame_buffers, camera_configs=None, drop=False, logger=None):
+        self.bound = sorted(frame_buffers)
+        return super().bind_cameras(frame_buffers, camera_configs, drop, logger)
+
+    def submit_host(self, lane, images, cameras=None):
+        self.seen += [int(im.reshape(-1)[0]) // 10 for im in images]
+        super().submit_host(lane, images, cameras)
+
+
+def test_camera_affinity_deals_whole_cameras_and_latches_exactly_once():
+    """`kwargs['hip_affinity']` (north star: "whole cameras are hashed across the 8 GPUs"; the reference has ONE queue for all
+    detectors, `watsor/main.py:414-418`): two workers on one shared queue, six cameras dealt round-robin.  Each worker binds only its
+    own cameras' frame buffers, every payload is processed by its camera's owner -- whoever drew it from the shared queue -- and every
+    payload's latch is stepped exactly once."""
+    from watsor_amd.detection.detector import camera_affinity
+    ctx, cams = setup(6)
+    aff = camera_affinity(cams, 2, queue_factory=queue.Queue)
+    assert aff["owners"] == {"cam0": 0, "cam1": 1, "cam2": 0, "cam3": 1, "cam4": 0, "cam5": 1} and len(aff["side"]) == 2
+    shared = queue.Queue()
+    workers = [Worker(), Worker()]
+    dets = [AffinityDetector(), AffinityDetector()]
+    gauges = [(shm.Gauge(ctx), shm.Gauge(ctx)) for _ in workers]
+    payloads = [shm.Payload("cam%d" % c, i) for i in range(4) for c in range(6)]          # 24 payloads, every frame of every camera once
+    for p in payloads:
+        shared.put(p)
+    for _ in range(200):                                                                   # the two workers take turns on the one queue
+        for k, (w, d) in enumerate(zip(workers, dets)):
+            w._process(shared, None, cams, gauges[k][0], gauges[k][1], d, hip_affinity=dict(aff, index=k))
+        if shared.empty() and all(q.empty() for q in aff["side"]) and not any(w._hip_worker_state["inflight"] for w in workers):
+            break
+    for k, w in enumerate(workers):
+        w.drain(*gauges[k])
+    assert dets[0].bound == ["cam0", "cam2", "cam4"] and dets[1].bound == ["cam1", "cam3", "cam5"]      # disjoint camera sets
+    assert sorted(set(dets[0].seen)) == [0, 2, 4] and sorted(set(dets[1].seen)) == [1, 3, 5]
+    assert len(dets[0].seen) == 12 and len(dets[1].seen) == 12
+    for c in range(6):
+        for f in cams["cam%d" % c].frames:
+            assert f.latch.steps.value == 1                                                # exactly once, by the owner
+    assert sum(w._hip_worker_state.get("forwarded", 0) for w in workers) > 0              # (payloads really changed hands)
+    assert gauges[0][0].count.value + gauges[1][0].count.value == 24
 
 
 def test_plain_plugin_without_batch_or_async_api():

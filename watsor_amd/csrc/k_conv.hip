@@ -564,11 +564,20 @@ __global__ __launch_bounds__(256) void wz_k_splitk_reduce_group(const WzReduceGr
         zstride = (size_t)a.M * a.n_pad;
     }
     if (n4 >= a.cout) return;   // padding columns: nothing is stored for them (and the wide tile kernel does not write their partials)
+    // the slices in groups of four: a group's loads are all requested before the first add (one memory latency per four slices instead of one
+    // per slice -- the launch is bound by exactly that chain); the adds stay in slice order 0, 1, 2 ...: bit-identical sums
     float4_t v = {0.f, 0.f, 0.f, 0.f};
-    for (int z = 0; z < a.splitk; ++z) {
-        const float4_t p = *reinterpret_cast<const float4_t*>(ws + (size_t)z * zstride + off);
+    for (int z0 = 0; z0 < a.splitk; z0 += 4) {
+        float4_t p[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += p[r];
+        for (int k = 0; k < 4; ++k)
+            p[k] = z0 + k < a.splitk ? *reinterpret_cast<const float4_t*>(ws + (size_t)(z0 + k) * zstride + off) : (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (z0 + k < a.splitk) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += p[k][r];
+            }
     }
     wz_head_finish(a, m, n4, v, g.list != 0, g.decode != 0, g.hint_logit, g.cbits, g.cbits_words, g.pc, g.anchors, g.boxes, g.valid);
 }

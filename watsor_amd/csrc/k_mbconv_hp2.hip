@@ -390,7 +390,7 @@ int wz_mbconv_hp2_applies(const WzMbArgs& a, int n) {
 // phase 0: both launches; 1: launch A only; 2: launch B only (the engine's stage timer brackets them separately).  prepare: kernel attributes.
 int wz_launch_mbconv_hp2(const WzMbArgs& a, int n, hipStream_t s, bool prepare, int phase) {
     static const int nw1 = wz_hp2_env("WZ_HP2_NW1", 4), nw2 = wz_hp2_env("WZ_HP2_NW2", 4);
-    static const int mt = wz_hp2_env("WZ_HP2_MT", 2);
+    static const int mt = wz_hp2_env("WZ_HP2_MT", 1);   // pixel tiles per workgroup of launch B: 1 (122 registers: two workgroups per CU) or 2
     int ra = 1, rb = 1;
     if (prepare || phase != 2) {
         if (a.stride == 1 && a.kc0 == 5) {

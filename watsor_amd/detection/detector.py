@@ -80,10 +80,20 @@ class BatchedWorkerMixin:
         st = getattr(self, "_hip_worker_state", None)
         if st is not None and st["detector"] is object_detector:
             return st
-        st = dict(detector=object_detector, inflight=deque(), next_lane=0, cams=None, lanes=1, asynchronous=False, table=None,
+        st = dict(detector=object_detector, inflight=deque(), next_lane=0, cams=None, lanes=1, asynchronous=False, table=None, affinity=None,
                   limit=getattr(object_detector, "max_batch", 1) if hasattr(object_detector, "detect_batch") else 1,
                   last_retire=0.0, acc_ms=0.0, acc_frames=0, last_flush=0.0,
                   metric_interval=float(kwargs.get("hip_metric_interval", 0.005)))
+        aff = kwargs.get("hip_affinity")
+        if isinstance(aff, dict) and aff.get("count", 1) > 1:
+            # camera affinity (`create_object_detectors(..., kwargs={'hip_affinity': True})`): this detector owns the cameras the factory dealt
+            # to it and binds / page-locks THEIR frame buffers only; payloads of other cameras that it draws from the shared queue are
+            # handed to their owner's side queue (`_gather_with_affinity`)
+            st["affinity"] = aff
+            frame_buffers = {n: fb for n, fb in frame_buffers.items() if aff["owners"].get(n, aff["index"]) == aff["index"]}
+            st["own_cameras"] = sorted(str(n) for n in frame_buffers)
+            self._info("camera affinity: detector %d of %d serves %d cameras (%s)" % (
+                aff["index"] + 1, aff["count"], len(frame_buffers), ", ".join(st["own_cameras"][:8]) + (" ..." if len(frame_buffers) > 8 else "")))
         bind = getattr(object_detector, "bind_cameras", None)
         if bind is not None:
             st["cams"] = bind(frame_buffers, kwargs.get("hip_cameras"), bool(kwargs.get("hip_drop", False)),
@@ -106,18 +116,21 @@ class BatchedWorkerMixin:
             st = self._hip_state(frame_buffers, object_detector, kwargs)
         inflight = st["inflight"]
         payloads = []
-        try:
-            # block for a frame only when nothing is in flight: a batch on the GPU is retired as soon as the queue runs dry
-            first = frame_queue.get(timeout=1) if not inflight else frame_queue.get_nowait()
-            if first is not None:
-                payloads.append(first)
-                get_nowait, limit = frame_queue.get_nowait, st["limit"]
-                while len(payloads) < limit:
-                    nxt = get_nowait()
-                    if nxt is not None:
-                        payloads.append(nxt)
-        except Empty:
-            pass
+        if st["affinity"] is not None:
+            payloads = self._gather_with_affinity(st, frame_queue, block=not inflight)
+        else:
+            try:
+                # block for a frame only when nothing is in flight: a batch on the GPU is retired as soon as the queue runs dry
+                first = frame_queue.get(timeout=1) if not inflight else frame_queue.get_nowait()
+                if first is not None:
+                    payloads.append(first)
+                    get_nowait, limit = frame_queue.get_nowait, st["limit"]
+                    while len(payloads) < limit:
+                        nxt = get_nowait()
+                        if nxt is not None:
+                            payloads.append(nxt)
+            except Empty:
+                pass
         if payloads:
             if st["asynchronous"]:
                 self._submit_frames(st, payloads, frame_buffers, fps, inference_time, object_detector)
@@ -129,6 +142,46 @@ class BatchedWorkerMixin:
             if st["acc_frames"]:
                 self._observe(st, inference_time, 0.0, 0, perf_counter(), flush=True)
             return self._no_frame(stop_event, frame_buffers, fps, inference_time, object_detector, *args, **kwargs)
+
+    # -- camera affinity: one shared queue, one owner per camera -------------------------------------------------------
+    AFFINITY_POLL_S = 0.002
+
+    def _gather_with_affinity(self, st, frame_queue, block):
+        """The payloads of THIS detector's cameras, up to the batch limit: first what the other detectors handed over (side queue), then
+        the shared queue -- whose `get` releases the camera's semaphore exactly as in the reference (`watsor/stream/sync.py:156-166`), so
+        the decoder may queue its next frame -- keeping what is ours and passing the rest to its owner's side queue.  Nothing is
+        latched here: the owner steps the latch of every payload it processes, once.  With nothing in flight the shared queue is
+        polled every AFFINITY_POLL_S (two sources cannot both be blocked on)."""
+        aff = st["affinity"]
+        me, owners, sides = aff["index"], aff["owners"], aff["side"]
+        mine, limit = [], st["limit"]
+        side = sides[me]
+        try:
+            while len(mine) < limit:
+                mine.append(side.get_nowait())
+        except Empty:
+            pass
+        first = True
+        while len(mine) < limit:
+            try:
+                p = frame_queue.get(timeout=self.AFFINITY_POLL_S) if (first and block and not mine) else frame_queue.get_nowait()
+            except Empty:
+                break
+            first = False
+            if p is None:
+                continue
+            k = owners.get(getattr(p, "sender", None), me)      # (an unknown sender stays here and is dropped with the usual warning)
+            if k == me:
+                mine.append(p)
+            else:
+                sides[k].put(p)
+                st["forwarded"] = st.get("forwarded", 0) + 1
+        return mine
+
+    def _info(self, msg):
+        logger = getattr(self, "_logger", None)
+        if logger is not None:
+            logger.info(msg)
 
     # -- synchronous path (any plugin with detect(); detect_batch() when it has one) --------------------------------
     def _resolve(self, payloads, frame_buffers):
@@ -328,11 +381,14 @@ def __getattr__(name):        # `from watsor_amd.detection.detector import Batch
     raise AttributeError("module %r has no attribute %r" % (__name__, name))
 
 
-def hip_detector_options(frame_buffers, kwargs):
+def hip_detector_options(frame_buffers, kwargs, n_detectors=1):
     """The third positional argument of `HipObjectDetector`: what the engine has to reserve, derived from the cameras
     this process is given (the largest frame of any `FrameBuffer`, `watsor/stream/share.py:27-31`) instead of from
-    environment defaults -- a 4K camera must not kill the worker with WZ_ELIMIT on its first frame."""
+    environment defaults -- a 4K camera must not kill the worker with WZ_ELIMIT on its first frame.
+    `n_detectors`: AMD detector processes that share these cameras' one queue (`watsor/main.py:414-418`): batch size and schedule
+    follow the cameras PER DETECTOR, ceil(cameras / detectors) -- 16 cameras on an 8-GPU host are two per detector, not sixteen."""
     opts = dict(kwargs.get("hip_options") or {})
+    per_detector = -(-len(frame_buffers) // max(1, int(n_detectors)))
     widths, heights = [], []
     for fb in frame_buffers.values():
         for frame in fb.frames[:1]:
@@ -347,18 +403,38 @@ def hip_detector_options(frame_buffers, kwargs):
     # only matters once that many frames are waiting -- and then one batch of 16 is both faster and sooner done than two of 8
     # (16 cameras, one MI355X: 40.1 k frames/s at 0.24 ms enqueue-to-latch against 34.1 k at 1.31 ms).
     # An operator's own setting -- `hip_options["max_batch"]` or WATSOR_HIP_MAX_BATCH -- is left alone.
-    if len(frame_buffers) > 8 and "max_batch" not in opts and not os.environ.get("WATSOR_HIP_MAX_BATCH"):
+    if per_detector > 8 and "max_batch" not in opts and not os.environ.get("WATSOR_HIP_MAX_BATCH"):
         opts["max_batch"] = 16
     # The schedule: "auto" (or nothing) -> by the number of cameras this detector serves.  `BalancedQueue` holds one queued frame per
-    # camera (`watsor/stream/sync.py:156-166`), so with up to 4 cameras a batch is 1 - 4 frames and at most one or two are in flight:
-    # the launch shapes that finish a lone batch soonest are the right ones (one frame: 0.35 -> 0.30 ms per detect()); with more
-    # cameras the lanes fill and the throughput shapes give 5 - 9 % more frames per second.
+    # camera (`watsor/stream/sync.py:156-166`), so with 2 - 4 cameras a batch is 2 - 4 frames and at most one or two are in flight:
+    # the launch shapes that finish a lone batch soonest are the right ones (a lone batch of four host frames 0.434 -> 0.394 ms); with
+    # more cameras the lanes fill and the throughput shapes give 5 - 9 % more frames per second.  ONE camera:
+    # a lone frame is launched kernel by kernel under either schedule and takes the same time (p50 0.286 ms both ways), while the
+    # throughput shapes carry 27 % more frames when the camera is faster than the detector (11 765 against 9 284 frames/s,
+    # bench.py legs.latency_schedule_b8 / config3_1x720p_b1) -- so one camera gets throughput.  The decision is a PREFERENCE
+    # ("auto:<name>"): a process whose schedule is already fixed keeps it (HipObjectDetector logs the fact instead of raising).
     if str(opts.get("schedule") or "auto").lower() == "auto" and not os.environ.get("WZ_SCHEDULE"):
-        opts["schedule"] = "latency" if 0 < len(frame_buffers) <= LATENCY_SCHEDULE_MAX_CAMERAS else "throughput"
+        opts["schedule"] = "auto:latency" if LATENCY_SCHEDULE_MIN_CAMERAS <= per_detector <= LATENCY_SCHEDULE_MAX_CAMERAS else "auto:throughput"
     return opts
 
 
+LATENCY_SCHEDULE_MIN_CAMERAS = 2
 LATENCY_SCHEDULE_MAX_CAMERAS = 4
+
+
+def camera_affinity(frame_buffers, n_detectors, queue_factory=None):
+    """Deals whole cameras to `n_detectors` detector processes, round-robin in the order of `frame_buffers` (the order of the
+    configuration's camera list, `watsor/main.py:357-414`): {"count", "owners": {camera: detector index}, "side": one queue per
+    detector}.  The reference has ONE shared queue for all detectors (`main.py:414-418`) and its decoders hold references to it, so
+    the routing happens on the consumer side: a detector that draws another one's camera from the shared queue passes the payload to
+    the owner's side queue (`BatchedWorkerMixin._gather_with_affinity`) -- one more hop for (n - 1) / n of the frames, in exchange
+    for every frame buffer being page-locked and bound by ONE process, the one pinned to its GPU's NUMA node."""
+    if queue_factory is None:
+        import multiprocessing
+        queue_factory = multiprocessing.Queue
+    names = list(frame_buffers)
+    return dict(count=int(n_detectors), owners={n: i % int(n_detectors) for i, n in enumerate(names)},
+                side=[queue_factory() for _ in range(int(n_detectors))])
 
 
 def create_object_detectors(delegate_class, stop_event, log_queue, frame_queue, frame_buffers, model_path,
@@ -377,19 +453,31 @@ def create_object_detectors(delegate_class, stop_event, log_queue, frame_queue, 
                    numa= True | False | "auto" (default: pin each detector process to its GPU's NUMA node on multi-GPU hosts)
       hip_lanes    batches kept in flight per GPU by the worker (default: the engine's lanes, 4)
       hip_metric_interval  seconds of batches folded into one `inference_time` observation (default 0.005; 0: one per batch)
-      hip_frame_table      False: describe the frames of every batch to the engine instead of binding them once"""
+      hip_frame_table      False: describe the frames of every batch to the engine instead of binding them once
+      hip_affinity         True (several AMD GPUs): whole cameras are dealt to the detectors (`camera_affinity`): a detector binds and
+                           page-locks only its own cameras' frame buffers; payloads drawn by the wrong detector are passed on"""
     _ref = _require_watsor()
     detectors = []
     if kwargs is None:
         kwargs = {}
 
     if path.isfile(path.join(model_path, ENGINE_FILE)):
-        options = hip_detector_options(frame_buffers, kwargs)
+        gpus = list(hip_gpus())
         BatchedObjectDetector = _batched_object_detector()
-        for device, clazz in hip_gpus():
+        affinity = camera_affinity(frame_buffers, len(gpus)) if (kwargs.get("hip_affinity") and len(gpus) > 1) else None
+        for k, (device, clazz) in enumerate(gpus):
+            kw = {key: v for key, v in kwargs.items() if key != "hip_affinity"}
+            if affinity is not None:
+                # whole cameras are dealt to the GPUs (north star: "whole cameras are hashed across the 8 GPUs"): detector k sizes its
+                # engine for, binds and page-locks ITS cameras only
+                own = {n: fb for n, fb in frame_buffers.items() if affinity["owners"][n] == k}
+                options = hip_detector_options(own, kwargs, 1)
+                kw["hip_affinity"] = dict(affinity, index=k)
+            else:
+                options = hip_detector_options(frame_buffers, kwargs, len(gpus))
             detectors.append(BatchedObjectDetector(
                 delegate_class, "detector{}".format(len(detectors) + 1), stop_event, log_queue, frame_queue,
-                frame_buffers, kwargs={**kwargs, 'detector_class': clazz, 'detector_args': (model_path, device, options)}))
+                frame_buffers, kwargs={**kw, 'detector_class': clazz, 'detector_args': (model_path, device, options)}))
 
     # The reference's own gates run as they always do (`detector.py:40-50`): Coral for edgetpu.tflite, CUDA for gpu.trt, CPU when
     # `_ALWAYS_USE_CPU` is set or NOTHING was found so far -- and the detectors they add continue the count ("detector3" after two AMD

@@ -74,11 +74,26 @@ class HipObjectDetector:
         if not os.path.isfile(engine_path):
             raise FileNotFoundError(engine_path)
         options = options or {}
-        schedule = options.get("schedule") or "auto"
-        if str(schedule).lower() not in ("auto", "latency", "throughput"):
-            raise ValueError("schedule %r: expected latency, throughput or auto" % (schedule,))
-        schedule = None if str(schedule).lower() == "auto" else str(schedule).lower()
+        schedule = str(options.get("schedule") or "auto").lower()
+        if schedule not in ("auto", "latency", "throughput", "auto:latency", "auto:throughput"):
+            raise ValueError("schedule %r: expected latency, throughput or auto" % (options.get("schedule"),))
+        # "auto:<name>" (what the factory's `auto` resolves to) is a PREFERENCE: the schedule is the process's (wz_set_schedule), and a
+        # process that has fixed the other one already -- Thread delegates, an engine or filter created earlier, a second factory
+        # call -- keeps it; only an operator's explicit "latency" / "throughput" is a demand (ValueError when it cannot be met)
+        soft = schedule.startswith("auto:")
+        schedule = None if schedule == "auto" else schedule.split(":")[-1]
+        self.schedule_note = None
+        if soft:
+            from ..runtime import get_schedule, set_schedule
+            try:
+                set_schedule(schedule)
+            except ValueError:
+                self.schedule_note = "schedule %r preferred for this camera count, %r already in force in this process: kept" % (schedule, get_schedule())
+                import logging
+                logging.getLogger(__name__).info(self.schedule_note)
+            schedule = None
         self.numa = None
+        self.arena_nodes = None
         numa = options.get("numa", "auto")
         if numa is True or (numa == "auto" and self._several_gpus()):
             from ..numa import pin_to_gpu_node
@@ -136,6 +151,9 @@ class HipObjectDetector:
         finally:
             self.__pinned = []
             self.__engine.close()
+            if self.numa:
+                from ..numa import restore_affinity
+                restore_affinity(self.numa)
 
     # -- what `BatchedObjectDetector` uses inside the worker process ----------------------------------------------------
     @property
@@ -163,16 +181,21 @@ class HipObjectDetector:
             if name in ids:
                 self.__filters.append(HipCameraFilter(self.__engine, ids[name], cfg, drop=drop))
         import ctypes
-        for fb in frame_buffers.values():
+        arenas = {}
+        for cam_name, fb in frame_buffers.items():
             for frame in fb.frames:
                 obj = frame.image.get_obj() if hasattr(frame.image, "get_obj") else frame.image
                 addr, size = ctypes.addressof(obj), ctypes.sizeof(obj)
+                arenas.setdefault(cam_name, addr)
                 try:
                     self.__engine.host_register_address(addr, size)
                     self.__pinned.append(addr)
                 except (RuntimeError, ValueError) as e:      # still correct, just not DMA speed
                     if logger is not None:
                         logger.warning("frame memory at 0x%x could not be page-locked: %s" % (addr, e))
+        if self.numa is not None:      # (multi-GPU hosts: where do the frames this detector will DMA from actually live?)
+            from ..numa import report_arena_nodes
+            self.arena_nodes = report_arena_nodes(arenas, self.numa.get("numa_node", -1), logger)
         return ids
 
     def bind_frame_table(self, frame_buffers, ids):
