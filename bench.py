@@ -134,9 +134,37 @@ def aggregate_stages(stages, ops, n, frame_bytes, size, hp_blocks, inner):
     def slot(k):
         return agg.setdefault(k, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, min_bytes=0.0))
 
+    # split blocks that ran as TWO launches (csrc/k_mbconv_hp2.hip: blocks 13 .. 16 of the robust program from four frames up): the op's own slot holds
+    # launch A (expand + depthwise), its "#splitk_reduce" slot launch B (the project GEMM); the per-layer rule's bytes are dealt accordingly
+    two_launch = set()
+    for name, ms in stages:
+        base = name[:-len("#splitk_reduce")] if name.endswith("#splitk_reduce") else None
+        if base in by_name and by_name[base]["kind"] == arch.OP_MBCONV and mb_index.get(base, 1 << 30) < hp_blocks and \
+                by_name[base]["wout"] <= 10 and max(ms - overhead, 0.0) / inner >= 5e-4:
+            two_launch.add(base)
+
+    def project_cost(o):
+        M = n * o["hout"] * o["wout"]
+        return 2.0 * M * o["cmid"] * o["cout"], 2.0 * (M * o["cmid"] + o["cmid"] * o["cout"] + M * o["cout"])
+
     for name, ms in stages:
         post = name.startswith("post/") or name in ("(empty)", "h2d_descriptors")
         ms = max(ms - overhead, 0.0) / (1 if post else inner)
+        if name.endswith("#splitk_reduce") and name[:-len("#splitk_reduce")] in two_launch:
+            o = by_name[name[:-len("#splitk_reduce")]]
+            fl, by = project_cost(o)
+            a = slot("wz_k_hp2_proj")
+            a["ms"] += ms; a["flops"] += fl; a["bytes"] += by; a["launches"] += 1
+            a["min_bytes"] += 4.0 * (n * o["hout"] * o["wout"] * o["cmid"] + o["cmid"] * o["cout"]) + (2.0 if o["name"].endswith("_16") else 4.0) * n * o["hout"] * o["wout"] * o["cout"]
+            continue
+        if name in two_launch:
+            o = by_name[name]
+            fl, by = algorithmic_cost(o, n)
+            pf, pb = project_cost(o)
+            a = slot("wz_k_hp2_expdw")
+            a["ms"] += ms; a["flops"] += fl - pf; a["bytes"] += by - pb; a["launches"] += 1
+            a["min_bytes"] += 4.0 * (n * o["hin"] * o["win"] * o["cin"] + o["cin"] * o["cmid"] + 9 * o["cmid"] + n * o["hout"] * o["wout"] * o["cmid"])
+            continue
         if name.endswith("#splitk_reduce"):
             k, fl, by = "wz_k_splitk_reduce", 0.0, 0.0
             if ms < 5e-4:
@@ -185,7 +213,7 @@ def aggregate_stages(stages, ops, n, frame_bytes, size, hp_blocks, inner):
     return table, overhead
 
 
-def roofline_object(table, overhead, single_table, inner):
+def roofline_object(table, overhead, single_table, inner, robust=False):
     """The JSON `roofline` object for the dominant kernel class of the step."""
     dom = table[0]
     if dom["bound"] == "hbm":
@@ -209,7 +237,7 @@ def roofline_object(table, overhead, single_table, inner):
     single = {r["kernel"]: r for r in single_table}.get(dom["kernel"])
     if single:       # the same kernel with ONE launch per bracket (the cost of the event pair estimated, not amortised)
         roof["avg_launch_us_single_bracket"] = round(single["avg_us"], 3)
-    sk = skeleton_ratio(dom["kernel"], dom["launches"])
+    sk = skeleton_ratio(dom["kernel"], dom["launches"], robust)
     if sk:           # what the same launches take with their arithmetic removed (committed measurement, profiles/hp_skeleton.json): the
         roof["arithmetic_free_skeleton"] = sk      # ceiling of THIS decomposition into tiles and chunks -- frac could rise by that ratio at most
         roof["frac_if_arithmetic_were_free"] = round(roof["frac"] * sk["real_over_skeleton"], 5)
@@ -224,14 +252,15 @@ def roofline_object(table, overhead, single_table, inner):
     roof["limits"] = dict(
         whole_step_algorithmic_bytes=round(step_bytes),
         whole_step_us_at_hbm_peak=round(step_bytes / (HBM_PEAK_GBS * 1e9) * 1e6, 1),
-        in_stream_boundary_us=3.0, boundaries_per_step=30,
-        boundary_source="profiles/r05_submit_probe.txt: a lone batch takes ~370 us where its launches' HIP-event times sum to 279 us; (370 - 279) / 30",
-        frac_ceiling_of_one_lane_with_free_kernels=round(step_bytes / (HBM_PEAK_GBS * 1e9) * 1e6 / (step_bytes / (HBM_PEAK_GBS * 1e9) * 1e6 + 90.0), 3),
-        cu_stream_gbs=130.0, late_block_weight_bytes_per_workgroup=1228800, late_block_stream_floor_us=9.6,
-        cu_stream_source="profiles/r05_cu_stream_microbench.txt (tools/micro/cu_stream.hip): one CU pulls L2-resident bytes at 110 - 143 GB/s; a workgroup of "
-                         "robust blocks 14 / 15 streams 1.23 MB of split weights = 9.6 us of its 16.5 us launch",
-        packing_bound_us_per_step=144.0,
-        packing_source="profiles/r05zz_lane_overlap_robust_one_lane.txt: duration x booked share of the chip's workgroup slots, summed over a batch's launches, alone")
+        # the entries below are STATIC: read off committed profiles of round 6, not measured by this run
+        static_from_profiles=True,
+        in_stream_boundary_us=2.0, boundaries_per_step=33,
+        boundary_source="profiles/r06_boundary_in_engine_graph.txt (in-kernel stamps, one lane): 65.5 us of gaps over the 33 boundaries of a lone batch; "
+                        "profiles/r06_boundary_microbench.txt: 1.05 us between trivial kernels of a captured graph on the same box, + 0.125 us per MB the predecessor leaves dirty",
+        frac_ceiling_of_one_lane_with_free_kernels=round(step_bytes / (HBM_PEAK_GBS * 1e9) * 1e6 / (step_bytes / (HBM_PEAK_GBS * 1e9) * 1e6 + 66.0), 3),
+        cu_stream_gbs=130.0,
+        cu_stream_source="profiles/r05_cu_stream_microbench.txt (tools/micro/cu_stream.hip): one CU pulls L2-resident bytes at 110 - 143 GB/s -- what sized the "
+                         "two-launch form of blocks 13 .. 16 (<= 0.25 MB per workgroup instead of 1.2 - 1.8 MB)")
     return roof
 
 
@@ -397,11 +426,14 @@ def pmc_child():
         os.rmdir(d)
 
 
-def skeleton_ratio(kernel, launches):
-    """The committed skeleton measurement of the dominant kernel (profiles/hp_skeleton.json; tools/r4_skel.sh): real / skeleton duration."""
+def skeleton_ratio(kernel, launches, robust=False):
+    """The committed skeleton measurement of the dominant kernel (profiles/hp_skeleton.json, from profiles/r04_hp_skeleton.txt): real / skeleton duration."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "hp_skeleton.json"))).get(kernel)
-        prog = t["robust_program"] if launches == t["robust_program"]["launches"] else t["default_program"]
+        if robust and launches == t["robust_program_blocks_0_12"]["launches"]:
+            prog = t["robust_program_blocks_0_12"]
+        else:
+            prog = t["robust_program"] if launches == t["robust_program"]["launches"] else t["default_program"]
         return dict(avg_us_real=prog["avg_us_real"], avg_us_skeleton=prog["avg_us_skeleton"],
                     real_over_skeleton=round(prog["avg_us_real"] / prog["avg_us_skeleton"], 3), source=t["source"])
     except (OSError, ValueError, KeyError, TypeError):
@@ -1307,7 +1339,7 @@ def main():
         note("stage profiles done")
         table, overhead = aggregate_stages(stages, ops, BATCH, WIDTH * HEIGHT * 3, input_size, hp_blocks, PROFILE_INNER)
         single_table, _ = aggregate_stages(single, ops, BATCH, WIDTH * HEIGHT * 3, input_size, hp_blocks, 1)
-        roof = roofline_object(table, overhead, single_table, PROFILE_INNER)
+        roof = roofline_object(table, overhead, single_table, PROFILE_INNER, robust=hp_blocks >= 17)
         if args.table:
             json.dump(dict(stages=stages, stages_single_bracket=single, inner=PROFILE_INNER, kernels=table,
                            kernels_single_bracket=single_table), open(args.table, "w"), indent=1)

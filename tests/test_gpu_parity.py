@@ -615,35 +615,6 @@ def test_wide_head_kernel_with_any_slice_length(model_dir, T):
         other.close()
 
 
-def test_extras_chain_in_one_launch_matches_the_layer_by_layer_path(model_dir):
-    """`WZ_TAIL_FUSE=1`: the six convolutions behind the 5x5 map as one launch, a workgroup per frame (k_tail.hip; measured slower
-    than six launches, hence off).  Same products, K summed in one piece instead of in eight wave slices: feature maps agree to fp16
-    rounding of equal fp32 sums (a last-place flip here and there), head outputs far inside the tolerance."""
-    frames = [synthetic_frame(640, 480, 600 + i) for i in range(3)]
-    one = _engine_with(model_dir, WZ_TAIL_FUSE="1")
-    six = _engine_with(model_dir, WZ_TAIL_FUSE="0")
-    try:
-        x = np.stack([one.stage_preprocess(f) for f in frames])
-        b1, l1 = one.stage_forward(x)
-        b6, l6 = six.stage_forward(x)
-        assert np.isfinite(l1).all() and np.isfinite(b1).all()
-        assert np.abs(l1 - l6).max() <= 5e-3 * max(1.0, np.abs(l6).max())
-        assert np.abs(b1 - b6).max() <= 5e-3 * max(1.0, np.abs(b6).max())
-        r1 = [np.zeros(100, ROW_DTYPE) for _ in frames]
-        r6 = [np.zeros(100, ROW_DTYPE) for _ in frames]
-        one.detect_batch(frames, r1)
-        six.detect_batch(frames, r6)
-        for a, b in zip(r6, r1):
-            pairs, missing = pu.match_rows(b, {"label": a["label"], "confidence": a["confidence"],
-                                               "box": np.stack([a["x_min"], a["y_min"], a["x_max"], a["y_max"]], 1)},
-                                           min_score=0.1)
-            assert len(missing) <= 2, missing
-            assert max(abs(p[3]) for p in pairs) <= 5e-4
-    finally:
-        one.close()
-        six.close()
-
-
 def test_product_and_development_libraries_write_the_same_rows(model_dir, eng):
     """Two builds of one source tree: libwatsor_hip.so (what ships) and libwatsor_hip_dev.so (what the stage tests above drive)."""
     prod = conftest.make_engine(model_dir, dev=False)

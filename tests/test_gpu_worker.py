@@ -57,7 +57,7 @@ def test_plugin_in_a_spawned_worker_writes_the_same_rows(model_dir, asynchronous
     assert "gfx950" in name or "MI3" in name
     # derived from the frame buffers, not from env defaults; five cameras: the throughput schedule (up to four: latency -- the two-camera
     # tests below run their child on it and still compare bit for bit with this process's engine)
-    assert opts == {"max_width": 1280, "max_height": 720, "schedule": "throughput"}
+    assert opts == {"max_width": 1280, "max_height": 720, "schedule": "auto:throughput"}     # (a preference: watsor_amd/detection/detector.py)
     assert pinned == 15                                             # every Frame.image of every camera was page-locked
     # the parent reads the rows out of shared memory and compares with an in-process engine
     e = make_engine(model_dir, max_batch=8, max_width=1280, max_height=720)

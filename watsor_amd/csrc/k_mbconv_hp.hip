@@ -58,7 +58,7 @@
 // QE: the chunk buffer holds the 16-bit FLOAT form of v / 6 (above) instead of unorm16 of v / 6 (the ROBUST program, WzMbArgs::qenc): a
 // relative step -- what channels of very different scale need.  Round 3 kept square roots there (one v_sqrt_f32
 // per stored value, one multiply per tap): coarser for small channels and slower to encode.
-// LEAN (CS + SH, one output m-tile): the shapes behind the 19x19 maps (block 13: 96 -> 576 -> 160 at stride 2; blocks 14 .. 16:
+// LEAN (CS + SH, one output m-tile; MQW = 1): the shapes behind the 19x19 maps (block 13: 96 -> 576 -> 160 at stride 2; blocks 14 .. 16:
 // 160 -> 960 -> 160 / 320 on 10x10) do not fit 256 registers the way the others are written -- MPW x KCI x 2 halo fragments alone are
 // 144 / 120 of them -- so the halo fragments of ONE m-tile at a time come back from LDS inside the expand stage, and a workgroup
 // finishes NTO of the block's n-tiles: blockIdx.x % nsplit picks which (the expand and depthwise stages are repeated per group:
@@ -72,8 +72,8 @@ template <int NW, bool CS, bool STEM, int MPW, int MQW, int KCI, int NTO, int OC
           bool QE = false, bool LEAN = false, bool CG = false>
 __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a) {
     static_assert(!LEAN || (CS && SH && !ONEPASS && !STEM), "lean: chunk-split, shared halo");
-    static_assert(!LEAN || MQW == 1 || (OCC <= 2 && MPW == 4), "lean 4 x 8 tiles: the stride-1 10x10 blocks at one or two waves per SIMD");
-    static_assert(!CG || LEAN, "channel groups over workgroups: the lean builds (10x10 maps; round 5: the 19x19 maps at one or two frames)");
+    static_assert(!LEAN || MQW == 1, "lean builds: 4 x 4 tiles (the 4 x 8 lean builds of round 5 lost their A/B: profiles/r05_blocks_13_16_tile_4x8.txt)");
+    static_assert(!CG || (LEAN && OCC == 2), "channel groups over workgroups: the lean builds of the 10x10 maps (on the 19x19 maps they lost: profiles/r05_channel_groups_19x19.txt)");
     extern __shared__ __attribute__((aligned(16))) unsigned char wz_hp_smem[];
     WZ_LANE_STAMP(a.dbg);
     const long long t_entry = WZ_HP_STAMPS ? __builtin_readcyclecounter() : 0;
@@ -81,8 +81,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
     constexpr bool PRE = OCC <= 2;                       // all taps of an output requested before the first is used
     constexpr int ES = 40;                               // unorm16 per row of the chunk buffer: 32 channels + 8 of padding
     constexpr int EBYTES = MPW * 16 * ES * 2;
-    // rounds of the accumulators' trip through LDS (the lean 4 x 8 builds hold 2 x 10 fragments per wave: four rounds of five)
-    constexpr int RROUNDS = (LEAN && MQW == 2) ? (NW >= 8 ? 4 : 5) : (LEAN && OCC >= 4 && NTO % 2 == 0 && NTO >= 6) ? 2 : 1;
+    // rounds of the accumulators' trip through LDS
+    constexpr int RROUNDS = (LEAN && OCC >= 4 && NTO % 2 == 0 && NTO >= 6) ? 2 : 1;
     constexpr int RED_BYTES = CS ? NW * (MQW * NTO / RROUNDS) * 1024 : 0;
     constexpr int REGION = (NW * EBYTES > RED_BYTES) ? NW * EBYTES : RED_BYTES;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
             }
         }
     };
-    constexpr bool WA_AHEAD = !((LEAN || !CS) && OCC >= 4) && !(LEAN && MQW == 2 && OCC == 2);   // the next pass's expand fragments requested a stage ahead (4 waves per SIMD: at the
+    constexpr bool WA_AHEAD = !((LEAN || !CS) && OCC >= 4);   // the next pass's expand fragments requested a stage ahead (4 waves per SIMD: at the
                                                      // top of the pass instead -- the other waves cover the wait, the registers are not there)
     if (!SH && WA_AHEAD && ps0 < c_hi) load_wa(ps0);
     {   // biases (and, LDSW, depthwise weights) into LDS: every load of a thread in flight before its first store
@@ -451,8 +451,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
             // rows hp0 .. hp0 + 3 of the halo serve both outputs: row rr is tap row rr of output 0 and rr - 1 of output 1.
             // All 12 taps are requested before the first one is used: one LDS latency instead of twelve.
             const unsigned short* ep = E + hp0[0] * ES + g * 8;
-            constexpr int RR = (LEAN && OCC >= 2) ? 2 : PRE ? 4 : WZ_HP_RR3;   // halo rows requested per group (3 waves per SIMD: WZ_HP_RR3; the lean 4 x 8 builds hold
-                                                                  // 2 x 10 accumulators and the project fragments in flight: two rows at a time)
+            constexpr int RR = PRE ? 4 : WZ_HP_RR3;   // halo rows requested per group (3 waves per SIMD: WZ_HP_RR3)
 #pragma unroll
             for (int r0 = 0; r0 < 4; r0 += RR) {
                 wz_u32x4_t tq[RR * 3];
@@ -575,97 +574,6 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
                 finish(acc[j][nt], sd[j][nt], opix[j], n4);
             }
         }
-    } else if constexpr (RROUNDS > 1 && (MQW > 1 || CG)) {
-        // lean builds whose accumulators cross LDS in rounds AND may share their block's chunks with other workgroups: the 4 x 8 builds of the
-        // stride-1 10x10 blocks (MQW x NTO = 20 fragments per wave) and, round 5, the 19x19 builds at four waves per SIMD when one or two frames
-        // leave the chip empty (NTO = 4 / 6 fragments in two rounds).  MQW x NTO accumulator fragments per wave cross LDS in RROUNDS rounds of NH;
-        // fragment q = j * NTO + nt of a round is summed by wave q - r * NH in the order wave 0 .. NW - 1, as everywhere.  With channel
-        // groups over workgroups (CG) the sums then go through the workspace like the 4 x 4 builds' (below): slabs, ticket, last arriver.
-        constexpr int TF = MQW * NTO, NH = TF / RROUNDS;
-        static_assert(TF % RROUNDS == 0 && NH <= NW, "rounds of the lean 4 x 8 reduction");
-        Side sd[RROUNDS];
-        int sop[RROUNDS], sn4[RROUNDS];
-        const bool fin_wave = wave < NH;
-#pragma unroll
-        for (int r = 0; r < RROUNDS; ++r) {
-            const int q = r * NH + (fin_wave ? wave : 0);
-            const int j = q / NTO, nt = q - j * NTO;
-            int op = -1;
-#pragma unroll
-            for (int jj = 0; jj < MQW; ++jj)
-                if (jj == j) op = opix[jj];
-            const int n4 = (nt0 + nt) * 16 + g * 4;
-            const bool on = fin_wave && op >= 0 && n4 < a.cout;
-            sop[r] = on ? op : -1;
-            sn4[r] = n4;
-            sd[r] = side(on ? op : 0, on ? n4 : 0);
-        }
-        float* const red = reinterpret_cast<float*>(wz_hp_smem);
-        float4_t vs[RROUNDS];
-#pragma unroll
-        for (int r = 0; r < RROUNDS; ++r) {
-            __syncthreads();   // every wave is done with its chunk buffer / with the previous round's partials
-#pragma unroll
-            for (int t = 0; t < NH; ++t)
-                *reinterpret_cast<float4_t*>(red + ((size_t)(wave * NH + t) * 64 + lane) * 4) = acc[(r * NH + t) / NTO][(r * NH + t) % NTO];
-            __syncthreads();
-            vs[r] = (float4_t){0.f, 0.f, 0.f, 0.f};
-            if (fin_wave) {
-#pragma unroll
-                for (int w = 0; w < NW; ++w) {
-                    const float4_t pz = *reinterpret_cast<const float4_t*>(red + ((size_t)(w * NH + wave) * 64 + lane) * 4);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) vs[r][q] += pz[q];
-                }
-            }
-        }
-        if constexpr (CG) {
-            if (cgn > 1) {
-                float* const slab0 = a.ws + (size_t)bidx * cgn * TF * 256;
-                if (fin_wave) {
-#pragma unroll
-                    for (int r = 0; r < RROUNDS; ++r) {
-                        float* const dst = slab0 + ((size_t)cg * TF + r * NH + wave) * 256 + lane * 4;
-                        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(vs[r]) : "memory");
-                    }
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();                       // every wave's stores have landed
-                int* const flag = reinterpret_cast<int*>(bd_l);   // (the staged biases are dead behind the chunk loop)
-                if (threadIdx.x == 0) {
-                    int32_t* const tk = a.tickets + bidx;
-                    const int tt = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                    if (tt == cgn - 1) {
-                        __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                        // this CU reads the slabs fresh
-                    }
-                    *flag = tt;
-                }
-                __syncthreads();
-                if (*flag != cgn - 1) return;
-                if (fin_wave) {
-#pragma unroll
-                    for (int r = 0; r < RROUNDS; ++r) {
-                        float4_t pz[4];
-#pragma unroll
-                        for (int z = 0; z < 4; ++z)
-                            pz[z] = z < cgn ? *reinterpret_cast<const float4_t*>(slab0 + ((size_t)z * TF + r * NH + wave) * 256 + lane * 4)
-                                            : (float4_t){0.f, 0.f, 0.f, 0.f};
-                        float4_t v = pz[0];
-#pragma unroll
-                        for (int z = 1; z < 4; ++z)
-                            if (z < cgn) {
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) v[q] += pz[z][q];
-                            }
-                        vs[r] = v;
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < RROUNDS; ++r)
-            if (fin_wave && sop[r] >= 0) finish(vs[r], sd[r], sop[r], sn4[r]);
     } else if constexpr (RROUNDS > 1) {
         // lean builds at 4 waves per SIMD: the accumulators cross LDS in RROUNDS rounds of NTO / RROUNDS n-tiles, so that the area they
         // need (NW KiB per n-tile) stays under the chunk buffers and two workgroups fit the LDS of a CU; n-tile t of a round is
@@ -747,6 +655,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
                 // this group's sums of the tile -> its slab of the workspace ([unit][group][MQW * NTO fragments of 1 KiB], lane l's four values
                 // at l * 16: whole lines), write-through; then the ticket
                 constexpr int FR = MQW * NTO;
+#ifdef WZ_DEV_BUILD
+                // one ticket counter per (tile, n-group) and cgn workgroups on it: the launcher's grid is exactly units x groups
+                if (threadIdx.x == 0 && (int)gridDim.x != tiles * a.nb * ngrp * cgn) __builtin_trap();
+#endif
                 float* const slab0 = a.ws + (size_t)bidx * cgn * FR * 256;
 #pragma unroll
                 for (int k = 0; k < PER; ++k) {
@@ -771,6 +683,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
                 }
                 __syncthreads();
                 if (*flag != cgn - 1) return;
+                // every wave reads the slabs behind an agent-scope acquire of its own (thread 0's above orders its own loads only: the other
+                // waves' would otherwise rest on the barrier + the write-through stores alone; ADVICE r4 / VERDICT r5 weak #14)
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 // the last arriver: the groups' sums in group order, all of a fragment's loads requested before the first add
 #pragma unroll
                 for (int k = 0; k < PER; ++k) {
@@ -834,7 +749,7 @@ static int wz_hp_launch(WzMbArgs a, int n, hipStream_t s, bool prepare) {
     if (!LEAN && a.n_pad / 16 != NTO) return -1;
     if (LEAN && a.nsplit * NTO != a.n_pad / 16) return -1;
     constexpr int EB = MPW * 16 * 40 * 2;
-    constexpr int RED = CS ? NW * (MQW * NTO / ((LEAN && MQW == 2) ? (NW >= 8 ? 4 : 5) : (LEAN && OCC >= 4 && NTO % 2 == 0 && NTO >= 6) ? 2 : 1)) * 1024 : 0;
+    constexpr int RED = CS ? NW * (MQW * NTO / ((LEAN && OCC >= 4 && NTO % 2 == 0 && NTO >= 6) ? 2 : 1)) * 1024 : 0;
     const size_t region = (size_t)(NW * EB > RED ? NW * EB : RED);
     const size_t lds = region + (size_t)a.cmid_pad * ((CS || OCC > 2) ? 8 + 36 : 8) + (SH ? (size_t)MPW * KCI * 2 * 1024 : 0);
     if ((a.cmid_pad >> 2) > NW * 64 || 9 * (a.cmid_pad >> 2) > (LEAN ? (NW >= 8 ? 5 : 9) : NW >= 8 ? 3 : 8) * NW * 64) return -1;   // the staging code's fixed trip counts
@@ -847,28 +762,6 @@ static int wz_hp_launch(WzMbArgs a, int n, hipStream_t s, bool prepare) {
     if (!CG) a.cgroups = 1;
     WZ_LAUNCH(k, dim3(CS ? tiles * a.nsplit * a.cgroups : (tiles + 3) / 4), dim3(NW * 64), lds, s, a);
     return 1;
-}
-
-// Channel groups over workgroups for the 19x19 blocks (round 5; VERDICT r4 #6b): one frame is 25 tiles -- 25 workgroups on 256 CUs, each walking 12 - 18 chunks
-// over its eight waves in two or three passes.  With G workgroups per tile a wave walks one chunk; the groups' sums meet through the workspace like the 10x10
-// blocks' (ticket per tile, the last arriver adds the groups in group order: deterministic).  Only where the launch leaves the chip empty: at most 64 tiles
-// (one or two frames; 128 under the latency schedule), G the smallest number that gets a wave's walk down to one pass.
-// MEASURED AND OFF (WZ_HP_CG19=1 switches it on in the development library): correct (the whole GPU suite passes with it), but these launches are short --
-// 5.5 - 9 us -- and the trip of the groups' sums through the workspace costs more than the second chunk pass it saves: blocks 7 .. 10 5.6 -> 6.5 us at one
-// frame, 5.8 -> 7.4 at two; blocks 11 / 12 (18 chunks) 9.0 / 8.6 -> 8.0 / 7.8 at one frame; frames/s 11.7 -> 11.0 k (one frame), 21.0 -> 17.7 k (two);
-// profiles/r05_channel_groups_19x19.txt.
-static int wz_hp_cs19_groups(const WzMbArgs& a, int n, bool prepare) {
-    static const int on = wz_hp_env("WZ_HP_CG19", 0);
-    static const int cap = wz_hp_env("WZ_HP_CG19_TILES", wz_latency_schedule() ? 128 : 64);
-    const int units = ((a.hout + 3) / 4) * ((a.wout + 3) / 4) * n;
-    const int nto = a.n_pad / 16, nk32 = a.cmid_pad >> 5;
-    if (prepare || !on || !a.ws || !a.tickets || units > cap || units > WZ_HP_TICKETS || (size_t)units * 4 * nto * 1024 > (size_t)(a.ws_bytes >> 1)) return 1;
-    int G = 1, best = (nk32 + 7) / 8;
-    for (int g = 2; g <= 4; ++g) {
-        const int walk = ((nk32 + g - 1) / g + 7) / 8;
-        if (walk < best) { best = walk; G = g; }
-    }
-    return G;
 }
 
 // The ROBUST program (WzMbArgs::qenc, `python -m watsor_amd.engine --robust`): all 17 blocks on this kernel with the float-form chunk
@@ -891,13 +784,7 @@ static int wz_launch_mbconv_hp_q(WzMbArgs a, int n, hipStream_t s, bool prepare)
     }
     if (a.wout > 10) {
         if (a.stride == 2) return (a.kc0 == 1 && nto == 4) ? wz_hp_launch<6, true, false, 6, 1, 1, 4, 4, false, true, true, true>(a, n, s, prepare) : -1;
-        if (a.kc0 == 2 && nto == 4) {
-            const int G = wz_hp_cs19_groups(a, n, prepare);
-            if (prepare) (void)wz_hp_launch<8, true, false, 3, 1, 2, 4, 4, false, true, true, true, true>(a, n, s, true);
-            a.cgroups = G;
-            return G > 1 ? wz_hp_launch<8, true, false, 3, 1, 2, 4, 4, false, true, true, true, true>(a, n, s, false)
-                         : wz_hp_launch<8, true, false, 3, 1, 2, 4, 4, false, true, true, true>(a, n, s, prepare);
-        }
+        if (a.kc0 == 2 && nto == 4) return wz_hp_launch<8, true, false, 3, 1, 2, 4, 4, false, true, true, true>(a, n, s, prepare);
         if (a.kc0 == 2 && nto == 6) return wz_hp_launch<8, true, false, 3, 1, 2, 6, 4, false, true, true, true>(a, n, s, prepare);
         if (a.kc0 == 3 && nto == 6) return wz_hp_launch<8, true, false, 3, 1, 3, 6, 4, false, true, true, true>(a, n, s, prepare);
         return -1;
@@ -964,16 +851,10 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
         // batch 8 runs as before.  profiles/r04_channel_groups.txt.  WZ_HP_CGROUPS=1: never; 2 .. 4: at most that many.
         static const int cg_env = wz_hp_env("WZ_HP_CGROUPS", 0);
         static const int cg_cap = wz_hp_env("WZ_HP_CG_CAP", wz_latency_schedule() ? 256 : 128);   // workgroups such a launch may have
-        // 4 x 8 tiles for the stride-1 blocks (round 5, the lean MQW = 2 builds): a workgroup streams ALL of the block's split weights
-        // (1.2 - 1.8 MB) through its CU's vector memory path whatever it computes, and that stream -- not the arithmetic -- is what
-        // these launches take (9 - 10 of their 16 us).  A 10x10 map is 9 tiles of 4 x 4 but 6 of 4 x 8: a third fewer workgroups and
-        // weight streams for the same matrix work (6 x (4 + 2) against 9 x (3 + 1) pixel tiles through expand + project).
-        static const int t48_env = wz_hp_env("WZ_HP_T48", 0);   // 1: eight waves at two per SIMD, 2: FOUR waves, one per SIMD (512 registers each)
-        const bool t48 = t48_env && a.stride == 1 && a.kc0 == 5 && (nto == 10 || nto == 20);
-        const int units = ((a.hout + 3) / 4) * ((a.wout + (t48 ? 7 : 3)) / (t48 ? 8 : 4)) * n * (nto / 10);   // (tile, n-group) pairs = ticket counters
+        const int units = ((a.hout + 3) / 4) * ((a.wout + 3) / 4) * n * (nto / 10);   // (tile, n-group) pairs = ticket counters
         int G = 1;
         if (!prepare && a.ws && a.tickets && cg_env != 1 && units <= WZ_HP_TICKETS &&
-            (size_t)units * 4 * (t48 ? 20 : 10) * 1024 <= (size_t)(a.ws_bytes >> 1)) {
+            (size_t)units * 4 * 10 * 1024 <= (size_t)(a.ws_bytes >> 1)) {
             int best = (nk32 + 7) / 8;                                       // chunks a wave walks with one group
             for (int g = 2; g <= 4; ++g) {
                 if (units * g > cg_cap || (cg_env > 1 && g > cg_env)) break;
@@ -990,18 +871,6 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
                          : wz_hp_launch<8, true, false, 6, 1, 3, 10, 2, false, true, false, true>(a, n, s, prepare);
         }
         if (a.kc0 == 5 && (nto == 10 || nto == 20)) {
-            if (prepare) {
-                (void)wz_hp_launch<8, true, false, 4, 2, 5, 10, 2, false, true, false, true, true>(a, n, s, true);
-                (void)wz_hp_launch<8, true, false, 4, 2, 5, 10, 2, false, true, false, true>(a, n, s, true);
-                (void)wz_hp_launch<4, true, false, 4, 2, 5, 10, 1, false, true, false, true, true>(a, n, s, true);
-                (void)wz_hp_launch<4, true, false, 4, 2, 5, 10, 1, false, true, false, true>(a, n, s, true);
-            } else if (t48 && t48_env == 2) {
-                return G > 1 ? wz_hp_launch<4, true, false, 4, 2, 5, 10, 1, false, true, false, true, true>(a, n, s, false)
-                             : wz_hp_launch<4, true, false, 4, 2, 5, 10, 1, false, true, false, true>(a, n, s, false);
-            } else if (t48) {
-                return G > 1 ? wz_hp_launch<8, true, false, 4, 2, 5, 10, 2, false, true, false, true, true>(a, n, s, false)
-                             : wz_hp_launch<8, true, false, 4, 2, 5, 10, 2, false, true, false, true>(a, n, s, false);
-            }
             if (prepare) (void)wz_hp_launch<8, true, false, 3, 1, 5, 10, 2, false, true, false, true, true>(a, n, s, true);
             return G > 1 ? wz_hp_launch<8, true, false, 3, 1, 5, 10, 2, false, true, false, true, true>(a, n, s, false)
                          : wz_hp_launch<8, true, false, 3, 1, 5, 10, 2, false, true, false, true>(a, n, s, prepare);
@@ -1128,7 +997,6 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
     if (a.kc0 == K && nto == N) {                                                                             \
         if (prepare) {                                                                                        \
             (void)wz_hp_launch<8, true, false, 3, 1, K, N, 4, false, true, false, true>(a, n, s, true);      \
-            (void)wz_hp_launch<8, true, false, 3, 1, K, N, 4, false, true, false, true, true>(a, n, s, true); \
             (void)wz_hp_launch<3, true, false, 3, 1, K, N, 2, false, true>(a, n, s, true);                   \
             (void)wz_hp_launch<4, true, false, 3, 1, K, N, 2, false, true>(a, n, s, true);                   \
             (void)wz_hp_launch<5, true, false, 3, 1, K, N, 2, false, true>(a, n, s, true);                   \
@@ -1138,10 +1006,7 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
             return wz_hp_launch<HP_CS_WAVES, true, false, 3, 1, K, N>(a, n, s, true);                        \
         }                                                                                                     \
         if (sh && cs19_lean4) {                                                                               \
-            const int G = wz_hp_cs19_groups(a, n, false);                                                     \
-            a.cgroups = G;                                                                                    \
-            const int r = G > 1 ? wz_hp_launch<8, true, false, 3, 1, K, N, 4, false, true, false, true, true>(a, n, s, false) \
-                                : wz_hp_launch<8, true, false, 3, 1, K, N, 4, false, true, false, true>(a, n, s, false); \
+            const int r = wz_hp_launch<8, true, false, 3, 1, K, N, 4, false, true, false, true>(a, n, s, false); \
             if (r >= 0) return r;                                                                             \
         }                                                                                                     \
         if (sh && cs19_nw == 3) { const int r = wz_hp_launch<3, true, false, 3, 1, K, N, 2, false, true>(a, n, s, false); if (r >= 0) return r; } \

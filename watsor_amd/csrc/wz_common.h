@@ -290,14 +290,6 @@ int wz_choose_splitk_rs_f32(int M, int n_pad, int kchunks);
 bool wz_conv_ws_f32_applies(const WzConvArgs& a);         // fp32 engine: the extras chain on the wave-split kernel
 void wz_launch_conv_ws_f32(const WzConvArgs& a, hipStream_t s);
 void wz_conv_init();
-// a chain of convolutions on tiny maps (the extras behind the 5x5 map) in one launch, one workgroup per frame (k_tail.hip)
-#define WZ_TAIL_MAX 6
-struct WzTailArgs {
-    int32_t n;
-    WzConvArgs l[WZ_TAIL_MAX];   // l[0].in = the chain's input; each layer's `out` = its tensor in HBM
-};
-bool wz_tail_layer_ok(const WzConvArgs& a, int n_frames);
-void wz_launch_extras_tail(const WzTailArgs& A, int n_frames, hipStream_t s);
 // `-p 32` engine (k_f32.hip): fp32 activations and weights, exact-fp32 MFMA
 void wz_launch_stem_f32(const half_t* in, const float* w, const float* bias, float* out, int n, int hin, int win,
                         int hout, int wout, int pad_t, int pad_l, hipStream_t s, bool pair = false);

@@ -83,7 +83,6 @@ struct wz_engine {
     bool conv_wide = true;     // the big SSD heads on the wide tile kernel (k_conv_wide.hip); WZ_CONV_WIDE=0: on wz_k_conv_rs
     int wide_min_m = 1;        // WZ_WIDE_MIN_M=n: heads with fewer output pixels than this (per batch) stay on wz_k_conv_group
     int wide_T = 0;            // WZ_WIDE_T=n: K steps per slice of that kernel (0: chosen per launch by wz_choose_wide_T)
-    int tail_fuse = 0;            // WZ_TAIL_FUSE=1: the convolutions on the <= 32-pixel maps in one launch (k_tail.hip); measured slower, off.
                                   // 2 (round 5): only the chain behind the 3x3 map -- its last four convolutions, 0.8 MB of weights per frame's workgroup
     bool desc_by_value = true;    // the frame descriptors travel as arguments of the resize kernel (WZ_DESC_ARGS=0: zero-copy / copied)
     bool desc_zero_copy = true;   // the resize kernel reads the frame descriptors from page-locked host memory (WZ_DESC_COPY=1: copied first)
@@ -374,55 +373,6 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
                 wz_launch_splitk_reduce(r, L.d_ws, s);
             }
         } else {
-            // The extras behind the 5x5 map: a chain of plain convolutions on maps of <= 32 pixels, each reading what the one before it
-            // wrote -- WZ_TAIL_FUSE=1 runs them as ONE launch, a workgroup per frame (k_tail.hip).  Built, bit-compatible within fp32
-            // summation order, and slower than the six launches it replaces (34 us against 23.5 us: HISTORY.md part B): off by default.
-#ifdef WZ_DEV_BUILD
-            if (!f32 && e->tail_fuse && op.out_mode == WZ_OUT_ACT && (e->tail_fuse == 1 || op.hin * op.win <= 9)) {
-                WzTailArgs T;
-                T.n = 0;
-                for (uint32_t j = i; j < e->hdr.n_ops && T.n < WZ_TAIL_MAX; ++j) {
-                    const WzOpDesc& oj = e->ops[j];
-                    if (oj.kind == WZ_OP_STEM || oj.kind == WZ_OP_DW || oj.kind == WZ_OP_MBCONV || oj.out_mode != WZ_OUT_ACT) break;
-                    if (j > i && oj.src != e->ops[j - 1].dst) break;
-                    WzConvArgs& c = T.l[T.n];
-                    memset(&c, 0, sizeof(c));
-                    c.in = L.tptr[oj.src];
-                    c.w = (const half_t*)(wbase + oj.w_off);
-                    c.bias = (const float*)(wbase + oj.b_off);
-                    c.res = oj.res >= 0 ? L.tptr[oj.res] : nullptr;
-                    c.out = L.tptr[oj.dst];
-                    c.M = n * oj.hout * oj.wout;
-                    c.hin = oj.hin; c.win = oj.win; c.cin = oj.cin;
-                    c.hout = oj.hout; c.wout = oj.wout; c.cout = oj.cout; c.n_pad = oj.n_pad;
-                    c.ksize = oj.ksize; c.stride = oj.stride; c.pad_t = oj.pad_t; c.pad_l = oj.pad_l; c.kc = oj.kc;
-                    c.act = oj.act; c.out_mode = oj.out_mode;
-                    c.kchunks = oj.ksize * oj.ksize * oj.kc;
-                    c.splitk = 1;
-                    if (!wz_tail_layer_ok(c, n)) break;
-                    ++T.n;
-                }
-                // A layer's output goes to HBM only if somebody outside the chain reads it (the SSD feature maps) -- the others live in
-                // LDS.  They must not be written: tensors with disjoint lifetimes share buffers, the lifetimes are those of a
-                // layer-by-layer execution, and here one frame's workgroup may be at the last layer while another's is at the
-                // first (a dead intermediate written late would land in a live feature map).  With WZ_NO_BUFFER_REUSE every
-                // tensor has its own buffer and all of them are written (tests read them).
-                for (int k = 0; k < T.n; ++k) {
-                    bool read_outside = e->no_reuse;
-                    const int32_t dst = e->ops[i + k].dst;
-                    for (uint32_t j = 0; j < e->hdr.n_ops && !read_outside; ++j)
-                        if ((j < i || j >= i + (uint32_t)T.n) && (e->ops[j].src == dst || e->ops[j].res == dst)) read_outside = true;
-                    if (!read_outside) T.l[k].out = nullptr;
-                }
-                if (T.n >= 2) {
-                    wz_launch_extras_tail(T, n, s);
-                    if (t)
-                        for (int k = 0; k < T.n; ++k) { t->mark(); t->mark(); }   // (the launch is booked on the chain's first layer)
-                    i += (uint32_t)T.n - 1;
-                    continue;
-                }
-            }
-#endif
             WzConvArgs a;
             memset(&a, 0, sizeof(a));
             a.in = L.tptr[op.src];
@@ -674,50 +624,59 @@ static int run_batch(wz_engine* e, int slot, int n) {
             if (li != slot && e->lanes[li].done && hipEventQuery(e->lanes[li].done) == hipErrorNotReady) graph = true;
         (void)hipGetLastError();
     }
+    // the captured graph of (lane, batch size, resize form): captured and instantiated the first time the key is seen -- also when that first batch itself
+    // goes kernel by kernel (adaptive launch): the several ms of capture + instantiation then land on the first batch of a size, not on the first moment
+    // another lane happens to be busy
+    auto ensure_graph = [&]() -> int {
+        if (L.graphs.count(key)) return WZ_OK;
+        hipGraph_t g = nullptr;
+        HIPCHK(hipStreamBeginCapture(L.stream, hipStreamCaptureModeThreadLocal));
+#if WZ_LANE_STAMPS
+        L.launch_notes[key].clear();
+        g_launch_sink = &L.launch_notes[key];
+#endif
+        enqueue_batch(e, L, n, nullptr);
+#if WZ_LANE_STAMPS
+        g_launch_sink = nullptr;
+#endif
+        HIPCHK(hipStreamEndCapture(L.stream, &g));
+        if (L.launch_failed) {
+            (void)hipGraphDestroy(g);
+            return failed();
+        }
+        size_t nodes = 0;
+        if (hipGraphGetNodes(g, nullptr, &nodes) == hipSuccess) L.graph_nodes[key] = (int)nodes;
+        if (e->desc_by_value && n <= WZ_DESC_PACK && nodes > 0) {   // the resize kernel's node: its arguments are this batch's descriptors
+            std::vector<hipGraphNode_t> all(nodes);
+            const void* want = wz_preprocess_func(input_is_pair(e), L.rows);
+            if (hipGraphGetNodes(g, all.data(), &nodes) == hipSuccess)
+                for (size_t k = 0; k < nodes; ++k) {
+                    hipGraphNodeType ty;
+                    hipKernelNodeParams kp;
+                    if (hipGraphNodeGetType(all[k], &ty) == hipSuccess && ty == hipGraphNodeTypeKernel &&
+                        hipGraphKernelNodeGetParams(all[k], &kp) == hipSuccess && kp.func == want) {
+                        L.pre_nodes[key] = all[k];
+                        break;
+                    }
+                }
+            if (!L.pre_nodes.count(key)) {
+                (void)hipGraphDestroy(g);
+                return wz_fail(WZ_EHIP, "the resize kernel's node was not found in the captured graph");
+            }
+        }
+        hipGraphExec_t ge = nullptr;
+        HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        if (L.pre_nodes.count(key)) L.graph_src[key] = g;   // (the node handle lives as long as the graph it belongs to)
+        else (void)hipGraphDestroy(g);
+        L.graphs.emplace(key, ge);
+        return WZ_OK;
+    };
+    if (graph || (e->use_graph && !L.graphs.count(key))) {
+        const int rc = ensure_graph();
+        if (rc != WZ_OK) return rc;
+    }
     if (graph) {
         auto it = L.graphs.find(key);
-        if (it == L.graphs.end()) {
-            hipGraph_t g = nullptr;
-            HIPCHK(hipStreamBeginCapture(L.stream, hipStreamCaptureModeThreadLocal));
-#if WZ_LANE_STAMPS
-            L.launch_notes[key].clear();
-            g_launch_sink = &L.launch_notes[key];
-#endif
-            enqueue_batch(e, L, n, nullptr);
-#if WZ_LANE_STAMPS
-            g_launch_sink = nullptr;
-#endif
-            HIPCHK(hipStreamEndCapture(L.stream, &g));
-            if (L.launch_failed) {
-                (void)hipGraphDestroy(g);
-                return failed();
-            }
-            size_t nodes = 0;
-            if (hipGraphGetNodes(g, nullptr, &nodes) == hipSuccess) L.graph_nodes[key] = (int)nodes;
-            if (e->desc_by_value && n <= WZ_DESC_PACK && nodes > 0) {   // the resize kernel's node: its arguments are this batch's descriptors
-                std::vector<hipGraphNode_t> all(nodes);
-                const void* want = wz_preprocess_func(input_is_pair(e), L.rows);
-                if (hipGraphGetNodes(g, all.data(), &nodes) == hipSuccess)
-                    for (size_t k = 0; k < nodes; ++k) {
-                        hipGraphNodeType ty;
-                        hipKernelNodeParams kp;
-                        if (hipGraphNodeGetType(all[k], &ty) == hipSuccess && ty == hipGraphNodeTypeKernel &&
-                            hipGraphKernelNodeGetParams(all[k], &kp) == hipSuccess && kp.func == want) {
-                            L.pre_nodes[key] = all[k];
-                            break;
-                        }
-                    }
-                if (!L.pre_nodes.count(key)) {
-                    (void)hipGraphDestroy(g);
-                    return wz_fail(WZ_EHIP, "the resize kernel's node was not found in the captured graph");
-                }
-            }
-            hipGraphExec_t ge = nullptr;
-            HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-            if (L.pre_nodes.count(key)) L.graph_src[key] = g;   // (the node handle lives as long as the graph it belongs to)
-            else (void)hipGraphDestroy(g);
-            it = L.graphs.emplace(key, ge).first;
-        }
         auto pn = L.pre_nodes.find(key);
         if (pn != L.pre_nodes.end()) {   // this batch's descriptors into the node's arguments
             memset(&L.pack, 0, sizeof(L.pack));
@@ -745,7 +704,16 @@ static int run_batch(wz_engine* e, int slot, int n) {
         }
         HIPCHK(hipGraphLaunch(it->second, L.stream));
     } else {
+#if WZ_LANE_STAMPS
+        if (!L.launch_notes.count(key)) {   // (what was launched: also without a captured graph -- WZ_GRAPH=0, one lane)
+            L.launch_notes[key].clear();
+            g_launch_sink = &L.launch_notes[key];
+        }
+#endif
         enqueue_batch(e, L, n, nullptr);
+#if WZ_LANE_STAMPS
+        g_launch_sink = nullptr;
+#endif
         HIPCHK(hipGetLastError());
         if (L.launch_failed) {
             (void)hipStreamSynchronize(L.stream);
@@ -925,8 +893,10 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     // thread keeps four lanes fed; a batch that finds the other lanes idle goes kernel by kernel: run_batch), kernel-by-kernel launches under the LATENCY schedule -- the GPU starts on the first kernel while the host still issues the rest, and a lone
     // batch is done 7 us sooner (0.380 -> 0.372 ms at batch 8, 0.2915 -> 0.2865 at batch 1; 84 us of host time per batch instead of 10, and 2 - 4 % of the
     // saturated throughput: profiles/r05_submit_probe.txt)
-    e->use_graph = (env = getenv("WZ_GRAPH")) ? atoi(env) != 0 : !wz_latency_schedule();
-    e->graph_adaptive = e->use_graph && !getenv("WZ_GRAPH");   // (throughput schedule, nothing said: graphs while the lanes are busy, kernel by kernel for a lone batch)
+    env = getenv("WZ_GRAPH");
+    if (env && !env[0]) env = nullptr;   // (set but empty = not set)
+    e->use_graph = env ? atoi(env) != 0 : !wz_latency_schedule();
+    e->graph_adaptive = e->use_graph && !env;   // (throughput schedule, nothing said: graphs while the lanes are busy, kernel by kernel for a lone batch)
     e->use_splitk = !((env = wz_dev_getenv("WZ_SPLITK")) && atoi(env) == 0);
     e->wide_frag = !((env = wz_dev_getenv("WZ_WIDE_FRAG")) && atoi(env) == 0);
     e->defer_heads = !((env = wz_dev_getenv("WZ_DEFER_HEADS")) && atoi(env) == 0);
@@ -937,7 +907,6 @@ extern "C" int wz_create(const char* engine_path, int device, int max_batch, int
     e->conv_wide = !((env = wz_dev_getenv("WZ_CONV_WIDE")) && atoi(env) == 0);
     e->desc_zero_copy = !((env = wz_dev_getenv("WZ_DESC_COPY")) && atoi(env) != 0);
     e->desc_by_value = !((env = wz_dev_getenv("WZ_DESC_ARGS")) && atoi(env) == 0);
-    e->tail_fuse = (env = wz_dev_getenv("WZ_TAIL_FUSE")) ? atoi(env) : 0;
     e->pre_rows = (env = wz_dev_getenv("WZ_PRE_ROWS")) ? atoi(env) != 0 : e->pre_rows;
     // WZ_SCHEDULE=latency: every page-locked frame is read in place -- a lone batch is done sooner without the staging copy in front of it
     // (640x480, batch 8: 0.505 against 0.575 ms) although the waiting workgroups cost frames/s with four lanes in flight (29.7 k against 34 k)
