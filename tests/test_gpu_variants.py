@@ -329,5 +329,7 @@ def test_kernel_by_kernel_launches_write_the_same_rows_as_the_captured_graph(mod
         res[g] = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert res["1"]["nodes"] >= 25 and res["0"]["nodes"] == 0          # a captured graph / none
     assert res["1"]["rows"] == res["0"]["rows"]
-    # nothing said (throughput schedule): a batch that finds the other lanes idle -- every batch of this child -- goes kernel by kernel as well
-    assert res[None]["nodes"] == 0 and res[None]["rows"] == res["1"]["rows"]
+    # nothing said (throughput schedule): a batch that finds the other lanes idle -- every batch of this child -- goes kernel by kernel as well; the
+    # graph of its size is captured at that first use all the same (the capture stall belongs to the first batch of a size, not to the first
+    # moment of contention: ADVICE r5), it is only not replayed
+    assert res[None]["nodes"] >= 25 and res[None]["rows"] == res["1"]["rows"]
