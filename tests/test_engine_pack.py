@@ -367,8 +367,8 @@ def test_builder_reports_the_channel_spread_and_warns_beyond_what_was_validated(
 
 
 def test_robust_program_packs_all_blocks_split_and_float_form_scaled(hp_blob, synth_weights):
-    """`build_engine(robust=True)`: all 17 blocks split-operand with flag 4 (float-form chunk buffer t = C + (x / 6) K: depthwise taps
-    carry 6 / K, the depthwise bias -C * (sum of the stored taps)), every tensor between them a pair; block 13 reads block 12's pair
+    """`build_engine(robust=True)`: all 17 blocks split-operand with flag 4 (float-form chunk buffer t = (x / 6) T, T = 2^-120 (2 - 2^-13):
+    depthwise taps carry 6 * 2^60 / (2 - 2^-13), the kernel scales the tap sum back by 2^60; the bias is the plain one), every tensor between them a pair; block 13 reads block 12's pair
     output and stores the first SSD feature map as its second output (plain fp16), like the default program's block 13; block 16
     stores its output twice (flag 8, a plain 640-channel tensor) and Conv_1 multiplies it with [hi | lo] halves of its weights."""
     rb = engine.build_engine(synth_weights, robust=True)
@@ -388,18 +388,26 @@ def test_robust_program_packs_all_blocks_split_and_float_form_scaled(hp_blob, sy
         wf, bf = engine.fold_batch_norm(synth_weights, dw)
         wd = np.frombuffer(rb, np.float32, 9 * o["cmid_pad"], hdr["weights_off"] + o["wd_off"]).reshape(9, -1)
         bd = np.frombuffer(rb, np.float32, o["cmid_pad"], hdr["weights_off"] + o["bd_off"])
-        C, K = 2.0 ** -7, (2.0 - 2.0 ** -13) - 2.0 ** -7
+        T, S = 2.0 ** -120 * (2.0 - 2.0 ** -13), 2.0 ** 60
         if not o["flags"] & 4:                                   # linear buffer: 6 / 65535 in the taps, the bias as it is
             np.testing.assert_allclose(wd[:, :o["cmid"]], wf.reshape(9, -1) * (6.0 / 65535.0), rtol=1e-6, atol=0)
             np.testing.assert_allclose(bd[:o["cmid"]], bf, rtol=1e-6, atol=1e-7)
             continue
-        np.testing.assert_allclose(wd[:, :o["cmid"]], wf.reshape(9, -1) * (6.0 / K), rtol=1e-6, atol=0)
-        # what the kernel computes from stored codes: sum_t wd_t * t_t + bd with t = C + (x / 6) K  ==  sum_t w_t * x_t + b  (also on
-        # padding, where x = 0 is t = C)
+        np.testing.assert_allclose(wd[:, :o["cmid"]], wf.reshape(9, -1) * (6.0 * S / (2.0 - 2.0 ** -13)), rtol=1e-6, atol=0)
+        assert np.isfinite(wd).all()
+        np.testing.assert_allclose(bd[:o["cmid"]], bf, rtol=1e-6, atol=1e-7)
+        # what the kernel computes from stored codes: S * sum_t wd_t * t_t + bd with t = (x / 6) T  ==  sum_t w_t * x_t + b  (padding: x = 0
+        # is t = 0 is code 0)
         x = np.random.default_rng(op.block).uniform(0, 6, (9, o["cmid"]))
         x[:3] = 0.0
-        got = (wd[:, :o["cmid"]].astype(np.float64) * (C + x / 6.0 * K)).sum(0) + bd[:o["cmid"]]
+        got = S * (wd[:, :o["cmid"]].astype(np.float64) * (x / 6.0 * T)).sum(0) + bd[:o["cmid"]]
         np.testing.assert_allclose(got, (wf.reshape(9, -1) * x).sum(0) + bf, rtol=0, atol=2e-5)
+        # the code itself: bits 10 .. 25 of the fp32 pattern of t, rounded; full scale is code 65535, 2^-7 of it code 8192 (where the subnormal range ends)
+        code = lambda z: (int(np.float32(z * T).view(np.uint32)) + 512) >> 10                       # noqa: E731
+        assert code(1.0) == 65535 and code(0.0) == 0 and code(2.0 ** -7 * (1 - 2.0 ** -14)) in (8191, 8192)
+        back = lambda c: float(np.uint32(c << 10).view(np.float32)) / T                                # noqa: E731
+        for z in (1e-4, 3e-3, 0.03, 0.4, 0.9999):
+            assert abs(back(code(z)) - z) <= max(z * 2.0 ** -13, 2.0 ** -20)
     b13 = next(o for o, op in blocks if op.block == 13)
     assert (b13["cin0"], b13["kc0"], b13["cmid"], b13["cout"], b13["stride"]) == (96, 3, 576, 160, 2)
     assert tensors[b13["src"]]["name"] == "expanded_conv_12/output" and tensors[b13["src"]]["flags"] == 1

@@ -434,10 +434,14 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
         wz_f32x2_t dd[MQW][4];
 #pragma unroll
         for (int j = 0; j < MQW; ++j) {
-            dd[j][0] = __builtin_shufflevector(b0, b0, 0, 1);
-            dd[j][1] = __builtin_shufflevector(b0, b0, 2, 3);
-            dd[j][2] = __builtin_shufflevector(b1, b1, 0, 1);
-            dd[j][3] = __builtin_shufflevector(b1, b1, 2, 3);
+            if constexpr (QE) {   // float form: the tap sum starts at zero and is scaled back + biased at the end (wz_hp_dw_finish)
+                dd[j][0] = dd[j][1] = dd[j][2] = dd[j][3] = (wz_f32x2_t){0.f, 0.f};
+            } else {
+                dd[j][0] = __builtin_shufflevector(b0, b0, 0, 1);
+                dd[j][1] = __builtin_shufflevector(b0, b0, 2, 3);
+                dd[j][2] = __builtin_shufflevector(b1, b1, 0, 1);
+                dd[j][3] = __builtin_shufflevector(b1, b1, 2, 3);
+            }
         }
         auto W0 = [&](int tp) -> float4_t {
             if constexpr (LDSW) return *reinterpret_cast<const float4_t*>(wd_l + tp * a.cmid_pad + coff);
@@ -495,6 +499,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
         // ---- relu6, split, project: acc += Wlo.dhi + Whi.dlo + Whi.dhi
 #pragma unroll
         for (int j = 0; j < MQW; ++j) {
+            wz_hp_dw_finish<QE>(dd[j], b0, b1);
             float v[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) v[r] = fminf(fmaxf(dd[j][r >> 1][r & 1], 0.0f), 6.0f);

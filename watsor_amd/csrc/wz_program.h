@@ -8,7 +8,7 @@
 #include <stdint.h>
 
 #define WZ_MAGIC 0x35335A57u /* "WZ35" */
-#define WZ_FORMAT_VERSION 10u
+#define WZ_FORMAT_VERSION 11u   // 11: the float-form chunk buffer's scaling changed (k_hp_ops.h, round 6): depthwise taps of WZ_OPF_QENC blocks carry 6 * 2^60 / (2 - 2^-13)
 
 enum WzOpKind { WZ_OP_STEM = 1, WZ_OP_DW = 2, WZ_OP_CONV = 3, WZ_OP_MBCONV = 4 };
 enum WzOutMode { WZ_OUT_ACT = 0, WZ_OUT_BOX = 1, WZ_OUT_CLS = 2, WZ_OUT_HEAD = 3 };
@@ -16,8 +16,8 @@ enum WzAct { WZ_ACT_NONE = 0, WZ_ACT_RELU6 = 1 };
 enum WzTensorFlags { WZ_TENSOR_HP = 1 };
 enum WzOpFlags {
     WZ_OPF_HP = 1, WZ_OPF_HP_OUT = 2,   // split-operand block (k_mbconv_hp.hip) / its output tensor is a hi + lo pair
-    WZ_OPF_QENC = 4,                    // ... whose chunk buffer holds the 16-bit float form of relu6(x) / 6 (the robust program; k_mbconv_hp.hip:
-                                        // depthwise weights carry 6 / K, the depthwise bias -(6 C / K) * sum of the channel's taps)
+    WZ_OPF_QENC = 4,                    // ... whose chunk buffer holds the 16-bit float form of relu6(x) / 6 (the robust program; k_hp_ops.h:
+                                        // depthwise weights carry 6 * 2^60 / (2 - 2^-13), the depthwise bias is the plain one)
     WZ_OPF_DUP_OUT = 8                  // ... whose output tensor has 2 * cout PLAIN channels holding the fp16 output twice: the 1x1 conv behind it
                                         // (Conv_1 of the robust program) has K = 2 * cout with the hi halves of its weights over the first copy and
                                         // the lo halves over the second, i.e. split WEIGHTS on the plain convolution kernels

@@ -24,7 +24,7 @@ from . import arch
 from .anchors import ssd_anchor_table
 
 MAGIC = 0x35335A57
-FORMAT_VERSION = 10
+FORMAT_VERSION = 11
 BN_EPSILON = 1e-3          # watsor/test/model/prepare.py:48
 
 DEFAULT_POST = dict(max_total=100, max_per_class=100, score_threshold=1e-8, iou_threshold=0.6,
@@ -136,8 +136,9 @@ def split_halves(w: np.ndarray):
 
 
 UNORM16_PER_6 = 65535.0 / 6.0    # the split-operand blocks keep relu6 outputs in LDS as unorm16 of x / 6
-FLOAT_FORM_C = 2.0 ** -7         # ... the robust program as a 16-bit float of t = C + (x / 6) K (3 exponent + 13 mantissa bits; k_mbconv_hp.hip)
-FLOAT_FORM_K = (2.0 - 2.0 ** -13) - FLOAT_FORM_C
+FLOAT_FORM_T = 2.0 ** -120 * (2.0 - 2.0 ** -13)   # ... the robust program as a 16-bit float: bits 10 .. 25 of the fp32 pattern of t = (x / 6) T -- exponent field
+                                                  # 0 .. 7, 13 mantissa bits, subnormal below code 8192 (csrc/k_hp_ops.h: one instruction decodes a value)
+FLOAT_FORM_TAP_SCALE = 6.0 * 2.0 ** 60 / (2.0 - 2.0 ** -13)   # what the depthwise taps of such a block carry; the kernel scales the tap sum back by 2^60
 FLOAT_FORM_LAST_BLOCK = 12       # the last block whose kernel has a float-form build (csrc/k_mbconv_hp.hip: wz_launch_mbconv_hp_q; the 10x10 maps do not)
 
 
@@ -346,11 +347,15 @@ def build_engine(weights: Dict[str, np.ndarray], precision: int = 16, model_widt
             bdp = np.zeros(cmid_pad, np.float32)
             float_form = robust and op.block <= float_form_upto
             if float_form:
-                # the buffer holds the 16-bit float form t = C + (x / 6) K (k_mbconv_hp.hip): x = (t - C) 6 / K, so the taps carry 6 / K
-                # and the bias takes -(6 C / K) * (sum of the channel's nine taps) -- exact on padding too, where t = C
+                # the buffer holds the 16-bit float form of t = (x / 6) T, T = 2^-120 (2 - 2^-13) (k_hp_ops.h): x = 6 t / T.  The factor is
+                # split -- the taps carry 6 * 2^60 / (2 - 2^-13), the kernel multiplies the tap sum by an exact 2^60 while it adds the bias --
+                # so that a large folded depthwise weight cannot overflow fp32 (6 / T alone is 4e36).  Padding is code 0 = value 0: the
+                # bias is the plain one
                 w9 = wd.reshape(9, op.cmid)
-                wdp[:, :op.cmid] = (w9 * (6.0 / FLOAT_FORM_K)).astype(np.float32)
-                bdp[:op.cmid] = bd - FLOAT_FORM_C * wdp[:, :op.cmid].astype(np.float64).sum(0)      # (of the taps as stored: fp32, with 6 / K)
+                wdp[:, :op.cmid] = (w9 * FLOAT_FORM_TAP_SCALE).astype(np.float32)
+                if not np.isfinite(wdp).all():
+                    raise ValueError("%s: a depthwise weight of %.3g does not fit the float-form scaling" % (op.scope, np.abs(w9).max()))
+                bdp[:op.cmid] = bd
             else:
                 wdp[:, :op.cmid] = (wd.reshape(9, op.cmid) / UNORM16_PER_6).astype(np.float32)
                 bdp[:op.cmid] = bd
