@@ -555,6 +555,15 @@ def config_legs(engine_path, device, rank, weights=None):
         r = throughput(eng, lambda lane, s: eng.submit_device(lane, [f720[s % 5]], [1280], [720]), 1, steps=300, warm=20)
         r["workload"] = "configs[2] share: 1 camera 1280x720, batch 1 on each of %d lanes, frames in HBM" % eng.num_slots
         legs["config3_1x720p_b1"] = r
+        h720 = synthetic_frame(1280, 720, 600)
+        if weights is not None:      # live parity of this leg's configuration (one 720p frame per batch): its rows against the oracle
+            try:
+                eng.submit_device(0, [f720[0]], [1280], [720])
+                eng.wait(0)
+                pr = rows_parity(eng.slot_rows(0, 1).copy(), [h720], weights, check=(0,))
+                r["parity"] = {k: pr[k] for k in ("max_dscore", "max_dbox_px", "frames", "rows_compared", "rows_unexplained", "within_tolerance")}
+            except Exception as e:
+                r["parity"] = dict(error=repr(e))
         # configs[3]: 32 x 1920x1080 cameras with per-camera alpha zone masks, 4 cameras per GPU: one frame of each per step
         filters = []
         masks = [synthetic_zone_mask(1920, 1080, 100 + c, 2 + c % 5) for c in range(8)]
@@ -566,6 +575,16 @@ def config_legs(engine_path, device, rank, weights=None):
         r = throughput(eng, lambda lane, s: eng.submit_device(lane, f1080[:4], [1920] * 4, [1080] * 4, cams=[0, 1, 2, 3]), 4)
         r["workload"] = "configs[3] share: 4 cameras 1920x1080, each with its alpha zone mask + sample-config thresholds (filters on), batch 4, frames in HBM"
         legs["config4_4x1080p_masks_b4"] = r
+        if weights is not None:      # live parity: one of the four 1080p frames' rows against the oracle, all four cameras' zones[] bit for bit
+            try:
+                eng.submit_device(0, f1080[:4], [1920] * 4, [1080] * 4, cams=[0, 1, 2, 3])
+                eng.wait(0)
+                got4 = eng.slot_rows(0, 4).copy()
+                pr = rows_parity(got4, h1080[:4], weights, check=(2,))
+                r["parity"] = {k: pr[k] for k in ("max_dscore", "max_dbox_px", "frames", "rows_compared", "rows_unexplained", "within_tolerance")}
+                r["parity"]["zones_bit_exact"] = zones_bit_exact(got4, [0, 1, 2, 3], {c: (1920, 1080, masks[c]) for c in range(4)})
+            except Exception as e:
+                r["parity"] = dict(error=repr(e))
         # configs[4]: 128 mixed cameras (640x480 / 1920x1080) with masks + confidence / area filters: 16 per GPU, saturation
         small_masks = [synthetic_zone_mask(640, 480, 300 + c, 2 + c % 5) for c in range(8)]
         hsmall = [synthetic_frame(640, 480, 800 + c) for c in range(8)]
@@ -1360,7 +1379,10 @@ def main():
                                  else "-p 16 (fp16 MFMA; stem + blocks 0..%d with split hi+lo operands, the rest plain fp16)" % (hp_blocks - 1)
                                  if hp_blocks else "-p 16 --plain-fp16",
                        "batch": BATCH, "frame": "%dx%d" % (WIDTH, HEIGHT), "parallelism": "replica-per-gpu x%d" % world, "batches_in_flight": lanes,
-                       "graph_nodes_per_batch": graph_nodes, "detections_per_frame": detections_per_frame},
+                       "graph_nodes_per_batch": graph_nodes, "detections_per_frame": detections_per_frame,
+                       **({"n_gpus_note": "value = %d independent replicas, each on frames resident in its own HBM: linear by construction (no collective, no "
+                                          "shared resource but the host); the shared-host measurement of an N > 1 run is legs_all_ranks_concurrently "
+                                          "(page-locked host frames, every rank at the same time)" % world} if world > 1 else {})},
             "parity": parity,
             "roofline": roof,
         }

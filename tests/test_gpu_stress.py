@@ -95,10 +95,10 @@ def test_robust_program_holds_the_tolerance_under_channel_spread(tmp_path, synth
 
 
 @pytest.mark.parametrize("batch", [1, 2, 3, 4])
-def test_robust_program_with_channel_groups_over_workgroups(tmp_path, synth_weights, batch):
-    """Few frames in a batch: the 10x10 split blocks deal their chunks out over 2 - 4 WORKGROUPS per tile whose partial sums meet through
-    the workspace (a ticket per tile, the last arriver adds the groups in order: `wz_k_mbconv_hp`'s CG builds; one frame: 3 groups for
-    block 13, 4 for blocks 14 .. 16; two and three frames: 2 - 4).  Same tolerance as any other launch shape, and the same rows every time."""
+def test_robust_program_on_few_frames(tmp_path, synth_weights, batch):
+    """Few frames in a batch -- the reference's normal load is ONE camera's frame at a time: the launch shapes that leave most of the chip
+    empty (blocks 13 .. 16 as two launches over 16 - 64 workgroups, csrc/k_mbconv_hp2.hip; rounds 4 / 5 dealt these blocks' chunks over
+    2 - 4 workgroups per tile with a ticketed cross-workgroup sum here).  Same tolerance as any other launch shape, and the same rows every time."""
     from watsor_amd.runtime import HipEngine
     from watsor_amd.share import DetectionArray
     W = spread_channel_scales(synth_weights, 1.0)

@@ -84,3 +84,27 @@ def test_resize_matches_scipy_sampling_at_the_legacy_coordinates():
         for c in range(3):
             ref = ndi.map_coordinates(img[..., c].astype(np.float64), [yy, xx], order=1, mode="nearest")
             assert np.abs(got[..., c] - ref).max() <= 2e-3      # fp32 lerps vs float64 spline evaluation on 0..255
+
+
+def test_half_pixel_resize_matches_torch_interpolate():
+    """The `half_pixel` variant of oracle/preprocess.py (graphs exported with `ResizeBilinear(half_pixel_centers=True)`: src =
+    (dst + 0.5) * scale - 0.5, clamped at the edges) against `torch.nn.functional.interpolate(mode="bilinear", align_corners=False,
+    antialias=False)` -- an independent implementation of the same coordinate rule that sits in this image (the variant
+    was pinned by hand-worked known answers only).  Up- and down-scaling, odd sizes; fp32 lerps on 0 .. 255 on both sides."""
+    import torch.nn.functional as F
+    from oracle import preprocess as pre
+    rng = np.random.Generator(np.random.PCG64(11))
+    for (w, h) in [(640, 480), (301, 299), (64, 48), (1280, 720), (300, 300)]:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        got = pre.resize_bilinear(img, 300, 300, half_pixel_centers=True)
+        x = torch.from_numpy(img.astype(np.float32)).permute(2, 0, 1)[None]
+        ref = F.interpolate(x, size=(300, 300), mode="bilinear", align_corners=False, antialias=False)[0].permute(1, 2, 0).numpy()
+        assert got.shape == ref.shape
+        # (the two compute the sample position with different roundings -- TF's three fp32 roundings against torch's scale arithmetic -- which
+        #  shows as a few 1e-3 on 0 .. 255 where neighbouring pixels differ by up to 255; the legacy rule is off by whole grey levels, below)
+        assert np.abs(got - ref).max() <= 1e-2, (w, h, np.abs(got - ref).max())
+    # ... and the legacy rule is a different function: the witness tells the two variants apart
+    img = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    ref = F.interpolate(torch.from_numpy(img.astype(np.float32)).permute(2, 0, 1)[None], size=(300, 300), mode="bilinear",
+                        align_corners=False)[0].permute(1, 2, 0).numpy()
+    assert np.abs(pre.resize_bilinear(img, 300, 300) - ref).max() > 1.0

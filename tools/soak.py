@@ -1,6 +1,6 @@
 """Soak: the same batches over all lanes for N seconds, every batch's rows compared bit for bit with the first result for those frames
 (the pipeline is deterministic: fixed summation orders everywhere).  Catches races that a single pass of the parity tests can miss.
-usage: python tools/soak.py [seconds] [--robust] [--small]     (--small: batches of 1 .. 5 frames -- the launch shapes with channel groups over workgroups)"""
+usage: python tools/soak.py [seconds] [--robust] [--small]     (--small: batches of 1 .. 5 frames -- launches that leave most of the chip empty)"""
 import os
 import sys
 import time

@@ -63,17 +63,14 @@
 // 144 / 120 of them -- so the halo fragments of ONE m-tile at a time come back from LDS inside the expand stage, and a workgroup
 // finishes NTO of the block's n-tiles: blockIdx.x % nsplit picks which (the expand and depthwise stages are repeated per group:
 // these launches have a third of a chip's worth of workgroups, the repeat costs no time and halves the accumulators).
-// CG (lean builds at two waves per SIMD: the 10x10 maps): the block's chunks are dealt out over WzMbArgs::cgroups WORKGROUPS per tile as well.
-// A workgroup of these blocks streams all of the block's split weights (1.3 MB) through one CU's vector memory path, whatever the batch
-// (profiles/r04_hp_stamps_late_blocks.txt): with G workgroups each streams a G-th.  Their partial outputs meet through the workspace: every
-// workgroup publishes its sums write-through and takes a ticket on the tile's counter; the one that finds the others there adds the groups
-// in group order (deterministic) and finishes the outputs -- the in-launch reduction of the head kernels (k_conv_rs.h), no second launch.
+// (Rounds 4 / 5 also dealt a 10x10 block's chunks over several WORKGROUPS per tile -- channel groups with a ticketed last-arriver sum -- and stored
+// block 13's second output from here; since round 6 the 10x10 blocks of the robust program run as two GEMM-shaped launches at every batch size
+// (k_mbconv_hp2.hip: faster from one frame up, profiles/r06_hp2_by_batch_size.txt) and both mechanisms left this kernel.)
 template <int NW, bool CS, bool STEM, int MPW, int MQW, int KCI, int NTO, int OCC = 2, bool ONEPASS = false, bool SH = false,
-          bool QE = false, bool LEAN = false, bool CG = false>
+          bool QE = false, bool LEAN = false>
 __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a) {
     static_assert(!LEAN || (CS && SH && !ONEPASS && !STEM), "lean: chunk-split, shared halo");
     static_assert(!LEAN || MQW == 1, "lean builds: 4 x 4 tiles (the 4 x 8 lean builds of round 5 lost their A/B: profiles/r05_blocks_13_16_tile_4x8.txt)");
-    static_assert(!CG || (LEAN && OCC == 2), "channel groups over workgroups: the lean builds of the 10x10 maps (on the 19x19 maps they lost: profiles/r05_channel_groups_19x19.txt)");
     extern __shared__ __attribute__((aligned(16))) unsigned char wz_hp_smem[];
     WZ_LANE_STAMP(a.dbg);
     const long long t_entry = WZ_HP_STAMPS ? __builtin_readcyclecounter() : 0;
@@ -104,9 +101,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
     // ---- the tile of this wave (CS: of this workgroup); wave-uniform, kept in scalar registers
     const int tiles = a.tiles_x * a.tiles_y;
     const int ngrp = LEAN ? a.nsplit : 1;                 // workgroups per tile, each with NTO of the n-tiles
-    const int cgn = CG ? a.cgroups : 1;                   // ... times that many channel groups
-    const int bidx = CG ? (int)blockIdx.x / cgn : (int)blockIdx.x;   // (tile, n-group): the unit that has one ticket counter
-    const int cg = CG ? (int)blockIdx.x - bidx * cgn : 0;
+    const int bidx = (int)blockIdx.x;                     // (tile, n-group)
     const int nt0 = LEAN ? (bidx % ngrp) * NTO : 0;
     const int wt = LEAN ? bidx / ngrp : CS ? (int)blockIdx.x : (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(wave);
     const bool live = wt < tiles * a.nb;                  // wave-uniform; dead waves still take the barrier below
@@ -139,9 +134,6 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
     // ---- halo pixels of this lane: input channels as B fragments, hi and lo
     half8_t xh[MPW][KCI], xl[MPW][KCI];
     bool inimg[MPW];
-    constexpr bool TAP = LEAN && OCC == 2 && MPW == 6;   // (the 256-register lean build of the stride-2 shape only: block 13)
-    int own2[MPW];   // lean builds with a second output (WzMbArgs::out2: block 13 of the robust program stores its expanded tensor, the first SSD
-                     // feature map): pixel offset into it for the halo pixels this tile owns (its first th * s rows / tw * s columns), else -1
     const float rcp_hw = 1.0f / (float)hw_;   // p < 96, hw_ <= 10: floor((p + 0.5) / hw_) is exact in fp32 (no integer division)
 #pragma unroll
     for (int i = 0; i < MPW; ++i) {
@@ -150,7 +142,6 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
         const int iy = iy_base + hy, ix = ix_base + hx;
         const bool ok = live && p < P && iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
         inimg[i] = ok;
-        own2[i] = (TAP && a.out2 && ok && nt0 == 0 && hy < a.th * s && hx < a.tw * s) ? (b * a.hin + iy) * a.win + ix : -1;
         if constexpr (STEM) {
             // K order of the stem GEMM in this program (engine.py: stem_k_rows): k = tap*4 + c for taps 0 .. 7, i.e. lane group
             // g holds the 4-channel pixels of taps 2g and 2g+1 exactly as they lie in the input pair tensor, and the ninth
@@ -231,8 +222,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
     const int nk32 = a.cmid_pad >> 5;                     // 32-channel chunks in all
     const int ntiles_e = a.nmid_pad >> 4;
     constexpr int STEP = CS ? NW : 1;
-    const int cpg = (nk32 + cgn - 1) / cgn;               // chunks of this workgroup: [c_lo, c_hi)
-    const int c_lo = CG ? cg * cpg : 0, c_hi = CG ? min(nk32, c_lo + cpg) : nk32;
+    const int c_lo = 0, c_hi = nk32;                      // the workgroup's chunks: all of the block's
     const int ps0 = CS ? c_lo + wave : 0;
     half8_t wah[2][KCI], wal[2][KCI];
     auto load_wa = [&](int ps) {
@@ -333,14 +323,6 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
         // ---- expand: E[p][ce] = in-frame ? unorm16(clamp((sum_k X[p][k] We[k][ce] + be[ce]) / 6, 0, 1)) : 0
         // one 16 x 4 tile of expanded values of a lane -> the chunk buffer (QE: in the float form)
         auto put = [&](float4_t d, int i, int nt, bool keep) {
-            if constexpr (TAP) {   // the second output: relu6 of the expanded value as plain fp16 (d carries the 1 / 6 of the chunk buffer)
-                if (own2[i] >= 0 && keep && ce0 + nt * 16 + g * 4 < a.cmid) {
-                    half4_t t2;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) t2[r] = (half_t)(6.0f * fminf(fmaxf(d[r], 0.0f), 1.0f));
-                    *reinterpret_cast<half4_t*>(a.out2 + (size_t)own2[i] * a.cmid + ce0 + nt * 16 + g * 4) = t2;
-                }
-            }
             wz_u32x2_t o;
             if constexpr (QE) {
                 o = wz_hp_fenc4(d);
@@ -655,62 +637,6 @@ __global__ __launch_bounds__(NW * 64, OCC) void wz_k_mbconv_hp(const WzMbArgs a)
                 for (int r = 0; r < 4; ++r) vs[k][r] += pz[r];
             }
         }
-        if constexpr (CG) {
-            if (cgn > 1) {
-                // this group's sums of the tile -> its slab of the workspace ([unit][group][MQW * NTO fragments of 1 KiB], lane l's four values
-                // at l * 16: whole lines), write-through; then the ticket
-                constexpr int FR = MQW * NTO;
-#ifdef WZ_DEV_BUILD
-                // one ticket counter per (tile, n-group) and cgn workgroups on it: the launcher's grid is exactly units x groups
-                if (threadIdx.x == 0 && (int)gridDim.x != tiles * a.nb * ngrp * cgn) __builtin_trap();
-#endif
-                float* const slab0 = a.ws + (size_t)bidx * cgn * FR * 256;
-#pragma unroll
-                for (int k = 0; k < PER; ++k) {
-                    const int pr = wave + k * NW;
-                    if (pr >= FR) break;
-                    float* const dst = slab0 + ((size_t)cg * FR + pr) * 256 + lane * 4;
-                    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(vs[k]) : "memory");
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();                       // every wave's stores have landed (and nobody reads `red` any more)
-                int* const flag = reinterpret_cast<int*>(bd_l);   // (the staged biases are dead behind the chunk loop)
-                if (threadIdx.x == 0) {
-                    int32_t* const tk = a.tickets + bidx;
-                    // (RELEASE: the slabs -- write-through stores that the barrier above saw land -- are ordered in front of the ticket by the
-                    //  memory model as well, not only by `sc1` + vmcnt(0))
-                    const int tt = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                    if (tt == cgn - 1) {
-                        __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                        // this CU reads the slabs fresh
-                    }
-                    *flag = tt;
-                }
-                __syncthreads();
-                if (*flag != cgn - 1) return;
-                // every wave reads the slabs behind an agent-scope acquire of its own (thread 0's above orders its own loads only: the other
-                // waves' would otherwise rest on the barrier + the write-through stores alone; ADVICE r4 / VERDICT r5 weak #14)
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                // the last arriver: the groups' sums in group order, all of a fragment's loads requested before the first add
-#pragma unroll
-                for (int k = 0; k < PER; ++k) {
-                    const int pr = wave + k * NW;
-                    if (pr >= FR) break;
-                    float4_t pz[4];
-#pragma unroll
-                    for (int z = 0; z < 4; ++z)
-                        pz[z] = z < cgn ? *reinterpret_cast<const float4_t*>(slab0 + ((size_t)z * FR + pr) * 256 + lane * 4) : (float4_t){0.f, 0.f, 0.f, 0.f};
-                    float4_t v = pz[0];
-#pragma unroll
-                    for (int z = 1; z < 4; ++z)
-                        if (z < cgn) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] += pz[z][r];
-                        }
-                    vs[k] = v;
-                }
-            }
-        }
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int pr = wave + k * NW;
@@ -741,11 +667,11 @@ static int wz_hp_env(const char* name, int dflt) {
 }
 
 template <int NW, bool CS, bool STEM, int MPW, int MQW, int KCI, int NTO, int OCC = 2, bool ONEPASS = false, bool SH = false,
-          bool QE = false, bool LEAN = false, bool CG = false>
+          bool QE = false, bool LEAN = false>
 static int wz_hp_launch(WzMbArgs a, int n, hipStream_t s, bool prepare) {
     if (ONEPASS && (a.cmid_pad >> 5) > NW) return -1;
     if (QE != (a.qenc != 0)) return -1;
-    if (a.has_out2 && !(LEAN && OCC == 2 && MPW == 6)) return -1;   // only the lean build of block 13's shape stores a second output
+    if (a.has_out2) return -1;   // (a second output -- block 13's expanded tensor -- is stored by the two-launch form: k_mbconv_hp2.hip)
     a.nb = n;
     if (MQW == 2) { a.th = 4; a.tw = 8; } else { a.th = 4; a.tw = 4; }
     a.tiles_y = (a.hout + a.th - 1) / a.th;
@@ -758,14 +684,13 @@ static int wz_hp_launch(WzMbArgs a, int n, hipStream_t s, bool prepare) {
     const size_t region = (size_t)(NW * EB > RED ? NW * EB : RED);
     const size_t lds = region + (size_t)a.cmid_pad * ((CS || OCC > 2) ? 8 + 36 : 8) + (SH ? (size_t)MPW * KCI * 2 * 1024 : 0);
     if ((a.cmid_pad >> 2) > NW * 64 || 9 * (a.cmid_pad >> 2) > (LEAN ? (NW >= 8 ? 5 : 9) : NW >= 8 ? 3 : 8) * NW * 64) return -1;   // the staging code's fixed trip counts
-    auto k = wz_k_mbconv_hp<NW, CS, STEM, MPW, MQW, KCI, NTO, OCC, ONEPASS, SH, QE, LEAN, CG>;
+    auto k = wz_k_mbconv_hp<NW, CS, STEM, MPW, MQW, KCI, NTO, OCC, ONEPASS, SH, QE, LEAN>;
     if (prepare) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return lds <= 160 * 1024 ? 0 : -1;
     }
     const int tiles = a.tiles_x * a.tiles_y * n;
-    if (!CG) a.cgroups = 1;
-    WZ_LAUNCH(k, dim3(CS ? tiles * a.nsplit * a.cgroups : (tiles + 3) / 4), dim3(NW * 64), lds, s, a);
+    WZ_LAUNCH(k, dim3(CS ? tiles * a.nsplit : (tiles + 3) / 4), dim3(NW * 64), lds, s, a);
     return 1;
 }
 
@@ -840,47 +765,11 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
     }
     if (a.cin0 == 0) return -1;
     if (a.wout <= 10) {
-        // 10x10 maps (blocks 13 .. 16 of the ROBUST program; the default program runs them on wz_k_mbconv_cs): lean builds, 8 waves per
-        // 4 x 4 tile, 10 n-tiles per workgroup (block 16: two workgroups per tile), LINEAR chunk buffer -- with the float form in front of
-        // them the scores do not notice which form these four blocks use (tools/err_budget.py: 6.9e-4 both ways at two decades of channel
-        // spread), and the linear one is the cheapest to decode (robust program, round 4: 17.2 / 20.9 / 20.5 / 21.3 us in the float form).
-        // Five n-tiles per workgroup and twice the workgroups was measured in round 3: blocks 14 / 15 18.9 -> 17.2 us alone, block 16
-        // 19.1 -> 34.3 us (288 workgroups that each take a whole CU: two rounds), 46.3 k -> 41.9 k frames/s (profiles/r03_robust_program.txt).
-        //
-        // Channel groups over workgroups (round 4, wz_k_mbconv_hp's CG): G workgroups per tile share the block's chunks, G the smallest number
-        // that gets a wave's chunk walk as short as a launch of at most 128 of these whole-CU workgroups allows (256 under the latency
-        // schedule).  Alone such a block is much faster (17 -> 9.5 us with 4 groups, 14 us with 2) -- but its workgroups own their CUs, and with
-        // four lanes in flight at batch 8 twice the workgroups cost more than the shorter launches bring (46.9 k -> 44.7 k frames/s with groups
-        // everywhere), so the groups are for the launches that leave the chip empty: ONE camera's frame at a time, the reference's normal
-        // load (4 groups: 10 986 -> 11 830 frames/s, p50 0.328 -> 0.300 ms), 2 frames (20.6 -> 21.6 k), 4 frames (same frames/s, p50 -3 %);
-        // batch 8 runs as before.  profiles/r04_channel_groups.txt.  WZ_HP_CGROUPS=1: never; 2 .. 4: at most that many.
-        static const int cg_env = wz_hp_env("WZ_HP_CGROUPS", 0);
-        static const int cg_cap = wz_hp_env("WZ_HP_CG_CAP", wz_latency_schedule() ? 256 : 128);   // workgroups such a launch may have
-        const int units = ((a.hout + 3) / 4) * ((a.wout + 3) / 4) * n * (nto / 10);   // (tile, n-group) pairs = ticket counters
-        int G = 1;
-        if (!prepare && a.ws && a.tickets && cg_env != 1 && units <= WZ_HP_TICKETS &&
-            (size_t)units * 4 * 10 * 1024 <= (size_t)(a.ws_bytes >> 1)) {
-            int best = (nk32 + 7) / 8;                                       // chunks a wave walks with one group
-            for (int g = 2; g <= 4; ++g) {
-                if (units * g > cg_cap || (cg_env > 1 && g > cg_env)) break;
-                const int walk = ((nk32 + g - 1) / g + 7) / 8;
-                if (walk < best) { best = walk; G = g; }
-            }
-        }
-        a.cgroups = G;
-        if (prepare) (void)wz_launch_mbconv_hp2(a, n, s, true, 0);   // (the two-launch form the engine picks from four frames up: k_mbconv_hp2.hip)
-        if (a.stride == 2) {
-            if (!(a.kc0 == 3 && nto == 10)) return -1;
-            if (prepare) (void)wz_hp_launch<8, true, false, 6, 1, 3, 10, 2, false, true, false, true, true>(a, n, s, true);
-            return G > 1 ? wz_hp_launch<8, true, false, 6, 1, 3, 10, 2, false, true, false, true, true>(a, n, s, false)
-                         : wz_hp_launch<8, true, false, 6, 1, 3, 10, 2, false, true, false, true>(a, n, s, prepare);
-        }
-        if (a.kc0 == 5 && (nto == 10 || nto == 20)) {
-            if (prepare) (void)wz_hp_launch<8, true, false, 3, 1, 5, 10, 2, false, true, false, true, true>(a, n, s, true);
-            return G > 1 ? wz_hp_launch<8, true, false, 3, 1, 5, 10, 2, false, true, false, true, true>(a, n, s, false)
-                         : wz_hp_launch<8, true, false, 3, 1, 5, 10, 2, false, true, false, true>(a, n, s, prepare);
-        }
-        return -1;
+        // 10x10 maps (blocks 13 .. 16 of the ROBUST program; the default program runs them on wz_k_mbconv_cs): two GEMM-shaped launches per block,
+        // k_mbconv_hp2.hip -- the engine asks wz_mbconv_hp2_applies() and enqueues them itself (one stage-timer slot each); this entry only
+        // prepares their kernels at load time.  (Rounds 3 .. 5 ran them here: lean builds, 8 waves per 4 x 4 tile streaming all of the block's split
+        // weights, channel groups over workgroups for few frames -- 65 us for the four at batch 8 against 42, 41 against 33 at batch 1.)
+        return prepare ? wz_launch_mbconv_hp2(a, n, s, true, 0) : -1;
     }
     if (a.wout > 19 && a.kc0 == 1 && nto == 2) {
         // Few frames (a single camera's frame at a time is the reference's normal load, detector.py:102-112): one wave per tile

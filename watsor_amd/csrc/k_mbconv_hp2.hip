@@ -7,6 +7,9 @@
 // vector-memory path (~130 GB/s: 9.6 - 10.2 us of a 16 - 19 us launch, profiles/r05_cu_stream_microbench.txt), each repeating the expand
 // GEMM on a 6 x 6 halo padded to 48 pixels for 16 outputs (3 x the matrix work), on 28 % of the CUs.  Here
 //
+// Since late round 6 this is the ONLY form of these blocks (the one-launch lean builds, their channel groups over workgroups and the ticketed
+// cross-workgroup sum left k_mbconv_hp.hip): it is the faster one at every batch size under both schedules.
+//
 //   launch A  wz_k_hp2_expdw   workgroup = (frame, band of output rows, group of NW 32-channel chunks), one chunk per WAVE:
 //             the band's input pixels (hi + lo fragments) are fetched once per workgroup and shared through LDS; a wave expands
 //             them for its 32 channels (three-term split products on v_mfma_f32_16x16x32_f16, relu6 / 6 -> unorm16 chunk buffer in
@@ -363,23 +366,16 @@ static int wz_hp2_launch_b(const WzMbArgs& a, int n, hipStream_t s, bool prepare
     return 1;
 }
 
-// Frames from which a 10x10 split block of the linear-buffer kind runs as two launches (0: never).  Below it the one-launch form with
-// channel groups over workgroups wins: a single frame's 100 pixels are 7 pixel tiles -- the GEMM shapes have nothing to spread.
-int wz_mbconv_hp2_min_frames() {
-    // (read at every call: the development library's tests switch WZ_HP2_MIN_N between engines of one process; the product library has no knobs)
-    return wz_hp2_env("WZ_HP2_MIN_N", wz_latency_schedule() ? 0 : 4);
-}
-
 // bytes of D (the depthwise output as project fragments) for n frames of this block
 static size_t wz_hp2_d_bytes(const WzMbArgs& a, int n) {
     return (size_t)((n * a.hout * a.wout + 15) >> 4) * (size_t)(a.cmid_pad >> 5) * 2048;
 }
 
-// 1: this block at this batch size takes the two-launch form (then wz_launch_mbconv_hp2 enqueues both, or one of them: `phase`)
+// 1: this block takes the two-launch form -- every 10x10 split block with the linear chunk buffer does, at every batch size (from one frame
+// up it is the faster form: 33 against 41 us for the four blocks at batch 1, 42 against 65 at batch 8, profiles/r06_hp2_by_batch_size.txt);
+// then wz_launch_mbconv_hp2 enqueues both launches, or one of them (`phase`)
 int wz_mbconv_hp2_applies(const WzMbArgs& a, int n) {
-    const int minf = wz_mbconv_hp2_min_frames();
     if (!a.hp || a.qenc || a.stem || a.cin0 == 0 || a.wout > 10 || a.hout > 10 || !a.ws || !a.we_lo || !a.wp_lo) return 0;
-    if (minf <= 0 || n < minf) return 0;
     if (a.nmid_pad != a.cmid_pad || (a.cmid_pad & 31) || a.kc != (a.cmid_pad >> 5) || a.cmid != a.cmid_pad || (a.cin0 & 31) || a.kc0 * 32 != a.cin0) return 0;
     if (wz_hp2_d_bytes(a, n) > (a.ws_bytes >> 1)) return 0;
     if (a.stride == 1 && a.kc0 == 5 && !a.has_out2) return 1;

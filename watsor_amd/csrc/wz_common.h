@@ -123,12 +123,8 @@ struct WzMbArgs {
     half_t* out2;          // chunk-split kernel: where the expanded tensor is stored as well (hin x win x cmid fp16), or nullptr
     int32_t has_out2;      // the op has such a second output (out2 itself is null while a launcher is only asked to prepare)
     int32_t qenc;          // split-operand kernel: the chunk buffer holds the 16-bit float form of v / 6 (the robust program; wd carries 6 / K, bd the offset)
-    int32_t cgroups;       // split-operand kernel, 10x10 maps: workgroups per tile that share the block's chunks (filled in by the launcher; 1 = no sharing)
-    int32_t* tickets;      // ... and their per-tile counters (the lane's block of them, zero between launches), or nullptr
     unsigned long long* dbg2;   // two-launch form (k_mbconv_hp2.hip): the second launch's stamp block (WZ_LANE_STAMPS builds), else nullptr
 };
-
-#define WZ_HP_TICKETS 4096   // per-tile counters a channel-group launch of the split-operand kernel may use (of the lane's WZ_TICKETS, wz_engine.hip)
 
 // Per-camera filter state resident in HBM (see wz_set_camera_filter).
 struct WzCamFilter {
@@ -301,7 +297,7 @@ int wz_launch_mbconv_wave(const WzMbArgs& a, int n, hipStream_t s, bool prepare)
 int wz_launch_mbconv_cs(const WzMbArgs& a, int n, hipStream_t s, bool prepare);     // channels split over waves (small maps); -2: n/a
 int wz_launch_mbconv_hp(const WzMbArgs& a, int n, hipStream_t s, bool prepare);     // split-operand blocks; -1: no kernel for this shape
 // ... the 10x10 ones of the robust program as TWO launches (k_mbconv_hp2.hip: expand + depthwise per band and chunk -> project fragments in the
-// workspace; then a plain split-operand GEMM over the whole batch's pixels).  applies: 1 = this block at this batch size takes that form.
+// workspace; then a plain split-operand GEMM over the whole batch's pixels).  applies: 1 = this block takes that form (its only one).
 // phase 0: both launches, 1: the first only, 2: the second only; prepare: kernel attributes (phase ignored).  -1: no kernel for this shape
 int wz_mbconv_hp2_applies(const WzMbArgs& a, int n);
 int wz_launch_mbconv_hp2(const WzMbArgs& a, int n, hipStream_t s, bool prepare, int phase);

@@ -48,7 +48,6 @@ int wz_set_error(int code, const char* fmt, ...) {
     } while (0)
 
 #define WZ_TICKETS 8192   // tile counters per lane: first half the tile-kernel heads, second half the small ones
-static_assert(WZ_HP_TICKETS <= WZ_TICKETS, "the split-operand blocks' channel groups count on the lane's counters");
 
 struct StageTimer {
     std::vector<hipEvent_t> ev;
@@ -338,14 +337,13 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
         } else if (op.kind == WZ_OP_MBCONV) {
             WzMbArgs a = mb_args(e, L, op);
             a.M = n * op.hout * op.wout;
-            a.ws = e->use_splitk ? L.d_ws : nullptr;
+            a.ws = (e->use_splitk || a.hp) ? L.d_ws : nullptr;   // (split-K partials of the plain blocks; the two-launch split blocks' project fragments)
             a.ws_bytes = ws_top;
-            a.tickets = e->use_splitk ? L.d_tickets : nullptr;   // (channel groups over workgroups of the 10x10 split blocks: k_mbconv_hp.hip)
             a.dbg = e->d_mbdbg ? e->d_mbdbg + (size_t)i * 16 : nullptr;
             WZ_STAMP_ARG(a);
             if (a.hp && wz_mbconv_hp2_applies(a, n)) {
-                // the 10x10 split blocks of the robust program from four frames up: two GEMM-shaped launches (k_mbconv_hp2.hip); the stage
-                // timer books the second one on the op's (otherwise empty) reduce slot
+                // the 10x10 split blocks of the robust program: two GEMM-shaped launches (k_mbconv_hp2.hip); the stage timer books the second one
+                // on the op's (otherwise empty) reduce slot
                 WZ_STAMP_ARG2(a);
                 int r2 = wz_launch_mbconv_hp2(a, n, s, false, 1);
                 if (t) t->mark();
