@@ -14,3 +14,6 @@ cp gpurun_out/$1_lanes1/rocprof_kernel_avg.json $P/rocprof_kernel_avg.json; cp g
 # round 5
 cp $S/lane_overlap_robust.txt $P/${T}_lane_overlap_robust.txt; cp $S/lane_overlap_default.txt $P/${T}_lane_overlap_default.txt; cp $S/lane_overlap_robust_one_lane.txt $P/${T}_lane_overlap_robust_one_lane.txt
 cp $S/lane_overlap_robust.json $P/lane_overlap.json; cp $S/cu_stream.txt $P/${T}_cu_stream.txt; cp $S/soak.txt $P/${T}_soak.txt
+# round 6
+cp $S/boundary_microbench.txt $P/${T}_boundary_microbench.txt; cp $S/boundary_in_engine_graph.txt $P/${T}_boundary_in_engine_graph.txt; cp $S/boundary_in_engine_eager.txt $P/${T}_boundary_in_engine_eager.txt
+cp $S/stage_table_robust_b1.txt $P/${T}_stage_table_robust_b1.txt

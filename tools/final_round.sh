@@ -21,3 +21,8 @@ timeout 200 python tools/lane_overlap.py --default-program --out $OUT/lane_overl
 WZ_LANES=1 timeout 200 python tools/lane_overlap.py --no-product --out $OUT/lane_overlap_robust_one_lane.txt > /dev/null 2>> $OUT/lane_overlap.err; grep -E "KERNELS|CU-SLOT|^run" $OUT/lane_overlap_robust_one_lane.txt
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w tools/micro/cu_stream.hip -o /tmp/cu_stream && timeout 60 /tmp/cu_stream > $OUT/cu_stream.txt 2>&1
 timeout 200 python tools/soak.py 40 --robust > $OUT/soak.txt 2>&1; timeout 100 python tools/soak.py 20 --robust --small >> $OUT/soak.txt 2>&1; tail -4 $OUT/soak.txt
+# round 6: what a kernel boundary costs -- micro-benchmark and the same measure inside the engine (stamps build), both launch paths
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -std=c++17 tools/micro/boundary.hip -o /tmp/boundary && timeout 120 /tmp/boundary > $OUT/boundary_microbench.txt 2>&1
+WZ_LANES=1 WZ_GRAPH=1 timeout 200 python tools/boundary_in_engine.py > $OUT/boundary_in_engine_graph.txt 2>&1; tail -1 $OUT/boundary_in_engine_graph.txt
+WZ_LANES=1 WZ_GRAPH=0 timeout 200 python tools/boundary_in_engine.py > $OUT/boundary_in_engine_eager.txt 2>&1; tail -1 $OUT/boundary_in_engine_eager.txt
+timeout 200 python tools/stage_table.py --robust --batch 1 --throughput > $OUT/stage_table_robust_b1.txt 2>&1; tail -2 $OUT/stage_table_robust_b1.txt
