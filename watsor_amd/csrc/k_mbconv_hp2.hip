@@ -29,22 +29,28 @@
 
 #define HP2_ES 40   // unorm16 per pixel of the chunk buffer: 32 channels + 8 of padding (as in k_mbconv_hp.hip)
 
-// S: stride; KCI: 32-channel K chunks of the expand conv; NW: waves (= chunks) per workgroup; OHR: output rows per band;
+// S: stride; KCI: 32-channel K chunks of the expand conv; NW: waves per workgroup; OHR: output rows per band;
 // MPW / MQW: 16-pixel tiles that cover a band's in-frame input pixels / its output pixels; TAP: the expanded tensor is a second output.
-template <int S, int KCI, int NW, int OHR, int MPW, int MQW, bool TAP>
+// PAIR: TWO waves per chunk (NW / 2 chunks per workgroup) -- wave 2c + h expands the 16-channel tile h of chunk c for all of the band's pixels into the
+// chunk's shared buffer and, behind a second barrier, runs the depthwise stage for every other output tile: twice the workgroups, half the serial
+// chain per wave.  For the launches that leave the chip half empty (128 workgroups of 4 waves at batch 8: a wave per SIMD on half of the CUs).
+template <int S, int KCI, int NW, int OHR, int MPW, int MQW, bool TAP, bool PAIR = false>
 __global__ __launch_bounds__(NW * 64, 2) void wz_k_hp2_expdw(const WzMbArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wz_hp2_smem[];
     WZ_LANE_STAMP(a.dbg);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int r16 = lane & 15, g = lane >> 4;
     const int nk32 = a.cmid_pad >> 5;
-    const int cgw = (nk32 + NW - 1) / NW;                 // chunk groups
+    constexpr int CPWG = PAIR ? NW / 2 : NW;              // chunks per workgroup
+    constexpr int NTW = PAIR ? 1 : 2;                     // 16-channel tiles of the chunk a wave expands
+    const int cgw = (nk32 + CPWG - 1) / CPWG;             // chunk groups
     const int nr = (a.hout + OHR - 1) / OHR;              // bands per frame
     int id = (int)blockIdx.x;
     const int cgp = id % cgw;
     id /= cgw;
     const int r = id % nr, b = id / nr;
-    const int ps = cgp * NW + wave;                       // this wave's chunk
+    const int ci = PAIR ? wave >> 1 : wave, half = PAIR ? wave & 1 : 0;
+    const int ps = cgp * CPWG + ci;                       // this wave's chunk
     const bool havec = ps < nk32;
     const int psc = havec ? ps : nk32 - 1;
     const int ce0 = psc * 32;
@@ -77,19 +83,19 @@ __global__ __launch_bounds__(NW * 64, 2) void wz_k_hp2_expdw(const WzMbArgs a) {
         }
     }
     // ---- this wave's weights: expand fragments (2 n-tiles x KCI, hi and lo), depthwise taps and both biases, all in flight together
-    half8_t wah[2][KCI], wal[2][KCI];
+    half8_t wah[NTW][KCI], wal[NTW][KCI];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const size_t off = ((size_t)(psc * 2 + nt) * a.kc0 * 64 + lane) * 8;
+    for (int nt = 0; nt < NTW; ++nt) {
+        const size_t off = ((size_t)(psc * 2 + nt + half) * a.kc0 * 64 + lane) * 8;
 #pragma unroll
         for (int c = 0; c < KCI; ++c) {
             wah[nt][c] = *reinterpret_cast<const half8_t*>(a.we + off + (size_t)c * 512);
             wal[nt][c] = *reinterpret_cast<const half8_t*>(a.we_lo + off + (size_t)c * 512);
         }
     }
-    float4_t bv[2];
+    float4_t bv[NTW];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) bv[nt] = *reinterpret_cast<const float4_t*>(a.be + ce0 + nt * 16 + g * 4);
+    for (int nt = 0; nt < NTW; ++nt) bv[nt] = *reinterpret_cast<const float4_t*>(a.be + ce0 + (nt + half) * 16 + g * 4);
     const float* const wd32 = reinterpret_cast<const float*>(a.wd);      // [9][cmid_pad], already * 6 / 65535
     const int coff = ce0 + g * 8;
     float4_t wt0[9], wt1[9];
@@ -102,52 +108,54 @@ __global__ __launch_bounds__(NW * 64, 2) void wz_k_hp2_expdw(const WzMbArgs a) {
     const float4_t b1 = *reinterpret_cast<const float4_t*>(a.bd + coff + 4);
 
     // ---- this wave's chunk buffer: zero (padding stays zero: code 0 = value 0), then the halo fragments are parked
-    unsigned char* const Eb = wz_hp2_smem + (size_t)NFRAG * 1024 + (size_t)wave * ebytes;
+    unsigned char* const Eb = wz_hp2_smem + (size_t)NFRAG * 1024 + (size_t)ci * ebytes;
     unsigned short* const E = reinterpret_cast<unsigned short*>(Eb);
-    for (int o = lane * 16; o < ebytes; o += 1024) *reinterpret_cast<wz_u32x4_t*>(Eb + o) = (wz_u32x4_t){0u, 0u, 0u, 0u};
+    for (int o = (half * 64 + lane) * 16; o < ebytes; o += (PAIR ? 2048 : 1024)) *reinterpret_cast<wz_u32x4_t*>(Eb + o) = (wz_u32x4_t){0u, 0u, 0u, 0u};
 #pragma unroll
     for (int k = 0; k < PERW; ++k) {
         const int f = wave + k * NW;
         if (f < NFRAG) *reinterpret_cast<half8_t*>(wz_hp2_smem + (size_t)f * 1024 + lane * 16) = part[k];
     }
-    __syncthreads();   // the only workgroup barrier
-    if (!havec) return;
+    __syncthreads();   // the band's fragments are in LDS, the chunk buffers zeroed
+    if (!PAIR && !havec) return;
 
     // ---- expand: E[pixel][ce] = unorm16(clamp((sum_k X[pixel][k] We[k][ce] + be[ce]) / 6, 0, 1)) for the band's in-frame pixels
     const float rcp_win = 1.0f / (float)a.win;   // p < 96, win <= 19: floor((p + 0.5) / win) is exact in fp32
 #pragma unroll
     for (int i = 0; i < MPW; ++i) {
-        if (i * 16 >= npix) break;               // (uniform)
+        if (i * 16 >= npix || !havec) break;     // (uniform)
         half8_t fh[KCI], fl[KCI];
 #pragma unroll
         for (int c = 0; c < KCI; ++c) {
             fh[c] = *reinterpret_cast<const half8_t*>(wz_hp2_smem + (size_t)((i * KCI + c) * 2) * 1024 + lane * 16);
             fl[c] = *reinterpret_cast<const half8_t*>(wz_hp2_smem + (size_t)((i * KCI + c) * 2 + 1) * 1024 + lane * 16);
         }
-        float4_t d[2] = {bv[0], bv[1]};
+        float4_t d[NTW];
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) d[nt] = bv[nt];
 #pragma unroll
         for (int c = 0; c < KCI; ++c)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) d[nt] = WZ_HP_MFMA(wal[nt][c], fh[c], d[nt]);
+            for (int nt = 0; nt < NTW; ++nt) d[nt] = WZ_HP_MFMA(wal[nt][c], fh[c], d[nt]);
 #pragma unroll
         for (int c = 0; c < KCI; ++c)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) d[nt] = WZ_HP_MFMA(wah[nt][c], fl[c], d[nt]);
+            for (int nt = 0; nt < NTW; ++nt) d[nt] = WZ_HP_MFMA(wah[nt][c], fl[c], d[nt]);
 #pragma unroll
         for (int c = 0; c < KCI; ++c)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) d[nt] = WZ_HP_MFMA(wah[nt][c], fh[c], d[nt]);
+            for (int nt = 0; nt < NTW; ++nt) d[nt] = WZ_HP_MFMA(wah[nt][c], fh[c], d[nt]);
         const int p = i * 16 + r16;
         const bool keep = p < npix;
         const int py = (int)(((float)p + 0.5f) * rcp_win), px = p - py * a.win;
         const int iy = iy0 + py;
         unsigned short* const erow = E + ((iy - ey0) * EW + px + a.pad_l) * HP2_ES + g * 4;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < NTW; ++nt) {
             wz_u32x2_t o;
             o[0] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pknorm_u16(d[nt][0], d[nt][1]));
             o[1] = __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pknorm_u16(d[nt][2], d[nt][3]));
-            if (keep) *reinterpret_cast<wz_u32x2_t*>(erow + nt * 16) = o;
+            if (keep) *reinterpret_cast<wz_u32x2_t*>(erow + (nt + half) * 16) = o;
             if constexpr (TAP) {
                 // the second output: relu6 of the expanded value as plain fp16 (d carries the 1 / 6 of the chunk buffer), for the rows this band
                 // OWNS -- [oy0 * S, (oy0 + OHR) * S): every input row exactly once over the bands
@@ -155,22 +163,27 @@ __global__ __launch_bounds__(NW * 64, 2) void wz_k_hp2_expdw(const WzMbArgs a) {
                     half4_t t2;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) t2[q] = (half_t)(6.0f * fminf(fmaxf(d[nt][q], 0.0f), 1.0f));
-                    *reinterpret_cast<half4_t*>(a.out2 + (size_t)((b * a.hin + iy) * a.win + px) * a.cmid + ce0 + nt * 16 + g * 4) = t2;
+                    *reinterpret_cast<half4_t*>(a.out2 + (size_t)((b * a.hin + iy) * a.win + px) * a.cmid + ce0 + (nt + half) * 16 + g * 4) = t2;
                 }
             }
         }
     }
-    // the wave's own LDS writes are ordered before its reads by the LDS queue; keep the compiler from moving the reads up
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if constexpr (PAIR) {
+        __syncthreads();   // both halves of every chunk buffer are written
+        if (!havec) return;
+    } else {
+        // the wave's own LDS writes are ordered before its reads by the LDS queue; keep the compiler from moving the reads up
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
 
     // ---- depthwise 3x3 in fp32 (lane = output pixel x 8 channels), relu6, split, -> D as B fragments of the project GEMM
     half_t* const D = reinterpret_cast<half_t*>(a.ws);
     const float rcp_wout = 1.0f / (float)a.wout;
     const int nout = oh * a.wout;
 #pragma unroll
-    for (int j = 0; j < MQW; ++j) {
+    for (int j = half; j < MQW; j += (PAIR ? 2 : 1)) {
         if (j * 16 >= nout) break;               // (uniform)
         const int q = j * 16 + r16;
         const bool valid = q < nout;
@@ -319,12 +332,13 @@ static int wz_hp2_env(const char* name, int dflt) {
     return (e && e[0] && atoi(e) >= 0) ? atoi(e) : dflt;
 }
 
-template <int S, int KCI, int NW, int OHR, int MPW, int MQW, bool TAP>
+template <int S, int KCI, int NW, int OHR, int MPW, int MQW, bool TAP, bool PAIR = false>
 static int wz_hp2_launch_a(const WzMbArgs& a, int n, hipStream_t s, bool prepare) {
-    auto k = wz_k_hp2_expdw<S, KCI, NW, OHR, MPW, MQW, TAP>;
+    auto k = wz_k_hp2_expdw<S, KCI, NW, OHR, MPW, MQW, TAP, PAIR>;
+    constexpr int CPWG = PAIR ? NW / 2 : NW;
     const int EW = (a.wout - 1) * S + 3, EH = (OHR - 1) * S + 3;
     const size_t ebytes = ((size_t)EH * EW * HP2_ES * 2 + 15) & ~(size_t)15;
-    const size_t lds = (size_t)MPW * KCI * 2 * 1024 + (size_t)NW * ebytes;
+    const size_t lds = (size_t)MPW * KCI * 2 * 1024 + (size_t)CPWG * ebytes;
     // every band's in-frame input pixels fit MPW tiles, its outputs MQW tiles
     const int nr = (a.hout + OHR - 1) / OHR;
     for (int r = 0; r < nr; ++r) {
@@ -340,7 +354,7 @@ static int wz_hp2_launch_a(const WzMbArgs& a, int n, hipStream_t s, bool prepare
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return 0;
     }
-    const int nk32 = a.cmid_pad >> 5, cgw = (nk32 + NW - 1) / NW;
+    const int nk32 = a.cmid_pad >> 5, cgw = (nk32 + CPWG - 1) / CPWG;
     WzMbArgs b = a;
     b.nb = n;
     WZ_LAUNCH(k, dim3(n * nr * cgw), dim3(NW * 64), lds, s, b);
@@ -386,16 +400,27 @@ int wz_mbconv_hp2_applies(const WzMbArgs& a, int n) {
 // phase 0: both launches; 1: launch A only; 2: launch B only (the engine's stage timer brackets them separately).  prepare: kernel attributes.
 int wz_launch_mbconv_hp2(const WzMbArgs& a, int n, hipStream_t s, bool prepare, int phase) {
     static const int nw1 = wz_hp2_env("WZ_HP2_NW1", 4), nw2 = wz_hp2_env("WZ_HP2_NW2", 4);
-    static const int mt = wz_hp2_env("WZ_HP2_MT", 1);   // pixel tiles per workgroup of launch B: 1 (122 registers: two workgroups per CU) or 2
+    static const int mt = wz_hp2_env("WZ_HP2_MT", 1);
+    // Two waves per chunk (PAIR: twice the workgroups, half the serial chain per wave -- launch A 7.0 -> 5.2 us at batch 8, 6.1 -> 3.8 us at batch 1) when the
+    // batch runs ALONE on the chip (WzMbArgs::lone: every other lane idle, run_batch) and the one-wave-per-chunk launch leaves at least half of the CUs empty
+    // (<= 128 workgroups of four waves: batch <= 8 on the 10x10 maps, <= 5 for block 13's bands), or when it leaves three quarters of them empty whatever the
+    // other lanes do (<= 64).  With four lanes in flight at batch 8 the pairs cost 1 % of the throughput (49.6 against 50.2 k frames/s: twice the workgroups
+    // hold the CUs), hence the condition.  Both shapes compute bit-identical tensors (a chunk's two 16-channel tiles are independent MFMA chains either way),
+    // so a batch's rows do not depend on which one ran (tests/test_gpu_variants.py: graph against kernel-by-kernel launches).
+    static const int pair_wgs = wz_hp2_env("WZ_HP2_PAIR_WGS", 128), pair_always_wgs = wz_hp2_env("WZ_HP2_PAIR_ALWAYS_WGS", 64);
+    const int nk32_ = a.cmid_pad >> 5;   // pixel tiles per workgroup of launch B: 1 (122 registers: two workgroups per CU) or 2
     int ra = 1, rb = 1;
     if (prepare || phase != 2) {
         if (a.stride == 1 && a.kc0 == 5) {
             if (prepare) {
                 (void)wz_hp2_launch_a<1, 5, 3, 5, 4, 4, false>(a, n, s, true);
                 (void)wz_hp2_launch_a<1, 5, 4, 5, 4, 4, false>(a, n, s, true);
+                (void)wz_hp2_launch_a<1, 5, 4, 5, 4, 4, false, true>(a, n, s, true);
                 (void)wz_hp2_launch_a<1, 5, 6, 5, 4, 4, false>(a, n, s, true);
                 ra = wz_hp2_launch_a<1, 5, 5, 5, 4, 4, false>(a, n, s, true);
             } else
+                if (nw1 == 4 && n * 2 * ((nk32_ + 3) / 4) <= (a.lone ? pair_wgs : pair_always_wgs)) ra = wz_hp2_launch_a<1, 5, 4, 5, 4, 4, false, true>(a, n, s, false);
+                else
                 ra = nw1 == 3 ? wz_hp2_launch_a<1, 5, 3, 5, 4, 4, false>(a, n, s, false)
                    : nw1 == 5 ? wz_hp2_launch_a<1, 5, 5, 5, 4, 4, false>(a, n, s, false)
                    : nw1 == 6 ? wz_hp2_launch_a<1, 5, 6, 5, 4, 4, false>(a, n, s, false)
@@ -404,8 +429,11 @@ int wz_launch_mbconv_hp2(const WzMbArgs& a, int n, hipStream_t s, bool prepare, 
             if (prepare) {
                 (void)wz_hp2_launch_a<2, 3, 3, 2, 6, 2, true>(a, n, s, true);
                 (void)wz_hp2_launch_a<2, 3, 4, 2, 6, 2, true>(a, n, s, true);
+                (void)wz_hp2_launch_a<2, 3, 4, 2, 6, 2, true, true>(a, n, s, true);
                 ra = wz_hp2_launch_a<2, 3, 6, 2, 6, 2, true>(a, n, s, true);
             } else
+                if (nw2 == 4 && n * 5 * ((nk32_ + 3) / 4) <= (a.lone ? pair_wgs : pair_always_wgs)) ra = wz_hp2_launch_a<2, 3, 4, 2, 6, 2, true, true>(a, n, s, false);
+                else
                 ra = nw2 == 3 ? wz_hp2_launch_a<2, 3, 3, 2, 6, 2, true>(a, n, s, false)
                    : nw2 == 6 ? wz_hp2_launch_a<2, 3, 6, 2, 6, 2, true>(a, n, s, false)
                               : wz_hp2_launch_a<2, 3, 4, 2, 6, 2, true>(a, n, s, false);

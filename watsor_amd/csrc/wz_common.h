@@ -124,6 +124,8 @@ struct WzMbArgs {
     int32_t has_out2;      // the op has such a second output (out2 itself is null while a launcher is only asked to prepare)
     int32_t qenc;          // split-operand kernel: the chunk buffer holds the 16-bit float form of v / 6 (the robust program; wd carries 6 / K, bd the offset)
     unsigned long long* dbg2;   // two-launch form (k_mbconv_hp2.hip): the second launch's stamp block (WZ_LANE_STAMPS builds), else nullptr
+    int32_t lone;               // the batch is being launched kernel by kernel because every other lane is idle (run_batch): launch shapes may use the whole chip
+                                // (only shapes whose results are bit-identical to the throughput shapes' may depend on it)
 };
 
 // Per-camera filter state resident in HBM (see wz_set_camera_filter).

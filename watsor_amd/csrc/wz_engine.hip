@@ -163,6 +163,7 @@ struct wz_engine {
         unsigned long long* h_stamps = nullptr;
         unsigned long long* m_stamps = nullptr;
         int stamp_next = 1;
+        bool lone = false;                       // the batch being enqueued goes kernel by kernel because the other lanes are idle (run_batch)
         std::map<int, std::vector<WzLaunchNote>> launch_notes;   // graph key -> what was launched, in order (grid, block, LDS, kernel)
         WzDescPack pack;                         // storage behind that node's kernelParams
         const WzFrameDesc* pre_frames = nullptr;
@@ -337,6 +338,7 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
         } else if (op.kind == WZ_OP_MBCONV) {
             WzMbArgs a = mb_args(e, L, op);
             a.M = n * op.hout * op.wout;
+            a.lone = L.lone ? 1 : 0;
             a.ws = (e->use_splitk || a.hp) ? L.d_ws : nullptr;   // (split-K partials of the plain blocks; the two-launch split blocks' project fragments)
             a.ws_bytes = ws_top;
             a.dbg = e->d_mbdbg ? e->d_mbdbg + (size_t)i * 16 : nullptr;
@@ -633,6 +635,7 @@ static int run_batch(wz_engine* e, int slot, int n) {
         L.launch_notes[key].clear();
         g_launch_sink = &L.launch_notes[key];
 #endif
+        L.lone = false;   // (a captured graph is what runs while the other lanes are busy)
         enqueue_batch(e, L, n, nullptr);
 #if WZ_LANE_STAMPS
         g_launch_sink = nullptr;
@@ -708,7 +711,9 @@ static int run_batch(wz_engine* e, int slot, int n) {
             g_launch_sink = &L.launch_notes[key];
         }
 #endif
+        L.lone = true;    // kernel by kernel: the other lanes are idle (adaptive launch), or the process runs without graphs (latency schedule, WZ_GRAPH=0)
         enqueue_batch(e, L, n, nullptr);
+        L.lone = false;
 #if WZ_LANE_STAMPS
         g_launch_sink = nullptr;
 #endif
