@@ -731,6 +731,14 @@ static int wz_launch_mbconv_hp_q(WzMbArgs a, int n, hipStream_t s, bool prepare)
 //     waves walking 6 chunks each leave most of the GPU idle) but every wave repeats the halo load and the accumulators
 //     take a trip through LDS, and with four lanes in flight CU x time is what counts: 37.2 k frames/s against 40.2 k
 //     with one wave per tile (75x75 on it as well: 35.0 k).
+// The launch shapes that lost their A/B (rounds 2 .. 5: HISTORY.md part B, each with its profile) stay reachable through their knobs in the DEVELOPMENT
+// library only: HP_DEV(...) compiles its argument there and to nothing in the product library, which instantiates the ~20 shapes its defaults can reach
+// at some batch size and nothing else (tests/test_gpu_parity.py holds the two libraries' rows bit-equal).
+#ifdef WZ_DEV_BUILD
+#define HP_DEV(...) __VA_ARGS__
+#else
+#define HP_DEV(...)
+#endif
 int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) {
     static const int cs_max_w = wz_hp_env("WZ_HP_CS_MAX_W", 19);
     static const int cs_few_wgs = wz_hp_env("WZ_HP_CS_FEW_WGS", 64);   // chunk-split when one wave per tile gives at most this many workgroups
@@ -755,13 +763,12 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
     if (a.stem) {
         if (!(a.kc0 == 1 && nto == 2 && a.stride == 1)) return -1;
         if (prepare) {
-            (void)wz_hp_launch<4, false, true, 4, 2, 1, 2, 3>(a, n, s, true);
-            (void)wz_hp_launch<4, false, true, 4, 2, 1, 2, 4>(a, n, s, true);
-            return wz_hp_launch<4, false, true, 4, 2, 1, 2>(a, n, s, true);
+            HP_DEV((void)wz_hp_launch<4, false, true, 4, 2, 1, 2, 4>(a, n, s, true); (void)wz_hp_launch<4, false, true, 4, 2, 1, 2>(a, n, s, true);)
+            return wz_hp_launch<4, false, true, 4, 2, 1, 2, 3>(a, n, s, true);
         }
-        if (occ == 3) return wz_hp_launch<4, false, true, 4, 2, 1, 2, 3>(a, n, s, false);
-        if (occ == 4) return wz_hp_launch<4, false, true, 4, 2, 1, 2, 4>(a, n, s, false);
-        return wz_hp_launch<4, false, true, 4, 2, 1, 2>(a, n, s, false);
+        HP_DEV(if (occ == 4) return wz_hp_launch<4, false, true, 4, 2, 1, 2, 4>(a, n, s, false);
+               if (occ != 3) return wz_hp_launch<4, false, true, 4, 2, 1, 2>(a, n, s, false);)
+        return wz_hp_launch<4, false, true, 4, 2, 1, 2, 3>(a, n, s, false);
     }
     if (a.cin0 == 0) return -1;
     if (a.wout <= 10) {
@@ -787,61 +794,65 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
         if (a.stride == 1) {        // 4 x 8 tiles, halo 6 x 10 = 60 pixels
             static const int cs_nw = wz_hp_env("WZ_HP_CS_NW", 3);   // 2 / 3 / 4: that many waves per tile, several chunks each (shared halo); 0: one chunk per wave
             if (prepare) {
-                (void)wz_hp_launch<2, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, true);
+                // live with the defaults: 3 waves per tile (few frames on the 75x75 map), 5 / 6 waves at four per SIMD (38x38), one wave per tile at
+                // three per SIMD (75x75 and wider) or two (a 38x38 block whose chunk count the chunk-split builds do not take)
                 (void)wz_hp_launch<3, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, true);
-                (void)wz_hp_launch<4, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, true);
                 (void)wz_hp_launch<5, true, false, 4, 2, 1, 2, 4, false, true>(a, n, s, true);
                 (void)wz_hp_launch<6, true, false, 4, 2, 1, 2, 4, false, true>(a, n, s, true);
-                (void)wz_hp_launch<5, true, false, 4, 2, 1, 2>(a, n, s, true);
-                (void)wz_hp_launch<6, true, false, 4, 2, 1, 2>(a, n, s, true);
-                (void)wz_hp_launch<5, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, true);
-                (void)wz_hp_launch<6, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, true);
                 (void)wz_hp_launch<4, false, false, 4, 2, 1, 2, 3>(a, n, s, true);
-                (void)wz_hp_launch<4, false, false, 4, 2, 1, 2, 4>(a, n, s, true);
+                HP_DEV((void)wz_hp_launch<2, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, true);
+                       (void)wz_hp_launch<4, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, true);
+                       (void)wz_hp_launch<5, true, false, 4, 2, 1, 2>(a, n, s, true);
+                       (void)wz_hp_launch<6, true, false, 4, 2, 1, 2>(a, n, s, true);
+                       (void)wz_hp_launch<5, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, true);
+                       (void)wz_hp_launch<6, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, true);
+                       (void)wz_hp_launch<4, false, false, 4, 2, 1, 2, 4>(a, n, s, true);)
                 return wz_hp_launch<4, false, false, 4, 2, 1, 2>(a, n, s, true);
             }
             static const int cs75_nw = wz_hp_env("WZ_HP_CS75_NW", 0);   // the 75x75 stride-1 block: 2 / 3 waves per tile (0: one wave per tile)
             static const int cs_occ4 = wz_hp_env("WZ_HP_CS_OCC4", 1);   // chunk-split stride-1 tiles: one chunk per wave at 128 registers (4 waves per SIMD)
-            if (!prepare && sh && a.wout > 38 && a.wout <= 75 && nk32 >= 4 && nk32 <= 6) {
+            HP_DEV(if (!prepare && sh && a.wout > 38 && a.wout <= 75 && nk32 >= 4 && nk32 <= 6) {
                 if (cs75_nw == 2) return wz_hp_launch<2, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, false);
                 if (cs75_nw == 3) return wz_hp_launch<3, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, false);
                 if (cs75_nw == 5 && nk32 <= 5) return wz_hp_launch<5, true, false, 4, 2, 1, 2, 4, false, true>(a, n, s, false);
-            }
+            })
+            (void)cs75_nw;
             if (!prepare && cs && sh && cs_occ4 && a.wout <= 38)
                 return nk32 <= 5 ? wz_hp_launch<5, true, false, 4, 2, 1, 2, 4, false, true>(a, n, s, false)
                                  : wz_hp_launch<6, true, false, 4, 2, 1, 2, 4, false, true>(a, n, s, false);
-            if (cs && sh && cs_nw == 2) return wz_hp_launch<2, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, false);
+            HP_DEV(if (cs && sh && cs_nw == 2) return wz_hp_launch<2, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, false);)
             if (cs && sh && cs_nw == 3) return wz_hp_launch<3, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, false);
-            if (cs && sh && cs_nw == 4) return wz_hp_launch<4, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, false);
-            if (cs && sh && nk32 <= 5) return wz_hp_launch<5, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, false);
-            if (cs && sh) return wz_hp_launch<6, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, false);
-            if (cs && nk32 <= 5) return wz_hp_launch<5, true, false, 4, 2, 1, 2>(a, n, s, false);
-            if (cs) return wz_hp_launch<6, true, false, 4, 2, 1, 2>(a, n, s, false);
+            HP_DEV(if (cs && sh && cs_nw == 4) return wz_hp_launch<4, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, false);
+                   if (cs && sh && nk32 <= 5) return wz_hp_launch<5, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, false);
+                   if (cs && sh) return wz_hp_launch<6, true, false, 4, 2, 1, 2, 2, false, true>(a, n, s, false);
+                   if (cs && nk32 <= 5) return wz_hp_launch<5, true, false, 4, 2, 1, 2>(a, n, s, false);
+                   if (cs) return wz_hp_launch<6, true, false, 4, 2, 1, 2>(a, n, s, false);)
             if (occ == 3) return wz_hp_launch<4, false, false, 4, 2, 1, 2, 3>(a, n, s, false);
-            if (occ == 4) return wz_hp_launch<4, false, false, 4, 2, 1, 2, 4>(a, n, s, false);
+            HP_DEV(if (occ == 4) return wz_hp_launch<4, false, false, 4, 2, 1, 2, 4>(a, n, s, false);)
             return wz_hp_launch<4, false, false, 4, 2, 1, 2>(a, n, s, false);
         }
         // stride 2: 4 x 4 tiles, halo 9 x 9 = 81 pixels
         static const int cs2_nw = wz_hp_env("WZ_HP_CS2_NW", 0);   // stride-2 blocks on maps up to WZ_HP_CS2_MAX_W: that many waves per tile
         static const int cs2_max_w = wz_hp_env("WZ_HP_CS2_MAX_W", 0);
         if (prepare) {
-            (void)wz_hp_launch<2, true, false, 6, 1, 1, 2, 2, false, true>(a, n, s, true);
-            (void)wz_hp_launch<3, true, false, 6, 1, 1, 2, 2, false, true>(a, n, s, true);
-            (void)wz_hp_launch<5, true, false, 6, 1, 1, 2>(a, n, s, true);
-            (void)wz_hp_launch<5, true, false, 6, 1, 1, 2, 2, false, true>(a, n, s, true);
-            (void)wz_hp_launch<4, false, false, 6, 1, 1, 2, 3>(a, n, s, true);
-            (void)wz_hp_launch<4, false, false, 6, 1, 1, 2, 4>(a, n, s, true);
-            return wz_hp_launch<4, false, false, 6, 1, 1, 2>(a, n, s, true);
+            (void)wz_hp_launch<5, true, false, 6, 1, 1, 2, 2, false, true>(a, n, s, true);     // (few frames)
+            HP_DEV((void)wz_hp_launch<2, true, false, 6, 1, 1, 2, 2, false, true>(a, n, s, true);
+                   (void)wz_hp_launch<3, true, false, 6, 1, 1, 2, 2, false, true>(a, n, s, true);
+                   (void)wz_hp_launch<5, true, false, 6, 1, 1, 2>(a, n, s, true);
+                   (void)wz_hp_launch<4, false, false, 6, 1, 1, 2, 4>(a, n, s, true);
+                   (void)wz_hp_launch<4, false, false, 6, 1, 1, 2>(a, n, s, true);)
+            return wz_hp_launch<4, false, false, 6, 1, 1, 2, 3>(a, n, s, true);
         }
-        if (sh && cs2_nw == 3 && a.wout <= cs2_max_w && nk32 >= 4 && nk32 <= 6)
-            return wz_hp_launch<3, true, false, 6, 1, 1, 2, 2, false, true>(a, n, s, false);
-        if (sh && cs2_nw == 2 && a.wout <= cs2_max_w && nk32 >= 3 && nk32 <= 6)
-            return wz_hp_launch<2, true, false, 6, 1, 1, 2, 2, false, true>(a, n, s, false);
+        HP_DEV(if (sh && cs2_nw == 3 && a.wout <= cs2_max_w && nk32 >= 4 && nk32 <= 6)
+                   return wz_hp_launch<3, true, false, 6, 1, 1, 2, 2, false, true>(a, n, s, false);
+               if (sh && cs2_nw == 2 && a.wout <= cs2_max_w && nk32 >= 3 && nk32 <= 6)
+                   return wz_hp_launch<2, true, false, 6, 1, 1, 2, 2, false, true>(a, n, s, false);)
+        (void)cs2_nw; (void)cs2_max_w;
         if (cs && sh && nk32 <= 5) return wz_hp_launch<5, true, false, 6, 1, 1, 2, 2, false, true>(a, n, s, false);
-        if (cs && nk32 <= 5) return wz_hp_launch<5, true, false, 6, 1, 1, 2>(a, n, s, false);
-        if (occ == 3) return wz_hp_launch<4, false, false, 6, 1, 1, 2, 3>(a, n, s, false);
-        if (occ == 4) return wz_hp_launch<4, false, false, 6, 1, 1, 2, 4>(a, n, s, false);
-        return wz_hp_launch<4, false, false, 6, 1, 1, 2>(a, n, s, false);
+        HP_DEV(if (cs && nk32 <= 5) return wz_hp_launch<5, true, false, 6, 1, 1, 2>(a, n, s, false);
+               if (occ == 4) return wz_hp_launch<4, false, false, 6, 1, 1, 2, 4>(a, n, s, false);
+               if (occ != 3) return wz_hp_launch<4, false, false, 6, 1, 1, 2>(a, n, s, false);)
+        return wz_hp_launch<4, false, false, 6, 1, 1, 2, 3>(a, n, s, false);
     }
     if (a.wout > 19) return -1;
     if (a.stride == 2) {
@@ -850,16 +861,20 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
                                                                       // each (49.8 k -> 50.5 k frames/s; 8: two waves idle, a CU per workgroup)
             static const int cs6_lean4 = wz_hp_env("WZ_HP_CS6_LEAN4", 1);   // six waves (one chunk each) at 128 registers
             if (prepare) {
-                (void)wz_hp_launch<6, true, false, 6, 1, 1, 4, 4, false, true, false, true>(a, n, s, true);
-                (void)wz_hp_launch<HP_CS_WAVES, true, false, 6, 1, 1, 4, 2, false, true>(a, n, s, true);
-                (void)wz_hp_launch<3, true, false, 6, 1, 1, 4, 2, false, true>(a, n, s, true);
-                (void)wz_hp_launch<6, true, false, 6, 1, 1, 4, 2, false, true>(a, n, s, true);
+                HP_DEV((void)wz_hp_launch<HP_CS_WAVES, true, false, 6, 1, 1, 4, 2, false, true>(a, n, s, true);
+                       (void)wz_hp_launch<3, true, false, 6, 1, 1, 4, 2, false, true>(a, n, s, true);
+                       (void)wz_hp_launch<6, true, false, 6, 1, 1, 4, 2, false, true>(a, n, s, true);
+                       (void)wz_hp_launch<HP_CS_WAVES, true, false, 6, 1, 1, 4>(a, n, s, true);)
+                return wz_hp_launch<6, true, false, 6, 1, 1, 4, 4, false, true, false, true>(a, n, s, true);
             }
-            if (sh && !prepare && cs6_lean4) return wz_hp_launch<6, true, false, 6, 1, 1, 4, 4, false, true, false, true>(a, n, s, false);
-            if (sh && !prepare && cs6_nw == 3) return wz_hp_launch<3, true, false, 6, 1, 1, 4, 2, false, true>(a, n, s, false);
-            if (sh && !prepare && cs6_nw == 6) return wz_hp_launch<6, true, false, 6, 1, 1, 4, 2, false, true>(a, n, s, false);
-            if (sh && !prepare) return wz_hp_launch<HP_CS_WAVES, true, false, 6, 1, 1, 4, 2, false, true>(a, n, s, false);
-            return wz_hp_launch<HP_CS_WAVES, true, false, 6, 1, 1, 4>(a, n, s, prepare);
+            HP_DEV(if (!(sh && cs6_lean4)) {
+                if (sh && cs6_nw == 3) return wz_hp_launch<3, true, false, 6, 1, 1, 4, 2, false, true>(a, n, s, false);
+                if (sh && cs6_nw == 6) return wz_hp_launch<6, true, false, 6, 1, 1, 4, 2, false, true>(a, n, s, false);
+                if (sh) return wz_hp_launch<HP_CS_WAVES, true, false, 6, 1, 1, 4, 2, false, true>(a, n, s, false);
+                return wz_hp_launch<HP_CS_WAVES, true, false, 6, 1, 1, 4>(a, n, s, false);
+            })
+            (void)cs6_nw; (void)cs6_lean4;
+            return wz_hp_launch<6, true, false, 6, 1, 1, 4, 4, false, true, false, true>(a, n, s, false);
         }
         return -1;
     }
@@ -867,7 +882,7 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
     // (profiles/r02r_*, A/B in one run): 8.97 against 8.0 us per block -- four more waves repeat the halo load and the
     // accumulators of twelve waves meet in LDS; the chunk walk is not what these launches wait for.  Off by default.
     static const int onepass = wz_hp_env("WZ_HP_ONEPASS", 0);
-    if (nk32 <= 12 && a.kc0 == 2 && (nto == 4 || nto == 6)) {
+    HP_DEV(if (nk32 <= 12 && a.kc0 == 2 && (nto == 4 || nto == 6)) {
         if (prepare) {
             (void)wz_hp_launch<12, true, false, 3, 1, 2, 4, 3, true>(a, n, s, true);
             (void)wz_hp_launch<12, true, false, 3, 1, 2, 6, 3, true>(a, n, s, true);
@@ -875,7 +890,8 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
             return nto == 4 ? wz_hp_launch<12, true, false, 3, 1, 2, 4, 3, true>(a, n, s, false)
                             : wz_hp_launch<12, true, false, 3, 1, 2, 6, 3, true>(a, n, s, false);
         }
-    }
+    })
+    (void)onepass;
     // 19x19 blocks: FOUR waves per tile (3 - 5 chunks each) instead of eight.  Alone a block gets slower (5.2 -> 6.5 us, 9.3 -> 11.5 us:
     // the chunk walk is longer) -- but a workgroup of four 256-register waves takes half a CU's register file, so two of them (of
     // this lane's launch or of another lane's) share a CU, where eight waves own it: 47.5 k -> 49.1 k frames/s with four lanes in
@@ -890,30 +906,31 @@ int wz_launch_mbconv_hp(const WzMbArgs& a0, int n, hipStream_t s, bool prepare) 
 #define HP_CASE(K, N)                                                                                         \
     if (a.kc0 == K && nto == N) {                                                                             \
         if (prepare) {                                                                                        \
-            (void)wz_hp_launch<8, true, false, 3, 1, K, N, 4, false, true, false, true>(a, n, s, true);      \
-            (void)wz_hp_launch<3, true, false, 3, 1, K, N, 2, false, true>(a, n, s, true);                   \
-            (void)wz_hp_launch<4, true, false, 3, 1, K, N, 2, false, true>(a, n, s, true);                   \
-            (void)wz_hp_launch<5, true, false, 3, 1, K, N, 2, false, true>(a, n, s, true);                   \
-            (void)wz_hp_launch<6, true, false, 3, 1, K, N, 2, false, true>(a, n, s, true);                   \
-            (void)wz_hp_launch<HP_CS_WAVES, true, false, 3, 1, K, N, 2, false, true>(a, n, s, true);         \
-            if (K == 2) (void)wz_hp_launch<12, true, false, 3, 1, 2, N, 3, false, true>(a, n, s, true);      \
-            return wz_hp_launch<HP_CS_WAVES, true, false, 3, 1, K, N>(a, n, s, true);                        \
+            HP_DEV((void)wz_hp_launch<3, true, false, 3, 1, K, N, 2, false, true>(a, n, s, true);            \
+                   (void)wz_hp_launch<4, true, false, 3, 1, K, N, 2, false, true>(a, n, s, true);            \
+                   (void)wz_hp_launch<5, true, false, 3, 1, K, N, 2, false, true>(a, n, s, true);            \
+                   (void)wz_hp_launch<6, true, false, 3, 1, K, N, 2, false, true>(a, n, s, true);            \
+                   (void)wz_hp_launch<HP_CS_WAVES, true, false, 3, 1, K, N, 2, false, true>(a, n, s, true);  \
+                   if (K == 2) (void)wz_hp_launch<12, true, false, 3, 1, 2, N, 3, false, true>(a, n, s, true); \
+                   (void)wz_hp_launch<HP_CS_WAVES, true, false, 3, 1, K, N>(a, n, s, true);)                 \
+            return wz_hp_launch<8, true, false, 3, 1, K, N, 4, false, true, false, true>(a, n, s, true);     \
         }                                                                                                     \
-        if (sh && cs19_lean4) {                                                                               \
-            const int r = wz_hp_launch<8, true, false, 3, 1, K, N, 4, false, true, false, true>(a, n, s, false); \
-            if (r >= 0) return r;                                                                             \
-        }                                                                                                     \
-        if (sh && cs19_nw == 3) { const int r = wz_hp_launch<3, true, false, 3, 1, K, N, 2, false, true>(a, n, s, false); if (r >= 0) return r; } \
-        if (sh && cs19_nw == 5) { const int r = wz_hp_launch<5, true, false, 3, 1, K, N, 2, false, true>(a, n, s, false); if (r >= 0) return r; } \
-        if (sh && cs19_nw == 4) { const int r = wz_hp_launch<4, true, false, 3, 1, K, N, 2, false, true>(a, n, s, false); if (r >= 0) return r; } \
-        if (sh && cs19_nw == 6) { const int r = wz_hp_launch<6, true, false, 3, 1, K, N, 2, false, true>(a, n, s, false); if (r >= 0) return r; } \
-        if (sh && w12 && K == 2) return wz_hp_launch<12, true, false, 3, 1, 2, N, 3, false, true>(a, n, s, false); \
-        if (sh) return wz_hp_launch<HP_CS_WAVES, true, false, 3, 1, K, N, 2, false, true>(a, n, s, false);    \
-        return wz_hp_launch<HP_CS_WAVES, true, false, 3, 1, K, N>(a, n, s, false);                            \
+        HP_DEV(if (!(sh && cs19_lean4)) {                                                                     \
+            if (sh && cs19_nw == 3) { const int r = wz_hp_launch<3, true, false, 3, 1, K, N, 2, false, true>(a, n, s, false); if (r >= 0) return r; } \
+            if (sh && cs19_nw == 5) { const int r = wz_hp_launch<5, true, false, 3, 1, K, N, 2, false, true>(a, n, s, false); if (r >= 0) return r; } \
+            if (sh && cs19_nw == 4) { const int r = wz_hp_launch<4, true, false, 3, 1, K, N, 2, false, true>(a, n, s, false); if (r >= 0) return r; } \
+            if (sh && cs19_nw == 6) { const int r = wz_hp_launch<6, true, false, 3, 1, K, N, 2, false, true>(a, n, s, false); if (r >= 0) return r; } \
+            if (sh && w12 && K == 2) return wz_hp_launch<12, true, false, 3, 1, 2, N, 3, false, true>(a, n, s, false); \
+            if (sh) return wz_hp_launch<HP_CS_WAVES, true, false, 3, 1, K, N, 2, false, true>(a, n, s, false); \
+            return wz_hp_launch<HP_CS_WAVES, true, false, 3, 1, K, N>(a, n, s, false);                        \
+        })                                                                                                    \
+        return wz_hp_launch<8, true, false, 3, 1, K, N, 4, false, true, false, true>(a, n, s, false);        \
     }
     HP_CASE(2, 4);
     HP_CASE(2, 6);
     HP_CASE(3, 6);
 #undef HP_CASE
+    (void)cs19_nw; (void)cs19_lean4; (void)w12; (void)sh;
     return -1;
 }
+#undef HP_DEV
