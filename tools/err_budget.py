@@ -83,6 +83,13 @@ def quant(x, mode):
         b = ((b + 512) >> 10) << 10
         tq = b.to(torch.int32).view(torch.float32).to(torch.float64)
         return (tq - c) / K * 6.0
+    if mode == "D":      # round 6's form of the same buffer (csrc/k_hp_ops.h): t = z * T, T = 2^-120 (2 - 2^-13), rounded to 13 mantissa bits; the code is
+        T = 2.0 ** -120 * (2.0 - 2.0 ** -13)   # bits 10 .. 25 of t's fp32 pattern (subnormal below 2^-7 of full scale): what `code << 10` decodes to
+        t = (torch.clamp(x, 0.0, 6.0) / 6.0 * T).to(torch.float32)
+        b = t.view(torch.int32).to(torch.int64)
+        b = ((b + 512) >> 10) << 10
+        tq = b.to(torch.int32).view(torch.float32).to(torch.float64)
+        return tq / T * 6.0
     raise ValueError(mode)
 
 
