@@ -188,3 +188,12 @@ class BalancedQueueStandIn:
 
 def spawn_context():
     return get_context("spawn")        # the reference's start method: watsor/main.py:474
+
+
+def affinity_echo(kwargs, out):
+    """Child-process half of tests/test_worker_logic.py::test_camera_affinity_travels_into_spawned_workers: what a spawned detector process
+    receives in `kwargs['hip_affinity']` -- the owner table and working queues."""
+    aff = kwargs["hip_affinity"]
+    got = aff["side"][aff["index"]].get(timeout=20)
+    aff["side"][1 - aff["index"]].put(("forwarded-by-%d" % aff["index"], got))
+    out.put((aff["index"], aff["count"], sorted(aff["owners"].items())))

@@ -317,6 +317,28 @@ def test_camera_affinity_deals_whole_cameras_and_latches_exactly_once():
     assert gauges[0][0].count.value + gauges[1][0].count.value == 24
 
 
+def test_camera_affinity_travels_into_spawned_workers():
+    """The reference starts its detectors as spawned processes (`watsor/main.py:474`): what the factory puts into `kwargs['hip_affinity']` -- the
+    owner table and one `multiprocessing.Queue` per detector -- is pickled into the child with the process's other arguments and must
+    arrive alive: a payload put by the parent reaches detector 0's side queue in the child, and what the child forwards reaches detector 1's."""
+    from watsor_amd.detection.detector import camera_affinity
+    ctx = shm.spawn_context()
+    _, cams = setup(4)
+    aff = camera_affinity(cams, 2, queue_factory=ctx.Queue)
+    out = ctx.Queue()
+    child = ctx.Process(target=shm.affinity_echo, args=({"hip_affinity": dict(aff, index=0)}, out))
+    child.start()
+    try:
+        aff["side"][0].put("payload-for-detector-0")
+        assert out.get(timeout=60) == (0, 2, [("cam0", 0), ("cam1", 1), ("cam2", 0), ("cam3", 1)])
+        assert aff["side"][1].get(timeout=20) == ("forwarded-by-0", "payload-for-detector-0")
+    finally:
+        child.join(30)
+        if child.is_alive():
+            child.terminate()
+    assert child.exitcode == 0
+
+
 def test_plain_plugin_without_batch_or_async_api():
     class Plain:
         def detect(self, shape, image, detections):
