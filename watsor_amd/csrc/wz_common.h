@@ -288,6 +288,9 @@ int wz_choose_splitk_rs_f32(int M, int n_pad, int kchunks);
 bool wz_conv_ws_f32_applies(const WzConvArgs& a);         // fp32 engine: the extras chain on the wave-split kernel
 void wz_launch_conv_ws_f32(const WzConvArgs& a, hipStream_t s);
 void wz_conv_init();
+// a 1x1 convolution and the 3x3 stride-2 convolution behind it on the small maps of the extras chain, in one launch (k_extras_pair.hip)
+bool wz_extras_pair_applies(const WzConvArgs& a, const WzConvArgs& b);
+void wz_launch_extras_pair(const WzConvArgs& a, const WzConvArgs& b, int n, hipStream_t s);
 // `-p 32` engine (k_f32.hip): fp32 activations and weights, exact-fp32 MFMA
 void wz_launch_stem_f32(const half_t* in, const float* w, const float* bias, float* out, int n, int hin, int win,
                         int hout, int wout, int pad_t, int pad_l, hipStream_t s, bool pair = false);

@@ -373,6 +373,41 @@ static void enqueue_network(wz_engine* e, Lane& L, int n, StageTimer* t, bool wi
                 wz_launch_splitk_reduce(r, L.d_ws, s);
             }
         } else {
+            // Two convolutions of the extras chain in one launch (k_extras_pair.hip): a 1x1 whose output only the 3x3 stride-2 convolution behind it
+            // reads, on the 5x5 / 3x3 / 2x2 maps -- three launches and three boundaries less per batch
+            if (!f32 && op.out_mode == WZ_OUT_ACT && op.ksize == 1 && i + 1 < e->hdr.n_ops) {
+                const WzOpDesc& nx = e->ops[i + 1];
+                bool only = nx.kind == WZ_OP_CONV && nx.src == op.dst && nx.out_mode == WZ_OUT_ACT && op.res < 0 && nx.res < 0;
+                for (uint32_t j = 0; only && j < e->hdr.n_ops; ++j)
+                    if (j != i + 1 && (e->ops[j].src == op.dst || e->ops[j].res == op.dst)) only = false;
+                if (only) {
+                    auto conv_args = [&](const WzOpDesc& o) {
+                        WzConvArgs c;
+                        memset(&c, 0, sizeof(c));
+                        c.in = L.tptr[o.src];
+                        c.w = (const half_t*)(wbase + o.w_off);
+                        c.bias = (const float*)(wbase + o.b_off);
+                        c.out = L.tptr[o.dst];
+                        c.M = n * o.hout * o.wout;
+                        c.hin = o.hin; c.win = o.win; c.cin = o.cin;
+                        c.hout = o.hout; c.wout = o.wout; c.cout = o.cout; c.n_pad = o.n_pad;
+                        c.ksize = o.ksize; c.stride = o.stride; c.pad_t = o.pad_t; c.pad_l = o.pad_l; c.kc = o.kc;
+                        c.act = o.act; c.out_mode = o.out_mode;
+                        c.kchunks = o.ksize * o.ksize * o.kc;
+                        c.splitk = 1;
+                        return c;
+                    };
+                    WzConvArgs pa = conv_args(op);
+                    const WzConvArgs pb = conv_args(nx);
+                    if (wz_extras_pair_applies(pa, pb)) {
+                        WZ_STAMP_ARG(pa);
+                        wz_launch_extras_pair(pa, pb, n, s);
+                        if (t) { t->mark(); t->mark(); t->mark(); t->mark(); }   // (both ops' slots; the launch is booked on the first)
+                        ++i;
+                        continue;
+                    }
+                }
+            }
             WzConvArgs a;
             memset(&a, 0, sizeof(a));
             a.in = L.tptr[op.src];
