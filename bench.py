@@ -254,10 +254,10 @@ def roofline_object(table, overhead, single_table, inner, robust=False):
         whole_step_us_at_hbm_peak=round(step_bytes / (HBM_PEAK_GBS * 1e9) * 1e6, 1),
         # the entries below are STATIC: read off committed profiles of round 6, not measured by this run
         static_from_profiles=True,
-        in_stream_boundary_us=2.0, boundaries_per_step=33,
-        boundary_source="profiles/r06_boundary_in_engine_graph.txt (in-kernel stamps, one lane): 65.5 us of gaps over the 33 boundaries of a lone batch; "
+        in_stream_boundary_us=2.0, boundaries_per_step=30,
+        boundary_source="profiles/r06zz_boundary_in_engine_graph.txt (in-kernel stamps, one lane): 60.9 us of gaps over the 30 boundaries of a lone batch; "
                         "profiles/r06_boundary_microbench.txt: 1.05 us between trivial kernels of a captured graph on the same box, + 0.125 us per MB the predecessor leaves dirty",
-        frac_ceiling_of_one_lane_with_free_kernels=round(step_bytes / (HBM_PEAK_GBS * 1e9) * 1e6 / (step_bytes / (HBM_PEAK_GBS * 1e9) * 1e6 + 66.0), 3),
+        frac_ceiling_of_one_lane_with_free_kernels=round(step_bytes / (HBM_PEAK_GBS * 1e9) * 1e6 / (step_bytes / (HBM_PEAK_GBS * 1e9) * 1e6 + 61.0), 3),
         cu_stream_gbs=130.0,
         cu_stream_source="profiles/r05_cu_stream_microbench.txt (tools/micro/cu_stream.hip): one CU pulls L2-resident bytes at 110 - 143 GB/s -- what sized the "
                          "two-launch form of blocks 13 .. 16 (<= 0.25 MB per workgroup instead of 1.2 - 1.8 MB)")
