@@ -117,3 +117,29 @@ def test_two_launch_form_is_what_runs(model_dir_robust):
     assert p.returncode == 0, p.stderr[-1500:]
     out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert out == {"8": 31, "1": 31}, out
+
+
+def test_small_batch_tile_shape_changes_no_bit(model_dir_robust, frames_640, monkeypatch):
+    """One or two frames per batch: the robust program's stride-1 blocks of the 75x75 and 38x38 maps (blocks 2, 4, 5) run on 4 x 4 tiles instead of 4 x 8
+    (csrc/k_mbconv_hp.hip, wz_launch_mbconv_hp_q: twice the workgroups on grids that fill a fifth of the chip).  A tile shape only decides which lane holds a
+    pixel: every tensor of the network, the box encodings and the class logits are the same bit for bit with the shape forced off and on."""
+    x_half = pu.oracle_input_half(frames_640[:2])
+    monkeypatch.setenv("WZ_NO_BUFFER_REUSE", "1")
+
+    def run(knob):
+        monkeypatch.setenv("WZ_HP_TILES44", knob)
+        e = conftest.make_engine(model_dir_robust, max_batch=2, dev=True)
+        try:
+            be, lg = e.stage_forward(x_half)
+            tensors = {name: np.stack([e.stage_read_tensor(idx, f) for f in range(2)]) for idx, (name, h, w, c) in enumerate(e.tensors()) if name != "input"}
+            return be, lg, tensors
+        finally:
+            e.close()
+
+    be0, lg0, t0 = run("0")
+    be1, lg1, t1 = run("1")
+    assert any(k.endswith("expanded_conv_2/output") for k in t0)
+    for k in t0:
+        np.testing.assert_array_equal(t0[k].view(np.uint16), t1[k].view(np.uint16), err_msg=k)
+    np.testing.assert_array_equal(be0, be1)
+    np.testing.assert_array_equal(lg0, lg1)

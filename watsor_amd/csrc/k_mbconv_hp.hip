@@ -700,6 +700,14 @@ static int wz_launch_mbconv_hp_q(WzMbArgs a, int n, hipStream_t s, bool prepare)
     const int nto = a.n_pad / 16;
     a.nsplit = 1;
     if (a.nmid_pad != a.cmid_pad || (a.cmid_pad & 31) || a.kc != (a.cmid_pad >> 5) || !a.we_lo || !a.wp_lo) return -1;
+    // One or two frames per batch: 4 x 4 tiles instead of 4 x 8 on the stride-1 blocks of the 75x75 and 38x38 maps (block 2; blocks 4 / 5), whose 4 x 8 grids are
+    // 48 - 95 / 50 - 100 workgroups then.  Twice the waves, 36 halo pixels each instead of 60, the same arithmetic in the same order for every output pixel
+    // (bit-identical tensors: a tile shape only decides which lane holds a pixel).  Batch 1: block 2 10.4 -> 7.4 us, blocks 4 / 5 5.0 / 4.5 -> 3.1 / 2.9 us, a single
+    // frame's p50 0.269 -> 0.262 ms and +2.5 % frames/s from four lanes; batch 2 the same; from three frames up the 20 % more halo work costs what the fuller grid
+    // gains (batch 4: p50 -2 us, -0.6 % frames/s; batch 6: -2 % frames/s), and block 0's 150x150 grid is large enough at batch 1 (4.9 -> 5.9 us with 4 x 4):
+    // profiles/r06_small_batch_tiles_4x4.txt.  WZ_HP_TILES44=0 / 1: never / always (development library; read per launch).
+    const int tiles44 = wz_hp_env("WZ_HP_TILES44", 2);
+    auto small44 = [&]() { return tiles44 == 1 || (tiles44 == 2 && n <= 2); };
     if (a.stem) {
         if (!(a.kc0 == 1 && nto == 2 && a.stride == 1)) return -1;
         return wz_hp_launch<4, false, true, 4, 2, 1, 2, 3, false, false, true>(a, n, s, prepare);
@@ -708,8 +716,16 @@ static int wz_launch_mbconv_hp_q(WzMbArgs a, int n, hipStream_t s, bool prepare)
     if (a.wout > 19 && a.kc0 == 1 && nto == 2) {
         const int nk32 = a.cmid_pad >> 5;
         if (a.stride == 2) return wz_hp_launch<4, false, false, 6, 1, 1, 2, 3, false, false, true>(a, n, s, prepare);
-        if (a.wout <= 38 && nk32 == 6) return wz_hp_launch<6, true, false, 4, 2, 1, 2, 4, false, true, true>(a, n, s, prepare);
+        if (a.wout <= 38 && nk32 == 6) {
+            if (prepare && wz_hp_launch<6, true, false, 3, 1, 1, 2, 4, false, true, true>(a, n, s, true) < 0) return -1;
+            if (!prepare && small44()) return wz_hp_launch<6, true, false, 3, 1, 1, 2, 4, false, true, true>(a, n, s, false);
+            return wz_hp_launch<6, true, false, 4, 2, 1, 2, 4, false, true, true>(a, n, s, prepare);
+        }
         if (a.wout <= 38 && nk32 >= 4 && nk32 <= 5) return wz_hp_launch<3, true, false, 4, 2, 1, 2, 2, false, true, true>(a, n, s, prepare);
+        if (a.wout > 38) {
+            if (prepare && wz_hp_launch<4, false, false, 3, 1, 1, 2, 3, false, false, true>(a, n, s, true) < 0) return -1;
+            if (!prepare && small44()) return wz_hp_launch<4, false, false, 3, 1, 1, 2, 3, false, false, true>(a, n, s, false);
+        }
         return wz_hp_launch<4, false, false, 4, 2, 1, 2, 3, false, false, true>(a, n, s, prepare);
     }
     if (a.wout > 10) {
