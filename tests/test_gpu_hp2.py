@@ -138,8 +138,48 @@ def test_small_batch_tile_shape_changes_no_bit(model_dir_robust, frames_640, mon
 
     be0, lg0, t0 = run("0")
     be1, lg1, t1 = run("1")
-    assert any(k.endswith("expanded_conv_2/output") for k in t0)
+    assert "expanded_conv_2/output" in t0
     for k in t0:
         np.testing.assert_array_equal(t0[k].view(np.uint16), t1[k].view(np.uint16), err_msg=k)
     np.testing.assert_array_equal(be0, be1)
     np.testing.assert_array_equal(lg0, lg1)
+
+
+def test_large_batch_shapes_of_the_early_blocks_tensor_by_tensor(model_dir_robust, oracle_net, frames_640, monkeypatch):
+    """The tensor-by-tensor tests run two frames, and at one or two frames per batch blocks 1 .. 3 take the chunk-split shape and blocks 4 / 5 the 4 x 4 tiles
+    (csrc/k_mbconv_hp.hip, wz_launch_mbconv_hp_q).  This test switches both rules off (WZ_HP_SMALL_CS=0, WZ_HP_TILES44=0: the shapes of batches >= 3, the
+    benchmarked ones) and holds the outputs of blocks 0 .. 5 against the fp32 oracle at the pair-tensor bound of
+    tests/test_gpu_parity.py::test_both_programs_close_to_oracle_tensor_by_tensor (5e-4 of the range), and against the small-batch shapes at a tenth of that
+    (5e-5 of the range: the chunk-split shape sums a tile's chunks in wave order, an fp32 rounding that the hi + lo split and the next blocks carry on)."""
+    x_half = pu.oracle_input_half(frames_640[:2])
+    rbe, rlg, T = pu.oracle_forward_from_half(oracle_net, x_half, keep=True)
+    monkeypatch.setenv("WZ_NO_BUFFER_REUSE", "1")
+    want = ["expanded_conv/output"] + ["expanded_conv_%d/output" % i for i in range(1, 6)]
+
+    def run(cs, t44):
+        monkeypatch.setenv("WZ_HP_SMALL_CS", cs)
+        monkeypatch.setenv("WZ_HP_TILES44", t44)
+        e = conftest.make_engine(model_dir_robust, max_batch=2, dev=True)
+        try:
+            be, lg = e.stage_forward(x_half)
+            out = {}
+            for idx, (name, h, w, c) in enumerate(e.tensors()):
+                if name in want:
+                    assert e.tensor_is_pair(idx)
+                    out[name] = (np.stack([e.stage_read_tensor(idx, f) for f in range(2)]).astype(np.float32), name)
+            return out, be, lg
+        finally:
+            e.close()
+
+    big, be_b, lg_b = run("0", "0")
+    small, be_s, lg_s = run("2", "2")
+    assert sorted(big) == sorted(want)
+    for k in want:
+        got, name = big[k]
+        ref = T[name]
+        scale = np.abs(ref).max()
+        assert np.abs(got - ref).max() <= 5e-4 * scale + 1e-4, k
+        assert np.abs(got - small[k][0]).max() <= 5e-5 * scale, "%s: %.3g of %.3g" % (k, np.abs(got - small[k][0]).max(), scale)
+    assert np.abs(lg_b - lg_s).max() <= 2e-3 and np.abs(be_b - be_s).max() <= 2e-3
+    from oracle.postprocess import sigmoid
+    assert np.abs(sigmoid(lg_b) - sigmoid(rlg)).max() <= 1e-3

@@ -715,6 +715,28 @@ static int wz_launch_mbconv_hp_q(WzMbArgs a, int n, hipStream_t s, bool prepare)
     if (a.cin0 == 0) return -1;
     if (a.wout > 19 && a.kc0 == 1 && nto == 2) {
         const int nk32 = a.cmid_pad >> 5;
+        // One or two frames per batch, blocks 1 .. 3 (150 -> 75 stride 2, 75x75 stride 1, 75 -> 38 stride 2): the chunks of a 4 x 4 tile dealt over the waves of a
+        // workgroup -- one chunk per wave, halo fetched once and shared through LDS, partial accumulators summed through LDS in wave order: the shape of the
+        // 38x38 / 19x19 blocks -- instead of one wave per tile walking 3 - 5 chunks: 3 - 5 times the waves on grids of 25 - 95 workgroups.  Batch 1: blocks 1 / 2 / 3
+        // 6.4 / 7.2 / 8.5 -> 4.3 / 3.9 / 3.7 us, a single frame's p50 0.263 -> 0.254 ms, +3 % frames/s from four lanes; batch 2: p50 0.272 -> 0.264 ms.  From
+        // three frames up the repeated halo work and the accumulators' trip through LDS cost more CU time than the chip has to spare (batch 3: p50 -4 us, -5 %
+        // frames/s; batch 4: -8 %): profiles/r06_small_batch_chunk_split.txt.  The sum over a tile's chunks is taken in another order than at batch >= 3 (fp32
+        // partials in wave order instead of one running accumulator): tensors agree to fp32 rounding, not bit for bit -- as batch sizes differ elsewhere
+        // (split-K choices follow the pixel count).  WZ_HP_SMALL_CS=0 / 1: never / always (development library; read per launch).
+        const int small_cs = wz_hp_env("WZ_HP_SMALL_CS", 2);
+        const bool scs = small_cs == 1 || (small_cs == 2 && n <= 2);
+        if (a.stride == 2 && nk32 == 3) {
+            if (prepare && wz_hp_launch<3, true, false, 6, 1, 1, 2, 3, true, true, true>(a, n, s, true) < 0) return -1;
+            if (!prepare && scs) return wz_hp_launch<3, true, false, 6, 1, 1, 2, 3, true, true, true>(a, n, s, false);
+        }
+        if (a.stride == 2 && nk32 == 5) {
+            if (prepare && wz_hp_launch<5, true, false, 6, 1, 1, 2, 3, true, true, true>(a, n, s, true) < 0) return -1;
+            if (!prepare && scs) return wz_hp_launch<5, true, false, 6, 1, 1, 2, 3, true, true, true>(a, n, s, false);
+        }
+        if (a.stride == 1 && a.wout > 38 && nk32 == 5) {
+            if (prepare && wz_hp_launch<5, true, false, 3, 1, 1, 2, 3, true, true, true>(a, n, s, true) < 0) return -1;
+            if (!prepare && scs) return wz_hp_launch<5, true, false, 3, 1, 1, 2, 3, true, true, true>(a, n, s, false);
+        }
         if (a.stride == 2) return wz_hp_launch<4, false, false, 6, 1, 1, 2, 3, false, false, true>(a, n, s, prepare);
         if (a.wout <= 38 && nk32 == 6) {
             if (prepare && wz_hp_launch<6, true, false, 3, 1, 1, 2, 4, false, true, true>(a, n, s, true) < 0) return -1;
