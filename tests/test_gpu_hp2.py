@@ -180,6 +180,8 @@ def test_large_batch_shapes_of_the_early_blocks_tensor_by_tensor(model_dir_robus
         scale = np.abs(ref).max()
         assert np.abs(got - ref).max() <= 5e-4 * scale + 1e-4, k
         assert np.abs(got - small[k][0]).max() <= 5e-5 * scale, "%s: %.3g of %.3g" % (k, np.abs(got - small[k][0]).max(), scale)
-    assert np.abs(lg_b - lg_s).max() <= 2e-3 and np.abs(be_b - be_s).max() <= 2e-3
+    # (behind the pair tensors the network rounds to fp16 per layer: an fp32 rounding upstream moves single fp16 steps downstream)
+    d_lg, d_be = np.abs(lg_b - lg_s).max(), np.abs(be_b - be_s).max()
+    assert d_lg <= 6e-3 and d_be <= 6e-3, (d_lg, d_be)
     from oracle.postprocess import sigmoid
-    assert np.abs(sigmoid(lg_b) - sigmoid(rlg)).max() <= 1e-3
+    assert np.abs(sigmoid(lg_b) - sigmoid(rlg)).max() <= 1e-3 and np.abs(sigmoid(lg_s) - sigmoid(rlg)).max() <= 1e-3
