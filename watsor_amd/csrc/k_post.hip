@@ -974,11 +974,33 @@ __global__ __launch_bounds__(NMS_THREADS) void wz_k_nms(WzPostBuffers b, WzPostC
                 // the grouped head reduce marked every class logit >= wz_logit_floor(hint) of this frame while it still
                 // had it in registers: the first band [hint, 1024) needs no scan of the logits, only of the bit map
                 // (22 KiB per frame; read and cleared here).  Same tests as wz_nms_scan_band.
-                if (tid == 0) S->ncand = 0;
+                if (tid == 0) { S->ncand = 0; S->pad[0] = 0; }
                 __syncthreads();
                 const int C = k.num_classes, n_entries = k.num_anchors * C, words = (n_entries + 31) >> 5;
                 uint32_t* const bits = b.cbits + (size_t)f * words;   // (words <= WPT * NMS_THREADS: checked by the launcher)
                 const float* __restrict__ lg = b.logits + (size_t)f * n_entries;
+                // one listed entry: the tests of wz_nms_scan_band, the key into the band's list
+                auto take = [&](int j) {
+                    const int a = j / C, col = j - a * C;
+                    const float x = lg[j];                      // both loads issued before either is used
+                    const uint8_t ok = b.valid[(size_t)f * k.num_anchors + a];
+                    if (col == 0 || !ok) return;
+                    const float sc = wz_sigmoid(x);
+                    if (!(sc > k.score_thr)) return;
+                    const uint32_t key = __float_as_uint(sc);
+                    const int bin = (int)(key >> 20);
+                    if (bin < lo_bin || bin >= hi_bin) return;
+                    const uint32_t tie = (uint32_t)(col - 1) * (uint32_t)k.num_anchors + (uint32_t)a;
+                    const uint32_t pos = atomicAdd(&S->ncand, 1u);
+                    if (pos < WZ_CAND_CAP)
+                        S->keys[pos] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - tie);
+                };
+                // Two passes since late round 6.  A thread that found several bits in its words used to walk them one after the other, a global round trip
+                // (logit + validity byte) each -- the slowest thread's chain was 2 - 4 of them (6 - 8 us).  Now the set bits are first written as entry numbers
+                // into LDS (the rank sort's destination buffer is idle here: 8 192 entries), then dealt out one per thread: ONE round trip for all of them.
+                // Which thread takes which entry changes nothing: the band's list is sorted on unique keys before anything reads it.
+                uint32_t* const elist = reinterpret_cast<uint32_t*>(S->keys2);
+                constexpr uint32_t ELIST_CAP = 2 * WZ_CAND_CAP;
 #pragma unroll
                 for (int u = 0; u < WPT; ++u) {
                     const int w = tid + u * NMS_THREADS;
@@ -987,21 +1009,14 @@ __global__ __launch_bounds__(NMS_THREADS) void wz_k_nms(WzPostBuffers b, WzPostC
                     while (m) {
                         const int j = w * 32 + __builtin_ctz(m);
                         m &= m - 1;
-                        const int a = j / C, col = j - a * C;
-                        const float x = lg[j];                      // both loads issued before either is used
-                        const uint8_t ok = b.valid[(size_t)f * k.num_anchors + a];
-                        if (col == 0 || !ok) continue;
-                        const float sc = wz_sigmoid(x);
-                        if (!(sc > k.score_thr)) continue;
-                        const uint32_t key = __float_as_uint(sc);
-                        const int bin = (int)(key >> 20);
-                        if (bin < lo_bin || bin >= hi_bin) continue;
-                        const uint32_t tie = (uint32_t)(col - 1) * (uint32_t)k.num_anchors + (uint32_t)a;
-                        const uint32_t pos = atomicAdd(&S->ncand, 1u);
-                        if (pos < WZ_CAND_CAP)
-                            S->keys[pos] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - tie);
+                        const uint32_t q = atomicAdd(reinterpret_cast<uint32_t*>(&S->pad[0]), 1u);
+                        if (q < ELIST_CAP) elist[q] = (uint32_t)j;
+                        else take(j);                               // (more listed entries than the buffer holds: the old way, nothing is lost)
                     }
                 }
+                __syncthreads();
+                const uint32_t nl = min((uint32_t)S->pad[0], ELIST_CAP);
+                for (uint32_t q = tid; q < nl; q += NMS_THREADS) take((int)elist[q]);
                 __syncthreads();
                 cnt = S->ncand;
                 __syncthreads();
